@@ -1,0 +1,106 @@
+"""Deterministic synthetic weights and inputs (no checkpoints / datasets are reachable here).
+
+Every tensor is generated from (seed, crc32(key)) with a per-key scale chosen so that
+activations stay O(1) through the conv / transformer stacks and the logits have a usable
+top-1 margin (needed for token-exact greedy parity, SURVEY.md section 7 "Hard parts").
+The same recipe feeds the reference (in tests/golden/make_golden.py), the CPU oracle and
+the HIP path, so only seeds - never weights - are committed.
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from typing import Dict
+
+import torch
+
+from .spec import VaeConfig, VarConfig, vae_state_shapes, var_state_shapes
+
+
+def _gen(seed: int, key: str) -> torch.Generator:
+    g = torch.Generator(device='cpu')
+    g.manual_seed((int(seed) * 1000003 + zlib.crc32(key.encode())) & 0x7FFFFFFFFFFF)
+    return g
+
+
+def _randn(shape, g, std=1.0, mean=0.0):
+    return torch.randn(shape, generator=g, dtype=torch.float32) * std + mean
+
+
+def synth_var_state(cfg: VarConfig, seed: int = 0, head_gain: float = 4.0) -> Dict[str, torch.Tensor]:
+    """state_dict for ControlVAR / VAR with the key set of spec.var_state_shapes()."""
+    C = cfg.C
+    py = cfg.pyramid
+    out: Dict[str, torch.Tensor] = {}
+    for key, (shape, kind) in var_state_shapes(cfg).items():
+        g = _gen(seed, key)
+        if key == 'lvl_1L':
+            out[key] = torch.from_numpy(py.level_of_token()).view(1, -1)
+        elif key == 'attn_bias_for_masking':
+            lvl = torch.from_numpy(py.level_of_token())
+            d = lvl.view(1, py.L, 1)
+            out[key] = torch.where(d >= d.transpose(1, 2), 0.0, -torch.inf).reshape(1, 1, py.L, py.L).contiguous()
+        elif key.endswith('zero_k_bias'):
+            out[key] = torch.zeros(shape)
+        elif key.endswith('scale_mul_1H11'):
+            out[key] = _randn(shape, g, std=0.3, mean=math.log(4.0))
+        elif key in ('pos_start', 'pos_1LC', 'lvl_embed.weight', 'cond_embed.weight'):
+            out[key] = _randn(shape, g, std=0.5)
+        elif key == 'class_emb.weight':
+            out[key] = _randn(shape, g, std=1.0)
+        elif key.endswith('ada_lin.1.weight'):
+            out[key] = _randn(shape, g, std=0.4 / math.sqrt(C))
+        elif key.endswith('ada_lin.1.bias'):
+            b = _randn(shape, g, std=0.1)
+            if key.startswith('blocks.'):
+                b[:2 * C] += 0.35            # gamma1, gamma2 rows: residual gates around 0.35
+            out[key] = b
+        elif key == 'head.weight':
+            out[key] = _randn(shape, g, std=head_gain / math.sqrt(C))
+        elif key.endswith('.weight') and len(shape) == 2:
+            out[key] = _randn(shape, g, std=1.0 / math.sqrt(shape[1]))
+        elif key.endswith('bias') or key.endswith('q_bias') or key.endswith('v_bias'):
+            out[key] = _randn(shape, g, std=0.05)
+        else:
+            raise KeyError(key)
+        assert tuple(out[key].shape) == tuple(shape), key
+    return out
+
+
+def synth_vae_state(cfg: VaeConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """state_dict for VQVAE with the key set of spec.vae_state_shapes()."""
+    out: Dict[str, torch.Tensor] = {}
+    for key, (shape, kind) in vae_state_shapes(cfg).items():
+        g = _gen(seed, key)
+        if key == 'quantize.ema_vocab_hit_SV':
+            out[key] = torch.zeros(shape)
+        elif key == 'quantize.embedding.weight':
+            out[key] = _randn(shape, g, std=0.6)
+        elif '.norm' in key and key.endswith('.weight'):
+            out[key] = _randn(shape, g, std=0.1, mean=1.0)
+        elif '.norm' in key and key.endswith('.bias'):
+            out[key] = _randn(shape, g, std=0.1)
+        elif key.endswith('.weight') and len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            gain = 1.0
+            if key.startswith('quantize.quant_resi'):
+                gain = 0.7
+            elif 'conv_out' in key:
+                gain = 1.5
+            out[key] = _randn(shape, g, std=gain / math.sqrt(fan_in))
+        elif key.endswith('.bias'):
+            out[key] = _randn(shape, g, std=0.05)
+        else:
+            raise KeyError(key)
+        assert tuple(out[key].shape) == tuple(shape), key
+    return out
+
+
+def synth_images(batch: int, size: int = 256, seed: int = 0) -> torch.Tensor:
+    """(B,3,size,size) fp32 in [-1,1]: smooth low-frequency field + uniform noise
+    (SURVEY.md section 8(c) G1 / 8(d) configs 1,5)."""
+    g = _gen(seed, f'images{size}')
+    low = torch.rand((batch, 3, 8, 8), generator=g) * 2 - 1
+    smooth = torch.nn.functional.interpolate(low, size=(size, size), mode='bilinear', align_corners=False)
+    noise = torch.rand((batch, 3, size, size), generator=g) * 2 - 1
+    return (0.75 * smooth + 0.25 * noise).clamp_(-1, 1).contiguous()

@@ -1,0 +1,317 @@
+#!/usr/bin/env python3
+"""Golden-vector generator (runs ONLY in the build container, where /root/reference exists).
+
+Imports the reference's own ``models`` package (read-only, no bytecode written), loads the
+deterministic synthetic weights of controlvar_amd.synth into the REFERENCE modules
+(strict=True, which also pins controlvar_amd.spec's key/shape tables), runs the reference
+and records its outputs as small fixtures under tests/golden/*.npz.  Only inputs' seeds and
+the reference's outputs are stored - no reference source, no weights.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [case ...]
+
+The reference has no tests or golden vectors of its own, so these
+fixtures are what pins oracle/ (tests/test_oracle_*.py) and, through it, the HIP path.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import sys
+import time
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, '/root/reference')
+
+import numpy as np
+import torch
+
+import models as ref_models                                    # the reference
+import models.control_var as ref_cv
+import models.var as ref_v
+from models import VQVAE, build_control_var, build_var
+from models.control_var import ControlVAR
+
+from controlvar_amd.spec import DEFAULT_PATCH_NUMS, VaeConfig, VarConfig
+from controlvar_amd.synth import synth_images, synth_vae_state, synth_var_state
+
+torch.set_num_threads(8)
+PN = DEFAULT_PATCH_NUMS
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **{k: (v.numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrs.items()})
+    print(f'  wrote {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+def make_vae(ch, seed=0):
+    vae = quiet(VQVAE, vocab_size=4096, z_channels=32, ch=ch, test_mode=True, share_quant_resi=4, v_patch_nums=PN)
+    vae.load_state_dict(synth_vae_state(VaeConfig(ch=ch), seed), strict=True)
+    return vae.eval()
+
+
+def make_cvar(vae, cfg: VarConfig, seed=0):
+    if cfg.control:
+        if cfg.embed_dim:   # explicit small width (used for the depth==30 cos-attn case)
+            m = quiet(ControlVAR, vae_local=vae, patch_nums=PN, depth=cfg.depth, embed_dim=cfg.C, num_heads=cfg.H,
+                      flash_if_available=False, fused_if_available=False, mask_factor=cfg.mask_factor,
+                      bidirectional=False, separate_decoding=False, separator=False, type_pos=False, indep=False,
+                      multi_cond=cfg.multi_cond, cond_drop_rate=0.0)
+        else:
+            m = quiet(build_control_var, vae, depth=cfg.depth, patch_nums=PN, mask_type='interleave_append' if cfg.mask_factor == 2 else 'replace',
+                      cond_drop_rate=0.0, multi_cond=cfg.multi_cond, flash_if_available=False, fused_if_available=False)
+    else:
+        m = quiet(build_var, vae, depth=cfg.depth, patch_nums=PN, flash_if_available=False, fused_if_available=False)
+        m.cond_drop_rate = 0.0
+    m.load_state_dict(synth_var_state(cfg, seed), strict=True)
+    return m.eval()
+
+
+class CaptureIdx:
+    """Record the ids returned by sample_with_top_k_top_p_ at every stage (the ids BEFORE
+    conditional_infer_cfg's teacher-forcing overwrite) and the CFG-combined logits."""
+
+    def __init__(self, module):
+        self.module, self.orig = module, module.sample_with_top_k_top_p_
+        self.idx, self.logit_samples, self.margins = [], [], []
+
+    def __enter__(self):
+        def wrapped(logits, *a, **k):
+            lg = logits.detach().clone()
+            t2 = lg.topk(2, dim=-1).values
+            self.margins.append((t2[..., 0] - t2[..., 1]).clone())
+            self.logit_samples.append(lg[:2, :, ::128].clone())
+            out = self.orig(logits, *a, **k)
+            self.idx.append(out[:, :, 0].clone())
+            return out
+        self.module.sample_with_top_k_top_p_ = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        self.module.sample_with_top_k_top_p_ = self.orig
+
+
+def img_stats(img):
+    return dict(mean=img.mean(dim=(2, 3)), std=img.std(dim=(2, 3)), crop=img[:, :, 100:116, 60:76].clone(),
+                crop2=img[:, :, -20:-4, 200:216].clone())
+
+
+# ------------------------------------------------------------------------------- cases
+def case_interp():
+    """F.interpolate area / bicubic on random maps for every scale (pins oracle/interp.py)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    f = torch.randn(2, 3, 16, 16, generator=g)
+    out['f'] = f
+    for p in PN[:-1]:
+        out[f'area_{p}'] = F.interpolate(f, size=(p, p), mode='area')
+        h = torch.randn(2, 3, p, p, generator=g)
+        out[f'h_{p}'] = h
+        out[f'bicubic_{p}'] = F.interpolate(h, size=(16, 16), mode='bicubic')
+    save('interp', **out)
+
+
+def case_tokenizer(ch, nimg, tag):
+    vae = make_vae(ch)
+    img = synth_images(nimg, 256, seed=1)
+    t0 = time.time()
+    with torch.no_grad():
+        f = vae.quant_conv(vae.encoder(img))
+        ids = vae.img_to_idxBl(img, v_patch_nums=PN)
+        fhats = vae.quantize.f_to_idxBl_or_fhat(f, to_fhat=True, v_patch_nums=PN)
+        var_in = torch.cat(vae.idxBl_to_h(ids), dim=1)
+        rec = vae.idxBl_to_img(ids, same_shape=True, last_one=True)
+        rec2 = vae.fhat_to_img(fhats[-1].clone())
+    print(f'  [{tag}] reference encode+decode {time.time() - t0:.1f}s;  rec==rec2 maxdiff {(rec - rec2).abs().max():.2e}')
+    st = img_stats(rec)
+    save(f'tokenizer_{tag}', nimg=nimg, ch=ch, f=f, ids=torch.cat(ids, dim=1).to(torch.int16), fhat_last=fhats[-1],
+         fhat_s3=fhats[3], var_in=var_in[:, ::5].contiguous(), rec_mean=st['mean'], rec_std=st['std'], rec_crop=st['crop'], rec_crop2=st['crop2'])
+
+
+def case_next_input():
+    """get_next_autoregressive_input for every si on random (f_hat, h) (quant.py:243-260)."""
+    vae = make_vae(32)
+    g = torch.Generator().manual_seed(5)
+    out = {}
+    for si, pn in enumerate(PN):
+        f_hat = torch.randn(1, 32, 16, 16, generator=g)
+        h = torch.randn(1, 32, pn, pn, generator=g)
+        out[f'fhat_in_{si}'] = f_hat.clone()
+        out[f'h_{si}'] = h
+        with torch.no_grad():
+            f2, nxt = vae.quantize.get_next_autoregressive_input(si, len(PN), f_hat, h)
+        out[f'fhat_out_{si}'] = f2.clone()
+        out[f'next_{si}'] = nxt.clone()
+    save('next_input', **out)
+
+
+def case_block(cos):
+    """One AdaLNSABlock (C=128, H=2) with the KV cache over two stages, and masked training
+    mode on 10 tokens (basic_var.py:203-210)."""
+    from functools import partial
+    from models.basic_var import AdaLNSABlock
+    import torch.nn as nn
+    C, H = 128, 2
+    cfg = VarConfig(depth=30 if cos else 2, embed_dim=C, num_heads=H)
+    sd = synth_var_state(cfg, seed=3)
+    blk = quiet(AdaLNSABlock, block_idx=0, last_drop_p=0, embed_dim=C, cond_dim=C, shared_aln=False,
+                norm_layer=partial(nn.LayerNorm, eps=1e-6), num_heads=H, tau=4, cos_attn=cos,
+                flash_if_available=False, fused_if_available=False).eval()
+    blk.load_state_dict({k[len('blocks.0.'):]: v for k, v in sd.items() if k.startswith('blocks.0.')}, strict=True)
+    g = torch.Generator().manual_seed(9)
+    cond = torch.randn(3, C, generator=g)
+    x0 = torch.randn(3, 2, C, generator=g)
+    x1 = torch.randn(3, 8, C, generator=g)
+    xm = torch.randn(3, 10, C, generator=g)
+    lvl = torch.tensor([0, 0, 1, 1, 1, 1, 1, 1, 1, 1]).view(1, 10, 1)
+    bias = torch.where(lvl >= lvl.transpose(1, 2), 0., -torch.inf).reshape(1, 1, 10, 10)
+    with torch.no_grad():
+        blk.attn.kv_caching(True)
+        y0 = blk(x0, cond, None)
+        y1 = blk(x1, cond, None)
+        blk.attn.kv_caching(False)
+        ym = blk(xm, cond, bias)
+    save('block_cos' if cos else 'block', cond=cond, x0=x0, x1=x1, xm=xm, y0=y0, y1=y1, ym=ym)
+
+
+def case_forward(depth, tag, mf=2):
+    """Teacher-forced logits of a small model (control_var.py:568-651 / var.py:209-253)."""
+    vae = make_vae(32)
+    cfg = VarConfig(depth=depth, mask_factor=mf, control=(mf == 2), multi_cond=(mf == 2))
+    m = make_cvar(vae, cfg)
+    B = 2
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, cfg.pyramid.L - cfg.pyramid.first_l, 32, generator=g)
+    labels = torch.tensor([3, 977])
+    types = torch.tensor([1, 2])
+    with torch.no_grad():
+        logits = m(labels, x, types, True) if mf == 2 else m(labels, x)
+    t2 = logits.topk(2, dim=-1).values
+    save(f'forward_{tag}', depth=depth, mf=mf, labels=labels, types=types, logits_sample=logits[:, ::9, ::31].contiguous(),
+         argmax=logits.argmax(-1).to(torch.int16), margin=(t2[..., 0] - t2[..., 1]), lsum=logits.double().sum(-1).float())
+
+
+def _run_generate(m, module, B, labels, cfg_scale, cond_type=None, four=False, c_mask=None, c_img=None, top_k=1, top_p=0.0, seed=0):
+    with CaptureIdx(module) as cap, torch.no_grad():
+        if four:
+            img = m.conditional_infer_cfg(B=B, label_B=labels, g_seed=seed, cfg=cfg_scale, top_k=top_k, top_p=top_p,
+                                          cond_type=cond_type, c_mask=c_mask, c_img=c_img)
+        elif module is ref_cv:
+            img = m.autoregressive_infer_cfg(B=B, label_B=labels, g_seed=seed, cfg=cfg_scale, top_k=top_k, top_p=top_p, cond_type=cond_type)
+        else:
+            img = m.autoregressive_infer_cfg(B=B, label_B=labels, g_seed=seed, cfg=cfg_scale, top_k=top_k, top_p=top_p)
+    ids = torch.cat(cap.idx, dim=1)
+    st = img_stats(img)
+    return dict(ids=ids.to(torch.int16), margin=torch.cat(cap.margins, dim=1), logit_samples=torch.cat(cap.logit_samples, dim=1)[:, ::3].contiguous(),
+                img_mean=st['mean'], img_std=st['std'], img_crop=st['crop'], img_crop2=st['crop2'])
+
+
+def case_generate_tiny():
+    """Greedy decode traces of depth-2 models over the tiny VQVAE (ch=32)."""
+    vae = make_vae(32)
+    cfg = VarConfig(depth=2)
+    m = make_cvar(vae, cfg)
+    # (a) B=2 explicit cond types
+    r = _run_generate(m, ref_cv, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]))
+    save('gen_d2_b2', **r)
+    # (b) B=4, cond_type=None -> [0,1,2,3]
+    r = _run_generate(m, ref_cv, 4, torch.tensor([1, 10, 100, 999]), 4.0, cond_type=None)
+    save('gen_d2_b4none', **r)
+    # (c) conditional_infer_cfg with c_mask / c_img from synthetic control images
+    ctrl = synth_images(2, 256, seed=4)
+    with torch.no_grad():
+        c_ids = vae.img_to_idxBl(ctrl, v_patch_nums=PN)
+    r = _run_generate(m, ref_cv, 2, torch.tensor([5, 6]), (4.0, 4.0, 4.0), cond_type=torch.tensor([2, 3]), four=True, c_mask=c_ids)
+    save('gen_d2_cmask', c_ids=torch.cat(c_ids, dim=1).to(torch.int16), **r)
+    r = _run_generate(m, ref_cv, 2, torch.tensor([5, 6]), (3.0, 2.0, 1.0), cond_type=torch.tensor([2, 3]), four=True, c_img=c_ids)
+    save('gen_d2_cimg', c_ids=torch.cat(c_ids, dim=1).to(torch.int16), **r)
+    # (d) stochastic defaults of the reference (top_k=900, top_p=0.96), CPU generator
+    r = _run_generate(m, ref_cv, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]), top_k=900, top_p=0.96, seed=42)
+    save('gen_d2_b2_sampled', **r)
+    # (e) plain VAR, mask_factor 1
+    cfgv = VarConfig(depth=2, mask_factor=1, control=False, multi_cond=False)
+    mv = make_cvar(vae, cfgv)
+    r = _run_generate(mv, ref_v, 2, torch.tensor([3, 7]), 4.0)
+    save('gen_var_d2_b2', **r)
+    # (f) cos-attn (depth == 30 forces it), narrow width
+    cfgc = VarConfig(depth=30, embed_dim=128, num_heads=2)
+    mc = make_cvar(vae, cfgc)
+    r = _run_generate(mc, ref_cv, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([3, 0]))
+    save('gen_d30n_b2', **r)
+
+
+def case_generate_d12():
+    """BASELINE config 1: d12 ControlVAR + full VQVAE (ch=160), B=2, greedy, cfg=4."""
+    vae = make_vae(160)
+    m = make_cvar(vae, VarConfig(depth=12))
+    t0 = time.time()
+    r = _run_generate(m, ref_cv, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]))
+    print(f'  d12 B=2 reference generate {time.time() - t0:.1f}s')
+    save('gen_d12_b2', **r)
+
+
+def case_sampler():
+    """-inf pattern of the top-k/top-p filter for fixed logits (helpers.py:8-15)."""
+    from models.helpers import sample_with_top_k_top_p_
+    g = torch.Generator().manual_seed(77)
+    logits = torch.randn(2, 6, 4096, generator=g) * 3
+    out = {}
+    for (k, p) in [(900, 0.96), (0, 0.5), (50, 0.0), (1, 0.0)]:
+        lg = logits.clone()
+        rng = torch.Generator().manual_seed(1)
+        idx = sample_with_top_k_top_p_(lg, top_k=k, top_p=p, rng=rng)[:, :, 0]
+        out[f'kept_{k}_{p}'] = np.packbits(torch.isfinite(lg).numpy(), axis=-1)
+        out[f'idx_{k}_{p}'] = idx
+    save('sampler', **out)
+
+
+def case_lr():
+    """lr_wd_annealing 'lin0' table (utils/lr_control.py:10-64)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_lr_control', '/root/reference/utils/lr_control.py')   # utils/__init__ needs wandb
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    lr_wd_annealing = mod.lr_wd_annealing
+    import torch.nn as nn
+    p = nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([{'params': [p], 'wd_sc': 1.0, 'lr_sc': 1.0}], lr=1.0)
+    rows = []
+    max_it, wp_it = 1000, 10
+    for it in [0, 1, 5, 9, 10, 11, 50, 59, 60, 61, 100, 500, 900, 999]:
+        lo = lr_wd_annealing('lin0', opt, 4e-5, 0.08, 0.08, it, wp_it, max_it, wp0=0.005, wpe=0.01)
+        rows.append([it] + [float(v) for v in lo])
+    save('lr_lin0', table=np.array(rows, dtype=np.float64), peak_lr=4e-5, wd=0.08, wd_end=0.08, wp_it=wp_it, max_it=max_it, wp0=0.005, wpe=0.01)
+
+
+CASES = {
+    'interp': case_interp,
+    'tok_tiny': lambda: case_tokenizer(32, 3, 'ch32'),
+    'tok_full': lambda: case_tokenizer(160, 2, 'ch160'),
+    'next_input': case_next_input,
+    'block': lambda: case_block(False),
+    'block_cos': lambda: case_block(True),
+    'fwd_d2': lambda: case_forward(2, 'd2'),
+    'fwd_var_d2': lambda: case_forward(2, 'var_d2', mf=1),
+    'gen_tiny': case_generate_tiny,
+    'gen_d12': case_generate_d12,
+    'sampler': case_sampler,
+    'lr': case_lr,
+}
+
+if __name__ == '__main__':
+    names = sys.argv[1:] or list(CASES)
+    for n in names:
+        print(f'[{n}]')
+        t0 = time.time()
+        CASES[n]()
+        print(f'  done in {time.time() - t0:.1f}s')

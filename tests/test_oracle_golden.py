@@ -1,0 +1,207 @@
+"""Pins oracle/ against the fixtures recorded from the reference (tests/golden/make_golden.py).
+
+These are CPU tests: they prove the restatement reproduces the reference's outputs on the
+same seeded weights/inputs, so that the GPU parity tests may use the oracle as the checker.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from controlvar_amd.spec import DEFAULT_PATCH_NUMS as PN, VaeConfig, VarConfig, phi_index_map
+from controlvar_amd.synth import synth_images, synth_vae_state, synth_var_state
+from oracle import var_ref, vqvae_ref
+from oracle.interp import area_matrix, bicubic_matrix
+from oracle.vqvae_ref import MSQuant
+
+torch.set_num_threads(8)
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def split_ids(ids, mf=1):
+    out, o = [], 0
+    for p in PN:
+        n = mf * p * p
+        out.append(t(ids[:, o:o + n]).long())
+        o += n
+    return out
+
+
+@pytest.fixture(scope='module')
+def vae32():
+    sd = synth_vae_state(VaeConfig(ch=32))
+    return sd, MSQuant(sd, PN, phi_index_map(10))
+
+
+def test_interp_matrices_match_torch_fixture():
+    g = golden('interp')
+    f = t(g['f']).double()
+    for p in PN[:-1]:
+        A = t(area_matrix(16, p))
+        got = torch.einsum('ih,bchw,jw->bcij', A, f, A)
+        assert np.abs(got.numpy() - g[f'area_{p}']).max() < 2e-6
+        M = t(bicubic_matrix(p, 16))
+        got = torch.einsum('ih,bchw,jw->bcij', M, t(g[f'h_{p}']).double(), M)
+        assert np.abs(got.numpy() - g[f'bicubic_{p}']).max() < 5e-6
+
+
+def test_phi_map():
+    assert phi_index_map(10) == [0, 0, 1, 1, 1, 2, 2, 3, 3, 3]          # SURVEY A15, measured on the reference
+
+
+def test_next_input_all_scales(vae32):
+    sd, msq = vae32
+    g = golden('next_input')
+    for si, p in enumerate(PN):
+        f2, nxt = msq.next_input(si, t(g[f'fhat_in_{si}']), t(g[f'h_{si}']))
+        assert (f2 - t(g[f'fhat_out_{si}'])).abs().max() < 2e-5
+        assert (nxt - t(g[f'next_{si}'])).abs().max() < 2e-5
+
+
+def _check_tokenizer(tag, ch):
+    g = golden(f'tokenizer_{tag}')
+    sd = synth_vae_state(VaeConfig(ch=ch))
+    msq = MSQuant(sd, PN, phi_index_map(10))
+    img = synth_images(int(g['nimg']), 256, seed=1)
+    with torch.no_grad():
+        f = vqvae_ref.img_to_f(sd, img)
+    assert (f - t(g['f'])).abs().max() < 2e-4 * max(1.0, float(np.abs(g['f']).max()))
+    # integer path on the REFERENCE's f: ids must be identical
+    ids, margins = msq.f_to_idx(t(g['f']), return_margins=True)
+    ids = torch.cat(ids, dim=1).numpy()
+    mism = ids != g['ids'].astype(np.int64)
+    mg = torch.cat(margins, dim=1).numpy()
+    assert mism.sum() == 0 or mg[mism].max() < 1e-4, f'{mism.sum()} id mismatches, margins {mg[mism]}'
+    fh = msq.f_to_idx(t(g['f']), to_fhat=True)
+    assert (fh[-1] - t(g['fhat_last'])).abs().max() < 1e-4
+    assert (fh[3] - t(g['fhat_s3'])).abs().max() < 1e-4
+    gi = split_ids(g['ids'].astype(np.int64))
+    var_in = torch.cat(msq.idx_to_var_input(gi), dim=1)
+    assert (var_in[:, ::5] - t(g['var_in'])).abs().max() < 2e-5
+    with torch.no_grad():
+        rec = vqvae_ref.idxBl_to_img(sd, msq, gi)
+    assert (rec[:, :, 100:116, 60:76] - t(g['rec_crop'])).abs().max() < 2e-4
+    assert (rec[:, :, -20:-4, 200:216] - t(g['rec_crop2'])).abs().max() < 2e-4
+    assert (rec.mean(dim=(2, 3)) - t(g['rec_mean'])).abs().max() < 1e-5
+
+
+def test_tokenizer_tiny():
+    _check_tokenizer('ch32', 32)
+
+
+@pytest.mark.slow
+def test_tokenizer_full():
+    _check_tokenizer('ch160', 160)
+
+
+@pytest.mark.parametrize('cos', [False, True])
+def test_block(cos):
+    g = golden('block_cos' if cos else 'block')
+    cfg = VarConfig(depth=30 if cos else 2, embed_dim=128, num_heads=2)
+    sd = synth_var_state(cfg, seed=3)
+    cond = t(g['cond'])
+    ada = var_ref.ada_params(sd, 'blocks.0.', cond, 6, var_ref.FP32)
+    cache = var_ref.KVCache(cfg.depth)
+    y0 = var_ref.block(sd, 0, cfg, t(g['x0']), ada, cache, None, var_ref.FP32)
+    y1 = var_ref.block(sd, 0, cfg, t(g['x1']), ada, cache, None, var_ref.FP32)
+    lvl = torch.tensor([0, 0, 1, 1, 1, 1, 1, 1, 1, 1]).view(1, 10, 1)
+    bias = torch.where(lvl >= lvl.transpose(1, 2), 0., -torch.inf).reshape(1, 1, 10, 10)
+    ym = var_ref.block(sd, 0, cfg, t(g['xm']), ada, None, bias, var_ref.FP32)
+    for got, key in ((y0, 'y0'), (y1, 'y1'), (ym, 'ym')):
+        assert (got - t(g[key])).abs().max() < 2e-5, key
+
+
+@pytest.mark.parametrize('tag,mf', [('d2', 2), ('var_d2', 1)])
+def test_forward_logits(tag, mf):
+    g = golden(f'forward_{tag}')
+    cfg = VarConfig(depth=2, mask_factor=mf, control=(mf == 2), multi_cond=(mf == 2))
+    sd = synth_var_state(cfg)
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(2, cfg.pyramid.L - cfg.pyramid.first_l, 32, generator=gen)
+    with torch.no_grad():
+        logits = var_ref.forward_logits(sd, cfg, t(g['labels']), x, t(g['types']))
+    assert (logits[:, ::9, ::31] - t(g['logits_sample'])).abs().max() < 1e-4
+    am = logits.argmax(-1).numpy()
+    mism = am != g['argmax'].astype(np.int64)
+    assert mism.sum() == 0 or g['margin'][mism].max() < 1e-4
+    assert (logits.double().sum(-1).float() - t(g['lsum'])).abs().max() < 2e-2
+
+
+def _gen_check(name, cfg, B, labels, cfg_scale, cond_type=None, four=False, teach=None, top_k=1, top_p=0.0, seed=0,
+               vae_ch=32, img_tol=5e-4):
+    g = golden(name)
+    sdv = synth_vae_state(VaeConfig(ch=vae_ch))
+    msq = MSQuant(sdv, PN, phi_index_map(10))
+    sd = synth_var_state(cfg)
+    kw = {}
+    if teach is not None:
+        kw[teach] = split_ids(g['c_ids'].astype(np.int64))
+    trace = {}
+    with torch.no_grad():
+        f_hats = var_ref.generate(sd, cfg, msq, B, labels, cfg_scale, top_k=top_k, top_p=top_p, g_seed=seed,
+                                  cond_type=cond_type, four_way=four, trace=trace, **kw)
+        img = var_ref.decode_fhat(sdv, f_hats)
+    ids = torch.cat(trace['idx'], dim=1).numpy()
+    ref_ids = g['ids'].astype(np.int64)
+    assert ids.shape == ref_ids.shape
+    mism = ids != ref_ids
+    assert mism.sum() == 0, f'{name}: {mism.sum()} token mismatches (min ref margin at mismatch {g["margin"][mism].min():.3e})'
+    lg = torch.cat(trace['logits'], dim=1)[:2, :, ::128][:, ::3]
+    assert (lg - t(g['logit_samples'])).abs().max() < 2e-3 * max(1.0, float(np.abs(g['logit_samples']).max()))
+    assert (img[:, :, 100:116, 60:76] - t(g['img_crop'])).abs().max() < img_tol
+    assert (img[:, :, -20:-4, 200:216] - t(g['img_crop2'])).abs().max() < img_tol
+    assert (img.mean(dim=(2, 3)) - t(g['img_mean'])).abs().max() < 1e-4
+
+
+def test_generate_d2_b2():
+    _gen_check('gen_d2_b2', VarConfig(depth=2), 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]))
+
+
+def test_generate_d2_b4_none():
+    _gen_check('gen_d2_b4none', VarConfig(depth=2), 4, torch.tensor([1, 10, 100, 999]), 4.0, cond_type=None)
+
+
+def test_generate_conditional_cmask():
+    _gen_check('gen_d2_cmask', VarConfig(depth=2), 2, torch.tensor([5, 6]), (4.0, 4.0, 4.0), cond_type=torch.tensor([2, 3]),
+               four=True, teach='c_mask')
+
+
+def test_generate_conditional_cimg():
+    _gen_check('gen_d2_cimg', VarConfig(depth=2), 2, torch.tensor([5, 6]), (3.0, 2.0, 1.0), cond_type=torch.tensor([2, 3]),
+               four=True, teach='c_img')
+
+
+def test_generate_sampled_same_generator():
+    """top_k=900/top_p=0.96 with the same CPU generator stream reproduces the reference's draw."""
+    _gen_check('gen_d2_b2_sampled', VarConfig(depth=2), 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]),
+               top_k=900, top_p=0.96, seed=42)
+
+
+def test_generate_plain_var():
+    _gen_check('gen_var_d2_b2', VarConfig(depth=2, mask_factor=1, control=False, multi_cond=False), 2, torch.tensor([3, 7]), 4.0)
+
+
+def test_generate_cos_attn():
+    _gen_check('gen_d30n_b2', VarConfig(depth=30, embed_dim=128, num_heads=2), 2, torch.tensor([3, 7]), 4.0,
+               cond_type=torch.tensor([3, 0]))
+
+
+@pytest.mark.slow
+def test_generate_d12_config1():
+    """BASELINE.json configs[0]: d12 ControlVAR, B=2, CPU greedy decode."""
+    _gen_check('gen_d12_b2', VarConfig(depth=12), 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]), vae_ch=160)
+
+
+def test_sampler_masks():
+    g = golden('sampler')
+    gen = torch.Generator().manual_seed(77)
+    logits = torch.randn(2, 6, 4096, generator=gen) * 3
+    for (k, p) in [(900, 0.96), (0, 0.5), (50, 0.0), (1, 0.0)]:
+        lg = var_ref.topk_topp_mask_(logits.clone(), k, p)
+        kept = np.packbits(torch.isfinite(lg).numpy(), axis=-1)
+        assert (kept == g[f'kept_{k}_{p}']).all()
+    # greedy == the reference's top_k=1 multinomial
+    assert (var_ref.sample(logits.clone(), 1, 0.0, None).numpy() == g['idx_1_0.0']).all()
