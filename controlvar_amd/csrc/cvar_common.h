@@ -1,0 +1,68 @@
+// Shared device helpers for libcvar_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/cvar.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;    // 8 bf16 = one 16-byte MFMA fragment
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef unsigned short bf16_t;                                  // raw bf16 bits
+
+#define CVAR_CHECK_LAUNCH()                                      \
+    do {                                                         \
+        hipError_t e__ = hipGetLastError();                      \
+        if (e__ != hipSuccess) return CVAR_ELAUNCH;              \
+    } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
+
+// round-to-nearest-even, NaN preserved (same rounding as torch's .to(bfloat16))
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int kDtype = CVAR_F32;
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int kDtype = CVAR_BF16;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ float ld_any(const void* p, int dtype, int64_t i) {
+    return dtype == CVAR_BF16 ? bf16_to_f32(((const bf16_t*)p)[i]) : ((const float*)p)[i];
+}
+__device__ __forceinline__ void st_any(void* p, int dtype, int64_t i, float v) {
+    if (dtype == CVAR_BF16) ((bf16_t*)p)[i] = f32_to_bf16(v);
+    else ((float*)p)[i] = v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_tanh_f(float t) {
+    // 0.5 t (1 + tanh(sqrt(2/pi) (t + 0.044715 t^3)))   (nn.GELU(approximate='tanh'), basic_var.py:39)
+    const float k = 0.7978845608028654f;
+    float u = k * (t + 0.044715f * t * t * t);
+    return 0.5f * t * (1.0f + tanhf(u));
+}
+
+static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,300 @@
+// MFMA GEMM / implicit-GEMM 3x3 convolution with fused epilogue for gfx950 (MI355X).
+//
+//   C[row(m), n] = cast( residual + gate * act(alpha * sum_k A[m,k] W[n,k] + bias[n]) )
+//
+// Design (cdna_hip_programming.md section 5):
+//   * block tile BM x BN, K tile = 128 bytes of K per row (64 bf16 / 32 f32), WM x WN waves, each wave owns an
+//     (BM/WM) x (BN/WN) sub-tile built from 32x32 MFMA blocks: v_mfma_f32_32x32x16_bf16 (bf16 mode) or the
+//     exact-f32 v_mfma_f32_32x32x2_f32 (parity mode);
+//   * global -> LDS by global_load_lds_dwordx4 (16 B per lane, no VGPR round trip), double buffered, counted
+//     vmcnt so the next tile's DMA stays in flight across the barrier;
+//   * LDS rows are 128 B; the 16-B chunk index is XOR-swizzled with (row>>1)&7 on the SOURCE side (LDS image
+//     stays lane-linear as the DMA requires) and on the ds_read_b128 side -> conflict-free fragment reads;
+//   * out-of-range rows / K tail / conv zero padding read a 16-byte zero chunk instead of branching;
+//   * conv mode gathers A rows from NHWC activations (3x3 taps, stride 1 or the (0,1,0,1)-padded stride 2,
+//     optional nearest x2 upsample folded into the address);
+//   * blockIdx -> tile mapping is XCD-aware (contiguous tile ranges per XCD L2) and grouped along M.
+#include "cvar_common.h"
+
+__device__ __attribute__((aligned(16))) unsigned int cvar_zero_chunk[4] = {0u, 0u, 0u, 0u};
+
+struct GemmParams {
+    int M, N, K;
+    const char* A; long lda;
+    const char* W; long ldw;
+    long strideA, strideW, strideC, strideR;
+    int conv, Hin, Win, Cin, Hout, Wout, stride, up;
+    float alpha;
+    const float* bias;
+    int act;
+    const float* gate; long ldg; int gate_rows;
+    const void* residual; int res_dtype; long ldr;
+    void* C; int out_dtype; long ldc;
+    int remap_l, remap_L, remap_off;
+    int tiles_m, tiles_n;
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <typename T, int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParams p) {
+    constexpr int NW = WM * WN;
+    constexpr int ES = sizeof(T);
+    constexpr int KCH = 16 / ES;         // elements per 16-byte chunk
+    constexpr int KT = 128 / ES;         // elements of K per tile
+    constexpr int A_INSTR = BM / 8, B_INSTR = BN / 8;     // 1 KiB wave-instructions per tile
+    constexpr int A_PER_W = A_INSTR / NW, B_PER_W = B_INSTR / NW;
+    static_assert(A_INSTR % NW == 0 && B_INSTR % NW == 0, "tile / wave mismatch");
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int SUB_M = BM / WM, SUB_N = BN / WN;
+    constexpr int MI = SUB_M / 32, NJ = SUB_N / 32;
+    static_assert(SUB_M % 32 == 0 && SUB_N % 32 == 0, "sub-tile must be 32x32 blocks");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- tile coordinates: bijective XCD remap, then grouped-M ordering
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7, local = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    constexpr int GM = 8;
+    const int group_sz = GM * p.tiles_n;
+    const int grp = bid / group_sz, first_m = grp * GM;
+    const int gm = min(p.tiles_m - first_m, GM);
+    const int tm = first_m + (bid % group_sz) % gm;
+    const int tn = (bid % group_sz) / gm;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const long zb = blockIdx.z;
+
+    const char* const zero = (const char*)cvar_zero_chunk;
+    const char* Abase = p.A + zb * p.strideA * ES;
+    const char* Wbase = p.W + zb * p.strideW * ES;
+
+    // ---- per-lane load descriptors
+    const int lr = lane >> 3, slot = lane & 7;
+    const char* a_ptr[A_PER_W];      // plain: row base + chunk offset (nullptr if row out of range)
+    int a_k0[A_PER_W];               // element offset of this lane's chunk inside a K tile
+    int a_b[A_PER_W], a_oy[A_PER_W], a_ox[A_PER_W];   // conv: decoded output pixel (a_b < 0: invalid)
+#pragma unroll
+    for (int jj = 0; jj < A_PER_W; ++jj) {
+        const int j = wave + jj * NW;
+        const int row = j * 8 + lr;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        a_k0[jj] = chunk * KCH;
+        const int m = m0 + row;
+        if (CONV) {
+            a_ptr[jj] = nullptr;
+            if (m < p.M) {
+                const int hw = p.Hout * p.Wout;
+                const int b = m / hw, rem = m - b * hw;
+                a_b[jj] = b; a_oy[jj] = rem / p.Wout; a_ox[jj] = rem - a_oy[jj] * p.Wout;
+            } else {
+                a_b[jj] = -1; a_oy[jj] = 0; a_ox[jj] = 0;
+            }
+        } else {
+            a_b[jj] = 0; a_oy[jj] = 0; a_ox[jj] = 0;
+            a_ptr[jj] = (m < p.M) ? Abase + ((long)m * p.lda + a_k0[jj]) * ES : nullptr;
+        }
+    }
+    const char* w_ptr[B_PER_W];
+    int w_k0[B_PER_W];
+#pragma unroll
+    for (int jj = 0; jj < B_PER_W; ++jj) {
+        const int j = wave + jj * NW;
+        const int row = j * 8 + lr;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        w_k0[jj] = chunk * KCH;
+        const int n = n0 + row;
+        w_ptr[jj] = (n < p.N) ? Wbase + ((long)n * p.ldw + w_k0[jj]) * ES : nullptr;
+    }
+
+    auto issue_tile = [&](int kt, int stage) {
+        char* sbase = smem + stage * STAGE;
+#pragma unroll
+        for (int jj = 0; jj < A_PER_W; ++jj) {
+            const int j = wave + jj * NW;
+            const int k = kt * KT + a_k0[jj];
+            const char* src = zero;
+            if (CONV) {
+                if (a_b[jj] >= 0 && k < p.K) {
+                    const int tap = k / p.Cin, ci = k - tap * p.Cin;
+                    const int ky = tap / 3, kx = tap - ky * 3;
+                    int iy, ix;
+                    bool ok;
+                    if (p.stride == 1) {
+                        iy = a_oy[jj] + ky - 1; ix = a_ox[jj] + kx - 1;
+                        ok = (iy >= 0) && (iy < p.Hout) && (ix >= 0) && (ix < p.Wout);
+                        if (p.up) { iy >>= 1; ix >>= 1; }
+                    } else {
+                        iy = 2 * a_oy[jj] + ky; ix = 2 * a_ox[jj] + kx;
+                        ok = (iy < p.Hin) && (ix < p.Win);
+                    }
+                    if (ok) src = Abase + ((((long)a_b[jj] * p.Hin + iy) * p.Win + ix) * p.Cin + ci) * ES;
+                }
+            } else {
+                if (a_ptr[jj] != nullptr && k < p.K) src = a_ptr[jj] + (long)kt * 128;
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + j * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < B_PER_W; ++jj) {
+            const int j = wave + jj * NW;
+            const int k = kt * KT + w_k0[jj];
+            const char* src = zero;
+            if (w_ptr[jj] != nullptr && k < p.K) src = w_ptr[jj] + (long)kt * 128;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + BM * 128 + j * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16_t acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int lrow = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
+    const int nk = (p.K + KT - 1) / KT;
+
+    issue_tile(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            issue_tile(kt + 1, cur ^ 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_PER_W + B_PER_W) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const char* As = smem + cur * STAGE + (wm * SUB_M + lrow) * 128;
+        const char* Bs = smem + cur * STAGE + BM * 128 + (wn * SUB_N + lrow) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int c = ((2 * ks + hi) ^ sw) * 16;
+            if constexpr (ES == 2) {
+                bf16x8_t a[MI], b[NJ];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8_t*)(As + i * 32 * 128 + c);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[j] = *(const bf16x8_t*)(Bs + j * 32 * 128 + c);
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            } else {
+                f32x4_t a[MI], b[NJ];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = *(const f32x4_t*)(As + i * 32 * 128 + c);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[j] = *(const f32x4_t*)(Bs + j * 32 * 128 + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue (C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+    char* Cb = (char*)p.C;
+    const long cz = zb * p.strideC, rz = zb * p.strideR;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * SUB_M + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (m >= p.M) continue;
+            long orow = m;
+            if (p.remap_l > 0) {
+                const int s = m / p.remap_l;
+                orow = (long)s * p.remap_L + p.remap_off + (m - s * p.remap_l);
+            }
+            const float* grow = p.gate ? p.gate + (long)(m / p.gate_rows) * p.ldg : nullptr;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + wn * SUB_N + j * 32 + lrow;
+                if (n >= p.N) continue;
+                float v = acc[i][j][r] * p.alpha;
+                if (p.bias) v += p.bias[n];
+                if (p.act == CVAR_ACT_GELU_TANH) v = gelu_tanh_f(v);
+                if (grow) v *= grow[n];
+                if (p.residual) v += ld_any(p.residual, p.res_dtype, rz + (long)m * p.ldr + n);
+                st_any(Cb, p.out_dtype, cz + orow * p.ldc + n, v);
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
+    GemmParams p = gp;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const size_t lds = 2 * (BM + BN) * 128;
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)batch), block(WM * WN * 64);
+    if (p.conv) {
+        auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, true>;
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
+    } else {
+        auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, false>;
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
+    }
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+template <typename T>
+static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
+    // small-M problems (early scales, ada_lin) use a 64-row tile to put more blocks on the chip
+    if (p.M <= 64) return launch_cfg<T, 64, 128, 1, 4>(p, batch, st);
+    return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
+}
+
+extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
+    if (!d || !d->A || !d->W || !d->C) return CVAR_EINVAL;
+    if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch < 1) return CVAR_EINVAL;
+    if (d->dtype != CVAR_F32 && d->dtype != CVAR_BF16) return CVAR_EUNSUPPORTED;
+    const int es = d->dtype == CVAR_BF16 ? 2 : 4, kch = 16 / es;
+    if (d->K % kch) return CVAR_EUNSUPPORTED;
+    if (((uintptr_t)d->A & 15) || ((uintptr_t)d->W & 15)) return CVAR_EINVAL;
+    if ((d->ldw % kch) || (d->strideW % kch) || (d->strideA % kch)) return CVAR_EUNSUPPORTED;
+    if (d->conv) {
+        if (d->Cin % kch || d->K != 9 * d->Cin) return CVAR_EUNSUPPORTED;
+        if (d->stride != 1 && d->stride != 2) return CVAR_EUNSUPPORTED;
+        if (d->stride == 2 && d->up) return CVAR_EUNSUPPORTED;
+        if (d->stride == 1 && (d->Hout != (d->up ? 2 : 1) * d->Hin || d->Wout != (d->up ? 2 : 1) * d->Win)) return CVAR_EINVAL;
+        if (d->stride == 2 && (d->Hout != d->Hin / 2 || d->Wout != d->Win / 2)) return CVAR_EINVAL;
+        if (d->M % (d->Hout * d->Wout)) return CVAR_EINVAL;
+    } else if (d->lda % kch) {
+        return CVAR_EUNSUPPORTED;
+    }
+    if (d->gate && d->gate_rows <= 0) return CVAR_EINVAL;
+    GemmParams p;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.A = (const char*)d->A; p.lda = d->lda; p.W = (const char*)d->W; p.ldw = d->ldw;
+    p.strideA = d->strideA; p.strideW = d->strideW; p.strideC = d->strideC; p.strideR = d->strideR;
+    p.conv = d->conv; p.Hin = d->Hin; p.Win = d->Win; p.Cin = d->Cin; p.Hout = d->Hout; p.Wout = d->Wout;
+    p.stride = d->stride; p.up = d->up;
+    p.alpha = d->alpha; p.bias = d->bias; p.act = d->act;
+    p.gate = d->gate; p.ldg = d->ldg; p.gate_rows = d->gate_rows;
+    p.residual = d->residual; p.res_dtype = d->res_dtype; p.ldr = d->ldr;
+    p.C = d->C; p.out_dtype = d->out_dtype; p.ldc = d->ldc;
+    p.remap_l = d->remap_l; p.remap_L = d->remap_L; p.remap_off = d->remap_off;
+    p.tiles_m = p.tiles_n = 0;
+    hipStream_t st = as_stream(stream);
+    return d->dtype == CVAR_BF16 ? launch_typed<bf16_t>(p, d->batch, st) : launch_typed<float>(p, d->batch, st);
+}

@@ -1,0 +1,237 @@
+// Multi-scale residual quantizer kernels (models/quant.py): one workgroup per 16x16x32 feature map, the whole
+// map pyramid lives in LDS ([C][S][S] fp32 = 32 KiB per map), so a scale step never touches HBM except for the
+// codebook rows (L2 resident, 512 KiB) and the final ids / f_hat / tokens.
+//   bicubic up  : separable, operator table (S x pn) from the host (F.interpolate bicubic semantics)
+//   phi         : 0.5*h + 0.5*(conv3x3(h)+b), weights repacked [ci][tap][co] and read as wave-uniform scalars
+//   area down   : separable, operator table (pn x S) (F.interpolate area == adaptive average pooling)
+//   nearest code: d = (|z|^2 + |e|^2) - 2 z.e in fp32, first minimum (torch.argmin), codebook split across lanes
+#include "cvar_common.h"
+
+constexpr int MS_C = 32;       // Cvae
+constexpr int MS_S = 16;       // largest scale
+constexpr int MS_MAP = MS_C * MS_S * MS_S;   // floats per map
+
+// u <- bicubic_up(E[idx]) (or the plain gather when pn == S).  hs / u alias is handled by the caller passing
+// distinct buffers: gather -> bufA ([C][pn][pn]); rows -> tmp ([C][S][pn]); cols -> bufA ([C][S][S]).
+__device__ void ms_gather_up(const int* __restrict__ idx, const float* __restrict__ E, const float* __restrict__ up,
+                             float* bufA, float* tmp, int pn) {
+    const int tid = threadIdx.x;
+    const int n = pn * pn;
+    for (int i = tid; i < n * MS_C; i += 256) {
+        const int t = i / MS_C, c = i % MS_C;
+        bufA[c * n + t] = E[(long)idx[t] * MS_C + c];
+    }
+    __syncthreads();
+    if (pn == MS_S) return;
+    // rows: tmp[c][i][x] = sum_j up[i][j] * h[c][j][x]
+    for (int o = tid; o < MS_C * MS_S * pn; o += 256) {
+        const int x = o % pn, i = (o / pn) % MS_S, c = o / (pn * MS_S);
+        float a = 0.f;
+        for (int j = 0; j < pn; ++j) a = fmaf(up[i * pn + j], bufA[c * n + j * pn + x], a);
+        tmp[o] = a;
+    }
+    __syncthreads();
+    // cols: u[c][i][i2] = sum_j up[i2][j] * tmp[c][i][j]
+    for (int o = tid; o < MS_MAP; o += 256) {
+        const int i2 = o % MS_S, ci = o / MS_S;          // ci = c*S + i
+        float a = 0.f;
+        for (int j = 0; j < pn; ++j) a = fmaf(up[i2 * pn + j], tmp[ci * pn + j], a);
+        bufA[o] = a;
+    }
+    __syncthreads();
+}
+
+// h = 0.5*u + 0.5*(conv3x3(u) + b);  fh += h;  (fr -= h if fr != nullptr).  One thread per pixel.
+__device__ void ms_phi_accumulate(const float* u, const float* __restrict__ w /*[ci][9][co]*/, const float* __restrict__ bias,
+                                  float* fh, float* fr) {
+    const int pix = threadIdx.x;                 // 256 threads == S*S pixels
+    const int y = pix / MS_S, x = pix % MS_S;
+    float acc[MS_C];
+#pragma unroll
+    for (int co = 0; co < MS_C; ++co) acc[co] = bias[co];
+    for (int ci = 0; ci < MS_C; ++ci) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            const float v = (yy >= 0 && yy < MS_S && xx >= 0 && xx < MS_S) ? u[ci * 256 + yy * MS_S + xx] : 0.f;
+            const float* wr = w + (ci * 9 + tap) * MS_C;
+#pragma unroll
+            for (int co = 0; co < MS_C; ++co) acc[co] = fmaf(v, wr[co], acc[co]);
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < MS_C; ++co) {
+        const float h = u[co * 256 + pix] * 0.5f + acc[co] * 0.5f;
+        fh[co * 256 + pix] += h;
+        if (fr) fr[co * 256 + pix] -= h;
+    }
+    __syncthreads();
+}
+
+// area-pool src ([C][S][S]) to pn x pn; result token-major: dst[t][c].  tmp: [C][pn][S].
+__device__ void ms_area_tokens(const float* src, const float* __restrict__ down /*[pn][S]*/, float* tmp, float* dst, int pn,
+                               bool dst_global) {
+    const int tid = threadIdx.x;
+    if (pn == MS_S) {
+        for (int o = tid; o < MS_MAP; o += 256) { const int c = o % MS_C, t = o / MS_C; dst[o] = src[c * 256 + t]; }
+        if (!dst_global) __syncthreads();
+        return;
+    }
+    for (int o = tid; o < MS_C * pn * MS_S; o += 256) {
+        const int x = o % MS_S, i = (o / MS_S) % pn, c = o / (MS_S * pn);
+        float a = 0.f;
+        for (int yy = 0; yy < MS_S; ++yy) a = fmaf(down[i * MS_S + yy], src[c * 256 + yy * MS_S + x], a);
+        tmp[o] = a;
+    }
+    __syncthreads();
+    for (int o = tid; o < pn * pn * MS_C; o += 256) {
+        const int c = o % MS_C, t = o / MS_C;
+        const int i = t / pn, j = t % pn;
+        float a = 0.f;
+        for (int xx = 0; xx < MS_S; ++xx) a = fmaf(down[j * MS_S + xx], tmp[(c * pn + i) * MS_S + xx], a);
+        dst[o] = a;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ms_next_input_kernel(const int* __restrict__ idx, const float* __restrict__ E,
+                                                           const float* __restrict__ phi_w, const float* __restrict__ phi_b,
+                                                           const float* __restrict__ up, const float* __restrict__ down,
+                                                           float* __restrict__ f_hat, float* __restrict__ tok_out,
+                                                           int nmaps, int pn, int pn_next) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* bufA = lds;                 // [C][S][S]
+    float* fh = lds + MS_MAP;
+    float* tmp = lds + 2 * MS_MAP;
+    const int map = blockIdx.x % nmaps;
+    const long b = blockIdx.x / nmaps;
+    float* fg = f_hat + (b * nmaps + map) * (long)MS_MAP;
+    for (int o = threadIdx.x; o < MS_MAP; o += 256) fh[o] = fg[o];
+    ms_gather_up(idx + (b * nmaps + map) * (long)(pn * pn), E, up, bufA, tmp, pn);
+    ms_phi_accumulate(bufA, phi_w, phi_b, fh, nullptr);
+    for (int o = threadIdx.x; o < MS_MAP; o += 256) fg[o] = fh[o];
+    if (tok_out) {
+        float* dst = tok_out + ((b * nmaps + map) * (long)(pn_next * pn_next)) * MS_C;
+        ms_area_tokens(fh, down, tmp, dst, pn_next, true);
+    }
+}
+
+extern "C" int cvar_ms_next_input(const int32_t* idx, const float* codebook, const float* phi_w, const float* phi_b,
+                                  const float* up_mat, const float* down_mat, float* f_hat, float* tok_out,
+                                  int nb, int nmaps, int pn, int pn_next, int S, int Cvae, void* stream) {
+    if (!idx || !codebook || !phi_w || !phi_b || !f_hat || nb <= 0 || nmaps <= 0 || pn <= 0 || pn > S) return CVAR_EINVAL;
+    if (S != MS_S || Cvae != MS_C) return CVAR_EUNSUPPORTED;
+    if (pn != S && !up_mat) return CVAR_EINVAL;
+    if (tok_out && (pn_next <= 0 || pn_next > S || (pn_next != S && !down_mat))) return CVAR_EINVAL;
+    const size_t lds = 3 * MS_MAP * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)ms_next_input_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ms_next_input_kernel, dim3((unsigned)((long)nb * nmaps)), dim3(256), lds, as_stream(stream), idx, codebook, phi_w, phi_b,
+                       up_mat, down_mat, f_hat, tok_out, nmaps, pn, pn_next);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+struct MsEncodeParams {
+    const float* f; const float* E; int V;
+    const float* phi_w; const float* phi_b;
+    const float* up; const float* down;
+    int* idx_out; float* f_hat_out; float* margin_out;
+    int nscale;
+    int pn[16], phi_map[16], up_off[16], down_off[16], idx_off[16];
+    int Ltot;
+};
+
+__global__ __launch_bounds__(256) void ms_encode_kernel(const MsEncodeParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* bufA = lds;
+    float* fh = lds + MS_MAP;
+    float* tmp = lds + 2 * MS_MAP;
+    float* fr = lds + 3 * MS_MAP;
+    __shared__ float red_d[256], red_d2[256];
+    __shared__ int red_i[256];
+    __shared__ int sidx[256];
+    const int tid = threadIdx.x;
+    const long b = blockIdx.x;
+    for (int o = tid; o < MS_MAP; o += 256) { fr[o] = p.f[b * MS_MAP + o]; fh[o] = 0.f; }
+    __syncthreads();
+    for (int si = 0; si < p.nscale; ++si) {
+        const int pn = p.pn[si], n = pn * pn;
+        // z[t][c] = area(f_rest) -> bufA (token-major)
+        ms_area_tokens(fr, p.down + p.down_off[si], tmp, bufA, pn, false);
+        // nearest code: thread = (token, part)
+        const int P = n >= 256 ? 1 : 256 / n;
+        const int t = tid / P, part = tid % P;
+        float bd = INFINITY, bd2 = INFINITY;
+        int bi = 0;
+        if (t < n) {
+            float z[MS_C], zz = 0.f;
+#pragma unroll
+            for (int c = 0; c < MS_C; ++c) { z[c] = bufA[t * MS_C + c]; }
+#pragma unroll
+            for (int c = 0; c < MS_C; ++c) zz = fmaf(z[c], z[c], zz);
+            const int lo = (int)((long)part * p.V / P), hi = (int)((long)(part + 1) * p.V / P);
+            for (int v = lo; v < hi; ++v) {
+                const float* e = p.E + (long)v * MS_C;
+                float dot = 0.f, ee = 0.f;
+#pragma unroll
+                for (int c = 0; c < MS_C; c += 4) {
+                    const f32x4_t ev = *(const f32x4_t*)(e + c);
+                    dot = fmaf(z[c], ev[0], dot); dot = fmaf(z[c + 1], ev[1], dot);
+                    dot = fmaf(z[c + 2], ev[2], dot); dot = fmaf(z[c + 3], ev[3], dot);
+                    ee = fmaf(ev[0], ev[0], ee); ee = fmaf(ev[1], ev[1], ee);
+                    ee = fmaf(ev[2], ev[2], ee); ee = fmaf(ev[3], ev[3], ee);
+                }
+                const float d = __fadd_rn(__fadd_rn(zz, ee), __fmul_rn(-2.0f, dot));
+                if (d < bd) { bd2 = bd; bd = d; bi = v; }
+                else if (d < bd2) bd2 = d;
+            }
+        }
+        red_d[tid] = bd; red_d2[tid] = bd2; red_i[tid] = bi;
+        __syncthreads();
+        if (t < n && part == 0) {
+            for (int q = 1; q < P; ++q) {        // parts are in increasing code order -> strict '<' keeps the first minimum
+                const float d = red_d[tid + q], d2 = red_d2[tid + q];
+                if (d < bd) { bd2 = fminf(bd, d2); bd = d; bi = red_i[tid + q]; }
+                else bd2 = fminf(bd2, d);
+            }
+            sidx[t] = bi;
+            p.idx_out[b * p.Ltot + p.idx_off[si] + t] = bi;
+            if (p.margin_out) p.margin_out[b * p.Ltot + p.idx_off[si] + t] = bd2 - bd;
+        }
+        __syncthreads();
+        // stages with more than 256 tokens do not occur (S*S == 256)
+        ms_gather_up(sidx, p.E, p.up + p.up_off[si], bufA, tmp, pn);
+        const int k = p.phi_map[si];
+        ms_phi_accumulate(bufA, p.phi_w + (long)k * MS_C * 9 * MS_C, p.phi_b + k * MS_C, fh, fr);
+    }
+    if (p.f_hat_out)
+        for (int o = tid; o < MS_MAP; o += 256) p.f_hat_out[b * MS_MAP + o] = fh[o];
+}
+
+extern "C" int cvar_ms_encode(const float* f, const float* codebook, int V, const float* phi_w, const float* phi_b,
+                              const int* phi_map_host, const int* patch_nums_host, int nscale, const float* up_mats,
+                              const float* down_mats, int32_t* idx_out, float* f_hat_out, float* margin_out,
+                              int B, int S, int Cvae, void* stream) {
+    if (!f || !codebook || !phi_w || !phi_b || !phi_map_host || !patch_nums_host || !up_mats || !down_mats || !idx_out) return CVAR_EINVAL;
+    if (B <= 0 || V <= 1 || nscale <= 0 || nscale > 16) return CVAR_EINVAL;
+    if (S != MS_S || Cvae != MS_C || patch_nums_host[nscale - 1] != S) return CVAR_EUNSUPPORTED;
+    MsEncodeParams p;
+    p.f = f; p.E = codebook; p.V = V; p.phi_w = phi_w; p.phi_b = phi_b; p.up = up_mats; p.down = down_mats;
+    p.idx_out = idx_out; p.f_hat_out = f_hat_out; p.margin_out = margin_out; p.nscale = nscale;
+    int uo = 0, io = 0;
+    for (int i = 0; i < 16; ++i) {
+        const int pn = i < nscale ? patch_nums_host[i] : 0;
+        if (i < nscale && (pn <= 0 || pn > S)) return CVAR_EINVAL;
+        p.pn[i] = pn; p.phi_map[i] = i < nscale ? phi_map_host[i] : 0;
+        p.up_off[i] = uo; p.down_off[i] = uo; p.idx_off[i] = io;
+        uo += S * pn; io += pn * pn;
+    }
+    p.Ltot = io;
+    const size_t lds = 4 * MS_MAP * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)ms_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ms_encode_kernel, dim3(B), dim3(256), lds, as_stream(stream), p);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}

@@ -1,0 +1,463 @@
+// Row-wise / element-wise kernels of the transformer path (HBM-bound; 16-byte vector accesses).
+#include "cvar_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// adaLN: out = LN(x) * (1 + scale) + shift.   One wave per row, values kept in registers.
+// ------------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, long ld_ada, int rows_per,
+                                                         TO* __restrict__ out, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    constexpr int MAXV = 8;                        // C <= 2048
+    const float* xr = x + (long)row * C;
+    f32x4_t v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < C) {
+            v[i] = *(const f32x4_t*)(xr + c);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < C) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[i][e] -= mean; q += v[i][e] * v[i][e]; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    const long g = row / rows_per;
+    const float* sc = scale + g * ld_ada;
+    const float* sh = shift + g * ld_ada;
+    TO* orow = out + (long)row * C;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < C) {
+            const f32x4_t a = *(const f32x4_t*)(sc + c), b = *(const f32x4_t*)(sh + c);
+            float y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] * rstd) * (1.0f + a[e]) + b[e];
+            if constexpr (sizeof(TO) == 4) {
+                f32x4_t o = {y[0], y[1], y[2], y[3]};
+                *(f32x4_t*)(orow + c) = o;
+            } else {
+                bf16x4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (short)f32_to_bf16(y[e]);
+                *(bf16x4_t*)(orow + c) = o;
+            }
+        }
+    }
+}
+
+extern "C" int cvar_ln_modulate(const float* x, const float* scale, const float* shift, int64_t ld_ada, int rows_per,
+                                void* out, int out_dtype, int M, int C, float eps, void* stream) {
+    if (!x || !scale || !shift || !out || M <= 0 || rows_per <= 0) return CVAR_EINVAL;
+    if (C % 4 || C > 2048 || ld_ada % 4) return CVAR_EUNSUPPORTED;
+    dim3 grid(cdiv(M, 4)), block(256);
+    if (out_dtype == CVAR_BF16)
+        hipLaunchKernelGGL(ln_modulate_kernel<bf16_t>, grid, block, 0, as_stream(stream), x, scale, shift, (long)ld_ada, rows_per, (bf16_t*)out, M, C, eps);
+    else if (out_dtype == CVAR_F32)
+        hipLaunchKernelGGL(ln_modulate_kernel<float>, grid, block, 0, as_stream(stream), x, scale, shift, (long)ld_ada, rows_per, (float*)out, M, C, eps);
+    else return CVAR_EUNSUPPORTED;
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename TO>
+__global__ void silu_cast_kernel(const float* __restrict__ x, TO* __restrict__ out, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float v = x[i];
+        Elem<TO>::st(out + i, v / (1.0f + __expf(-v)));
+    }
+}
+
+extern "C" int cvar_silu_cast(const float* x, void* out, int out_dtype, int64_t n, void* stream) {
+    if (!x || !out || n <= 0) return CVAR_EINVAL;
+    dim3 grid((unsigned)min((int64_t)2048, (n + 255) / 256)), block(256);
+    if (out_dtype == CVAR_BF16) hipLaunchKernelGGL(silu_cast_kernel<bf16_t>, grid, block, 0, as_stream(stream), x, (bf16_t*)out, (long)n);
+    else if (out_dtype == CVAR_F32) hipLaunchKernelGGL(silu_cast_kernel<float>, grid, block, 0, as_stream(stream), x, (float*)out, (long)n);
+    else return CVAR_EUNSUPPORTED;
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cos-attention pre-pass: q <- normalize(q) * exp(min(scale_mul_h, ln 100)), k <- normalize(k), in place.
+// One wave per (sequence, token, head, q|k); lane = channel.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void cos_qk_norm_kernel(T* __restrict__ qkv, int R, int H, int Lmax, int q_off, int l,
+                                                         const float* __restrict__ scale_mul) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);     // over R*l*H*2
+    const long total = (long)R * l * H * 2;
+    if (item >= total) return;
+    const int which = (int)(item & 1);
+    const int h = (int)((item >> 1) % H);
+    const long rt = (item >> 1) / H;
+    const int t = (int)(rt % l);
+    const long r = rt / l;
+    T* p = qkv + ((r * Lmax + q_off + t) * 3 + which) * (long)(H * 64) + h * 64 + lane;
+    const float v = Elem<T>::ld(p);
+    const float nrm = sqrtf(wave_sum(v * v));
+    float o = v / fmaxf(nrm, 1e-12f);                              // F.normalize eps
+    if (which == 0) o *= __expf(fminf(scale_mul[h], 4.605170185988092f));
+    Elem<T>::st(p, o);
+}
+
+extern "C" int cvar_cos_qk_norm(void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, const float* scale_mul,
+                                void* stream) {
+    if (!qkv || !scale_mul || R <= 0 || H <= 0 || l <= 0) return CVAR_EINVAL;
+    const long total = (long)R * l * H * 2;
+    dim3 grid(cdiv(total, 4)), block(256);
+    if (dtype == CVAR_BF16) hipLaunchKernelGGL(cos_qk_norm_kernel<bf16_t>, grid, block, 0, as_stream(stream), (bf16_t*)qkv, R, H, Lmax, q_off, l, scale_mul);
+    else if (dtype == CVAR_F32) hipLaunchKernelGGL(cos_qk_norm_kernel<float>, grid, block, 0, as_stream(stream), (float*)qkv, R, H, Lmax, q_off, l, scale_mul);
+    else return CVAR_EUNSUPPORTED;
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// word_embed + lvl_pos (fp32): x[rep*nb+b][t][c] = bias[c] + lvl_pos[t][c] + sum_k tok[b][t][k] W[c][k]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void word_embed_kernel(const float* __restrict__ tok, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, const float* __restrict__ lvl_pos,
+                                                        float* __restrict__ x, int nb, int nrep, int l, int Cvae, int C,
+                                                        int x_rows, int x_off) {
+    __shared__ float tk[64];
+    const long bt = blockIdx.x;               // b*l + t
+    const int t = (int)(bt % l);
+    const long b = bt / l;
+    if (threadIdx.x < Cvae) tk[threadIdx.x] = tok[bt * Cvae + threadIdx.x];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float* w = W + (long)c * Cvae;
+        float acc = 0.f;
+        for (int k = 0; k < Cvae; k += 4) {
+            const f32x4_t wv = *(const f32x4_t*)(w + k);
+            acc = fmaf(tk[k], wv[0], acc); acc = fmaf(tk[k + 1], wv[1], acc);
+            acc = fmaf(tk[k + 2], wv[2], acc); acc = fmaf(tk[k + 3], wv[3], acc);
+        }
+        const float v = (acc + bias[c]) + lvl_pos[(long)t * C + c];
+        for (int rep = 0; rep < nrep; ++rep) x[(((long)rep * nb + b) * x_rows + x_off + t) * C + c] = v;
+    }
+}
+
+extern "C" int cvar_word_embed(const float* tok, const float* W, const float* bias, const float* lvl_pos, float* x,
+                               int nb, int nrep, int l, int Cvae, int C, int x_rows, int x_off, void* stream) {
+    if (!tok || !W || !bias || !lvl_pos || !x || nb <= 0 || nrep <= 0 || l <= 0) return CVAR_EINVAL;
+    if (x_rows < x_off + l || x_off < 0) return CVAR_EINVAL;
+    if (Cvae > 64 || Cvae % 4) return CVAR_EUNSUPPORTED;
+    hipLaunchKernelGGL(word_embed_kernel, dim3((unsigned)((long)nb * l)), dim3(256), 0, as_stream(stream), tok, W, bias, lvl_pos, x, nb, nrep, l, Cvae, C, x_rows, x_off);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// first-scale tokens + adaLN condition
+__global__ void first_tokens_kernel(const float* __restrict__ class_emb, const float* __restrict__ cond_embed,
+                                    const int* __restrict__ labels, const int* __restrict__ types,
+                                    const float* __restrict__ pos_start, const float* __restrict__ lvl_pos,
+                                    float* __restrict__ x, float* __restrict__ cond, int R, int first_l, int C, int x_rows) {
+    const int r = blockIdx.x;
+    const float* ce = class_emb + (long)labels[r] * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float cls = ce[c];
+        cond[(long)r * C + c] = cls;
+        if (first_l == 2) {
+            const float ct = cond_embed[(long)types[r] * C + c];
+            x[((long)r * x_rows + 0) * C + c] = (ct + pos_start[c]) + lvl_pos[c];
+            x[((long)r * x_rows + 1) * C + c] = (cls + pos_start[C + c]) + lvl_pos[C + c];
+        } else {
+            x[(long)r * x_rows * C + c] = (cls + pos_start[c]) + lvl_pos[c];
+        }
+    }
+}
+
+extern "C" int cvar_first_tokens(const float* class_emb, const float* cond_embed, const int32_t* labels, const int32_t* types,
+                                 const float* pos_start, const float* lvl_pos, float* x, float* cond, int R, int first_l,
+                                 int C, int x_rows, void* stream) {
+    if (!class_emb || !labels || !pos_start || !lvl_pos || !x || !cond || R <= 0) return CVAR_EINVAL;
+    if (first_l != 1 && first_l != 2) return CVAR_EUNSUPPORTED;
+    if (x_rows < first_l) return CVAR_EINVAL;
+    if (first_l == 2 && (!cond_embed || !types)) return CVAR_EINVAL;
+    hipLaunchKernelGGL(first_tokens_kernel, dim3(R), dim3(256), 0, as_stream(stream), class_emb, cond_embed, labels, types, pos_start, lvl_pos, x, cond, R, first_l, C, x_rows);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// VQVAE helpers
+// ------------------------------------------------------------------------------------------------
+// GroupNorm statistics over NHWC: per-(image, pixel-chunk) per-channel sum / sum of squares, reduced in a fixed
+// order (no atomics -> bit-reproducible), then combined over chunks in double by gn_finalize_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ partial, int HW, int C, int pix_per_block) {
+    constexpr int VEC = 16 / sizeof(T);
+    extern __shared__ float sred[];          // [PL][C][2]
+    const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+    const int ncg = C / VEC;                 // vectors per pixel
+    const int PL = 256 / ncg;                // pixels in flight per block iteration
+    const int pl = threadIdx.x / ncg, cg = threadIdx.x % ncg;
+    if (pl < PL) {
+        float s[VEC], q[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { s[e] = 0.f; q[e] = 0.f; }
+        const int p0 = chunk * pix_per_block;
+        const int p1 = min(p0 + pix_per_block, HW);
+        for (int p = p0 + pl; p < p1; p += PL) {
+            const T* src = x + ((long)b * HW + p) * C + cg * VEC;
+            if constexpr (sizeof(T) == 2) {
+                const bf16x8_t v = *(const bf16x8_t*)src;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { const float f = bf16_to_f32((bf16_t)v[e]); s[e] += f; q[e] += f * f; }
+            } else {
+                const f32x4_t v = *(const f32x4_t*)src;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            sred[((long)pl * C + cg * VEC + e) * 2] = s[e];
+            sred[((long)pl * C + cg * VEC + e) * 2 + 1] = q[e];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        float a = 0.f;
+        for (int k = 0; k < PL; ++k) a += sred[(long)k * C * 2 + i];
+        partial[(((long)b * nchunk + chunk) * C) * 2 + i] = a;
+    }
+}
+
+// per (b, c): a = rstd_g * w_c, d = bias_c - mean_g * rstd_g * w_c
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, const float* __restrict__ weight,
+                                   const float* __restrict__ bias, float* __restrict__ coef, int HW, int C, int groups, float eps) {
+    const int b = blockIdx.x;
+    const int cpg = C / groups;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        double s = 0.0, q = 0.0;
+        for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc)
+            for (int k = 0; k < nchunk; ++k) {
+                s += (double)partial[(((long)b * nchunk + k) * C + cc) * 2];
+                q += (double)partial[(((long)b * nchunk + k) * C + cc) * 2 + 1];
+            }
+        const double n = (double)HW * cpg;
+        const double mean = s / n;
+        double var = q / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float a = rstd * weight[c];
+        coef[((long)b * C + c) * 2] = a;
+        coef[((long)b * C + c) * 2 + 1] = bias[c] - (float)mean * a;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ coef, T* __restrict__ out,
+                                                      long nvec, int HW, int C, int silu) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int ncg = C / VEC;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; i < nvec; i += stride) {
+        const int cg = (int)(i % ncg);
+        const long b = (i / ncg) / HW;
+        const float* cf = coef + ((long)b * C + cg * VEC) * 2;
+        float y[VEC];
+        if constexpr (sizeof(T) == 2) {
+            const bf16x8_t v = *(const bf16x8_t*)(x + i * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) y[e] = bf16_to_f32((bf16_t)v[e]) * cf[2 * e] + cf[2 * e + 1];
+        } else {
+            const f32x4_t v = *(const f32x4_t*)(x + i * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) y[e] = v[e] * cf[2 * e] + cf[2 * e + 1];
+        }
+        if (silu) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) y[e] = y[e] / (1.0f + __expf(-y[e]));
+        }
+        if constexpr (sizeof(T) == 2) {
+            bf16x8_t o;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = (short)f32_to_bf16(y[e]);
+            *(bf16x8_t*)(out + i * VEC) = o;
+        } else {
+            f32x4_t o = {y[0], y[1], y[2], y[3]};
+            *(f32x4_t*)(out + i * VEC) = o;
+        }
+    }
+}
+
+static inline int gn_pix_per_block(int HW) { return HW >= 16384 ? 512 : (HW >= 1024 ? 128 : 32); }
+
+extern "C" int64_t cvar_groupnorm_ws_bytes(int B, int HW, int C) {
+    const int64_t nchunk = cdiv(HW, gn_pix_per_block(HW));
+    return ((int64_t)B * nchunk * C * 2 + (int64_t)B * C * 2) * (int64_t)sizeof(float);
+}
+
+template <typename T>
+static int groupnorm_typed(const T* x, const float* weight, const float* bias, T* out, int B, int HW, int C, int groups,
+                           float eps, int silu, void* ws, hipStream_t st) {
+    constexpr int VEC = 16 / sizeof(T);
+    if (C % VEC || C % groups || C / VEC > 256) return CVAR_EUNSUPPORTED;
+    const int ppb = gn_pix_per_block(HW);
+    const int nchunk = cdiv(HW, ppb);
+    float* partial = (float*)ws;
+    float* coef = partial + (size_t)B * nchunk * C * 2;
+    const int PL = 256 / (C / VEC);
+    hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(nchunk, B), dim3(256), (size_t)PL * C * 2 * sizeof(float), st, x, partial, HW, C, ppb);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, partial, nchunk, weight, bias, coef, HW, C, groups, eps);
+    const long nvec = (long)B * HW * C / VEC;
+    hipLaunchKernelGGL(gn_apply_kernel<T>, dim3((unsigned)min((long)4096, (nvec + 255) / 256)), dim3(256), 0, st, x, coef, out, nvec, HW, C, silu);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+extern "C" int cvar_groupnorm_silu(const void* x, int dtype, const float* weight, const float* bias, void* out,
+                                   int B, int HW, int C, int groups, float eps, int silu, void* ws, void* stream) {
+    if (!x || !weight || !bias || !out || !ws || B <= 0 || HW <= 0 || C <= 0 || groups <= 0) return CVAR_EINVAL;
+    if (dtype == CVAR_BF16) return groupnorm_typed<bf16_t>((const bf16_t*)x, weight, bias, (bf16_t*)out, B, HW, C, groups, eps, silu, ws, as_stream(stream));
+    if (dtype == CVAR_F32) return groupnorm_typed<float>((const float*)x, weight, bias, (float*)out, B, HW, C, groups, eps, silu, ws, as_stream(stream));
+    return CVAR_EUNSUPPORTED;
+}
+
+// row softmax, one wave per row (cols <= 1024)
+template <typename TO>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, TO* __restrict__ p, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* sr = s + row * cols;
+    float v[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = i * 64 + lane;
+        v[i] = c < cols ? sr[c] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { v[i] = __expf(v[i] - mx); sum += v[i]; }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = i * 64 + lane;
+        if (c < cols) Elem<TO>::st(p + row * cols + c, v[i] * inv);
+    }
+}
+
+extern "C" int cvar_softmax_rows(const float* s, void* p, int out_dtype, int rows, int cols, void* stream) {
+    if (!s || !p || rows <= 0 || cols <= 0) return CVAR_EINVAL;
+    if (cols > 1024) return CVAR_EUNSUPPORTED;
+    dim3 grid(cdiv(rows, 4)), block(256);
+    if (out_dtype == CVAR_BF16) hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, grid, block, 0, as_stream(stream), s, (bf16_t*)p, rows, cols);
+    else if (out_dtype == CVAR_F32) hipLaunchKernelGGL(softmax_rows_kernel<float>, grid, block, 0, as_stream(stream), s, (float*)p, rows, cols);
+    else return CVAR_EUNSUPPORTED;
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// [B][n][c] (row stride ld_in) -> [B][c][n]
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int n, int c, long ld_in) {
+    __shared__ T tile[32][33];
+    const long b = blockIdx.z;
+    const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+    for (int r = ty; r < 32; r += 8)
+        if (n0 + r < n && c0 + tx < c) tile[r][tx] = in[(b * n + n0 + r) * ld_in + c0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (c0 + r < c && n0 + tx < n) out[(b * c + c0 + r) * (long)n + n0 + tx] = tile[tx][r];
+}
+
+extern "C" int cvar_transpose(const void* in, void* out, int dtype, int B, int n, int c, int64_t ld_in, void* stream) {
+    if (!in || !out || B <= 0 || n <= 0 || c <= 0) return CVAR_EINVAL;
+    dim3 grid(cdiv(n, 32), cdiv(c, 32), B), block(256);
+    if (dtype == CVAR_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, block, 0, as_stream(stream), (const bf16_t*)in, (bf16_t*)out, n, c, (long)ld_in);
+    else if (dtype == CVAR_F32) hipLaunchKernelGGL(transpose_kernel<float>, grid, block, 0, as_stream(stream), (const float*)in, (float*)out, n, c, (long)ld_in);
+    else return CVAR_EUNSUPPORTED;
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+template <typename TO>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, TO* __restrict__ out, int C, int HW, int Cpad, long total) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {            // i over B*HW*Cpad
+        const int c = (int)(i % Cpad);
+        const long bp = i / Cpad;
+        const long p = bp % HW, b = bp / HW;
+        Elem<TO>::st(out + i, c < C ? in[(b * C + c) * HW + p] : 0.f);
+    }
+}
+
+extern "C" int cvar_nchw_to_nhwc(const float* in, void* out, int dtype, int B, int C, int HW, int Cpad, void* stream) {
+    if (!in || !out || B <= 0 || C <= 0 || HW <= 0 || Cpad < C) return CVAR_EINVAL;
+    const long total = (long)B * HW * Cpad;
+    dim3 grid((unsigned)min((long)4096, (total + 255) / 256)), block(256);
+    if (dtype == CVAR_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, block, 0, as_stream(stream), in, (bf16_t*)out, C, HW, Cpad, total);
+    else if (dtype == CVAR_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, block, 0, as_stream(stream), in, (float*)out, C, HW, Cpad, total);
+    else return CVAR_EUNSUPPORTED;
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+template <typename TI>
+__global__ void nhwc_to_nchw_kernel(const TI* __restrict__ in, long ld_in, float* __restrict__ out, int C, int HW, long total,
+                                    float lo, float hi, float mul, float add) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {            // i over B*C*HW (output order)
+        const long p = i % HW;
+        const long bc = i / HW;
+        const int c = (int)(bc % C);
+        const long b = bc / C;
+        float v = Elem<TI>::ld(in + (b * HW + p) * ld_in + c);
+        v = fminf(fmaxf(v, lo), hi);
+        out[i] = v * mul + add;
+    }
+}
+
+extern "C" int cvar_nhwc_to_nchw(const void* in, int dtype, int64_t ld_in, float* out, int B, int C, int HW,
+                                 float lo, float hi, float mul, float add, void* stream) {
+    if (!in || !out || B <= 0 || C <= 0 || HW <= 0) return CVAR_EINVAL;
+    const long total = (long)B * C * HW;
+    dim3 grid((unsigned)min((long)4096, (total + 255) / 256)), block(256);
+    if (dtype == CVAR_BF16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, block, 0, as_stream(stream), (const bf16_t*)in, (long)ld_in, out, C, HW, total, lo, hi, mul, add);
+    else if (dtype == CVAR_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, block, 0, as_stream(stream), (const float*)in, (long)ld_in, out, C, HW, total, lo, hi, mul, add);
+    else return CVAR_EUNSUPPORTED;
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+extern "C" int cvar_abi_version(void) { return 1; }
+extern "C" const char* cvar_status_str(int status) {
+    switch (status) {
+        case CVAR_OK: return "ok";
+        case CVAR_EINVAL: return "invalid argument";
+        case CVAR_EUNSUPPORTED: return "unsupported shape or dtype";
+        case CVAR_ELAUNCH: return "kernel launch failed";
+        default: return "unknown status";
+    }
+}

@@ -1,0 +1,707 @@
+"""Host-side mirror of the reference's model API (models/__init__.py, models/vqvae.py,
+models/var.py, models/control_var.py) over the HIP kernels of libcvar_hip.so.
+
+Same class names, constructor keywords, method names / argument meaning and state_dict keys
+as the reference, so a checkpoint (or a caller such as train_control_var_hpu.py:157-176,288,
+322,332) works unchanged; the computation is organised MI355X-first instead of nn.Module-per-op:
+weights are packed once into GEMM-ready device buffers, the KV cache is a preallocated arena
+written by the QKV GEMM's epilogue, adaLN parameters are computed once per generation, and every
+scale step runs as a short sequence of fused kernels.  There is no CPU / eager fallback.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import ACT_GELU_TANH
+from .pyramid import packed_tables
+from .spec import DEFAULT_PATCH_NUMS, VaeConfig, VarConfig, vae_state_shapes, var_state_shapes
+from .synth import synth_vae_state, synth_var_state
+
+
+class _Tree(nn.Module):
+    """plain container so that dotted state_dict keys map onto nested attributes"""
+
+
+def _register_tree(root: nn.Module, shapes, values: Dict[str, torch.Tensor], requires_grad: bool):
+    for key, (shape, kind) in shapes.items():
+        parts = key.split('.')
+        m = root
+        for p in parts[:-1]:
+            if p not in m._modules:
+                m.add_module(p, _Tree())
+            m = m._modules[p]
+        t = values[key]
+        assert tuple(t.shape) == tuple(shape), key
+        if kind == 'param':
+            m.register_parameter(parts[-1], nn.Parameter(t, requires_grad=requires_grad and t.is_floating_point()))
+        else:
+            m.register_buffer(parts[-1], t)
+
+
+def _compute_dtype(d) -> torch.dtype:
+    if isinstance(d, torch.dtype):
+        return d
+    return {'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16, 'fp32': torch.float32, 'f32': torch.float32, 'float32': torch.float32}[d]
+
+
+# =====================================================================================
+# VQVAE
+# =====================================================================================
+class VQVAE(nn.Module):
+    """Multi-scale VQVAE tokenizer (reference: models/vqvae.py:16-109).
+
+    compute_dtype: torch.bfloat16 (throughput mode: bf16 NHWC activations, fp32 accumulate) or
+    torch.float32 (parity mode: exact-f32 MFMA).  The quantizer itself always runs in fp32.
+    """
+
+    def __init__(self, vocab_size=4096, z_channels=32, ch=128, dropout=0.0, beta=0.25, using_znorm=False, quant_conv_ks=3,
+                 quant_resi=0.5, share_quant_resi=4, default_qresi_counts=0, v_patch_nums=DEFAULT_PATCH_NUMS, test_mode=True,
+                 compute_dtype=torch.bfloat16, init_seed: int = 0, decode_chunk: int = 16):
+        super().__init__()
+        if using_znorm or quant_conv_ks != 3 or abs(quant_resi - 0.5) > 1e-9 or share_quant_resi != 4 or dropout != 0.0:
+            raise NotImplementedError('only the shipped VQVAE configuration (vqvae.py:18-27 defaults, share_quant_resi=4) is built')
+        self.cfg = VaeConfig(vocab=vocab_size, z_channels=z_channels, ch=ch, share_quant_resi=share_quant_resi,
+                             patch_nums=tuple(v_patch_nums))
+        self.test_mode = test_mode
+        self.V = self.vocab_size = vocab_size
+        self.Cvae = z_channels
+        self.downsample = 2 ** (len(self.cfg.ch_mult) - 1)
+        self.compute_dtype = _compute_dtype(compute_dtype)
+        self.decode_chunk = decode_chunk
+        _register_tree(self, vae_state_shapes(self.cfg), synth_vae_state(self.cfg, init_seed), requires_grad=not test_mode)
+        self._packed = None
+        if test_mode:
+            self.eval()
+
+    # ---- nn.Module plumbing
+    def load_state_dict(self, state_dict: Dict[str, Any], strict=True, assign=False):
+        key = 'quantize.ema_vocab_hit_SV'
+        if key in state_dict and state_dict[key].shape[0] != self.quantize.ema_vocab_hit_SV.shape[0]:
+            state_dict = dict(state_dict)
+            state_dict[key] = self.quantize.ema_vocab_hit_SV          # vqvae.py:106-108
+        self._packed = None
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    @property
+    def device(self):
+        return self.quant_conv.weight.device
+
+    # ---- weight packing (one-time layout work, not on the timed path)
+    def _pack(self):
+        if self._packed is not None:
+            return self._packed
+        dev, T = self.device, self.compute_dtype
+        if dev.type != 'cuda':
+            raise RuntimeError('controlvar_amd.VQVAE computes on the GPU only; call .to("cuda") first')
+        kch = 8 if T == torch.bfloat16 else 4
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        P: Dict[str, Any] = {'conv': {}, 'norm': {}}
+        for k, v in sd.items():
+            if k.endswith('.weight') and v.dim() == 4 and not k.startswith('quantize.'):
+                name = k[:-len('.weight')]
+                fp32_only = name in ('quant_conv', 'post_quant_conv')        # quantizer side stays fp32
+                Tw = torch.float32 if fp32_only else T
+                kc = 4 if fp32_only else kch
+                cout, cin, ks, _ = v.shape
+                if ks == 3:
+                    cin_p = (cin + kc - 1) // kc * kc
+                    w = torch.zeros(cout, 3, 3, cin_p, device=dev, dtype=torch.float32)
+                    w[..., :cin] = v.permute(0, 2, 3, 1)
+                    w = w.reshape(cout, 9 * cin_p)
+                else:
+                    cin_p = cin
+                    w = v.reshape(cout, cin)
+                P['conv'][name] = dict(w=w.to(Tw).contiguous(), b=sd[name + '.bias'].float().contiguous(), cin=cin_p, cout=cout, ks=ks)
+            elif '.norm' in k and k.endswith('.weight'):
+                name = k[:-len('.weight')]
+                P['norm'][name] = (v.float().contiguous(), sd[name + '.bias'].float().contiguous())
+        P['E'] = sd['quantize.embedding.weight'].float().contiguous()
+        nphi = self.cfg.share_quant_resi
+        pw = torch.stack([sd[f'quantize.quant_resi.qresi_ls.{k}.weight'] for k in range(nphi)])      # (k, co, ci, 3, 3)
+        P['phi_w'] = pw.permute(0, 2, 3, 4, 1).reshape(nphi, self.Cvae, 9, self.Cvae).float().contiguous()   # [k][ci][tap][co]
+        P['phi_b'] = torch.stack([sd[f'quantize.quant_resi.qresi_ls.{k}.bias'] for k in range(nphi)]).float().contiguous()
+        up, down, offs = packed_tables(self.cfg.patch_nums)
+        P['up'] = torch.from_numpy(up).to(dev)
+        P['down'] = torch.from_numpy(down).to(dev)
+        P['tab_off'] = [int(o) for o in offs]
+        P['phi_map'] = self.cfg.phi_map
+        self._packed = P
+        return P
+
+    # ---- conv-stack building blocks (NHWC activations of compute dtype)
+    def _conv(self, x, name, B, Hin, Win, *, stride=1, up=0, residual=None, out_dtype=None):
+        c = self._pack()['conv'][name]
+        T = c['w'].dtype
+        if c['ks'] == 1:
+            M = B * Hin * Win
+            out = torch.empty(M, c['cout'], device=x.device, dtype=out_dtype or T)
+            ops.gemm(x, c['w'], out, M=M, N=c['cout'], K=c['cin'], bias=c['b'], residual=residual)
+            return out, Hin, Win
+        Hout = Hin * 2 if up else (Hin // 2 if stride == 2 else Hin)
+        Wout = Win * 2 if up else (Win // 2 if stride == 2 else Win)
+        M = B * Hout * Wout
+        out = torch.empty(M, c['cout'], device=x.device, dtype=out_dtype or T)
+        ops.gemm(x, c['w'], out, M=M, N=c['cout'], K=9 * c['cin'], bias=c['b'], residual=residual,
+                 conv=dict(Hin=Hin, Win=Win, Cin=c['cin'], Hout=Hout, Wout=Wout, stride=stride, up=up))
+        return out, Hout, Wout
+
+    def _gn(self, x, name, B, HW, C, silu=True):
+        w, b = self._pack()['norm'][name]
+        ws = torch.empty(ops.groupnorm_ws_bytes(B, HW, C), device=x.device, dtype=torch.uint8)
+        out = torch.empty_like(x)
+        return ops.groupnorm_silu(x, w, b, out, B, HW, C, self.cfg.gn_groups, self.cfg.gn_eps, silu, ws)
+
+    def _resblock(self, x, name, B, H, W, cin, cout):
+        h = self._gn(x, name + '.norm1', B, H * W, cin)
+        h, _, _ = self._conv(h, name + '.conv1', B, H, W)
+        h = self._gn(h, name + '.norm2', B, H * W, cout)
+        if cin != cout:
+            x, _, _ = self._conv(x, name + '.nin_shortcut', B, H, W)
+        h, _, _ = self._conv(h, name + '.conv2', B, H, W, residual=x)
+        return h
+
+    def _attnblock(self, x, name, B, HW, C):
+        T = x.dtype
+        n = self._gn(x, name + '.norm', B, HW, C, silu=False)
+        qkv, _, _ = self._conv(n, name + '.qkv', B, HW, 1)                     # (B*HW, 3C): q | k | v
+        vT = torch.empty(B, C, HW, device=x.device, dtype=T)
+        ops.transpose(qkv, vT, B, HW, C, 3 * C, in_off=2 * C)
+        s = torch.empty(B, HW, HW, device=x.device, dtype=torch.float32)
+        ops.gemm(qkv, qkv, s, M=HW, N=HW, K=C, lda=3 * C, ldw=3 * C, w_off=C, alpha=float(int(C) ** -0.5), batch=B,
+                 strideA=HW * 3 * C, strideW=HW * 3 * C, strideC=HW * HW)
+        p = torch.empty(B, HW, HW, device=x.device, dtype=T)
+        ops.softmax_rows(s, p, B * HW, HW)
+        o = torch.empty(B * HW, C, device=x.device, dtype=T)
+        ops.gemm(p, vT, o, M=HW, N=C, K=HW, batch=B, strideA=HW * HW, strideW=C * HW, strideC=HW * C)
+        y, _, _ = self._conv(o, name + '.proj_out', B, HW, 1, residual=x)
+        return y
+
+    # ---- encoder / decoder
+    def _encode_f(self, img: torch.Tensor) -> torch.Tensor:
+        """quant_conv(encoder(img)) -> f (B, Cvae, 16, 16) fp32 (vqvae.py:74; vae_modules.py:144-160)."""
+        P = self._pack()
+        B, _, H, W = img.shape
+        T = self.compute_dtype
+        cfg = self.cfg
+        cin_p = P['conv']['encoder.conv_in']['cin']
+        x = torch.empty(B * H * W, cin_p, device=img.device, dtype=T)
+        ops.nchw_to_nhwc(img.contiguous().float(), x, B, 3, H * W, cin_p)
+        h, H, W = self._conv(x, 'encoder.conv_in', B, H, W)
+        nlev = len(cfg.ch_mult)
+        in_mult = (1,) + tuple(cfg.ch_mult)
+        cur = cfg.ch
+        for lv in range(nlev):
+            cout = cfg.ch * cfg.ch_mult[lv]
+            for b in range(cfg.num_res_blocks):
+                h = self._resblock(h, f'encoder.down.{lv}.block.{b}', B, H, W, cur, cout)
+                cur = cout
+                if lv == nlev - 1:
+                    h = self._attnblock(h, f'encoder.down.{lv}.attn.{b}', B, H * W, cur)
+            if lv != nlev - 1:
+                h, H, W = self._conv(h, f'encoder.down.{lv}.downsample.conv', B, H, W, stride=2)
+        h = self._resblock(h, 'encoder.mid.block_1', B, H, W, cur, cur)
+        h = self._attnblock(h, 'encoder.mid.attn_1', B, H * W, cur)
+        h = self._resblock(h, 'encoder.mid.block_2', B, H, W, cur, cur)
+        h = self._gn(h, 'encoder.norm_out', B, H * W, cur)
+        z, _, _ = self._conv(h, 'encoder.conv_out', B, H, W, out_dtype=torch.float32)      # (B*HW, Cvae) fp32 NHWC
+        f, _, _ = self._conv(z, 'quant_conv', B, H, W)                                      # fp32 weights
+        out = torch.empty(B, self.Cvae, H, W, device=img.device, dtype=torch.float32)
+        ops.nhwc_to_nchw(f, self.Cvae, out, B, self.Cvae, H * W)
+        return out
+
+    def _decode(self, f_hat: torch.Tensor, lo=-1.0, hi=1.0, mul=1.0, add=0.0) -> torch.Tensor:
+        """decoder(post_quant_conv(f_hat)).clamp(lo,hi)*mul+add (vqvae.py:88-89; vae_modules.py:210-225)."""
+        P = self._pack()
+        outs = []
+        for s in range(0, f_hat.shape[0], self.decode_chunk):
+            outs.append(self._decode_chunk(f_hat[s:s + self.decode_chunk].contiguous(), lo, hi, mul, add))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+
+    def _decode_chunk(self, f_hat, lo, hi, mul, add):
+        cfg = self.cfg
+        T = self.compute_dtype
+        B, Cv, H, W = f_hat.shape
+        x = torch.empty(B * H * W, Cv, device=f_hat.device, dtype=torch.float32)
+        ops.nchw_to_nhwc(f_hat.float(), x, B, Cv, H * W, Cv)
+        z, _, _ = self._conv(x, 'post_quant_conv', B, H, W, out_dtype=T)                   # fp32 conv, output in compute dtype
+        nlev = len(cfg.ch_mult)
+        cur = cfg.ch * cfg.ch_mult[-1]
+        h, _, _ = self._conv(z, 'decoder.conv_in', B, H, W)
+        h = self._resblock(h, 'decoder.mid.block_1', B, H, W, cur, cur)
+        h = self._attnblock(h, 'decoder.mid.attn_1', B, H * W, cur)
+        h = self._resblock(h, 'decoder.mid.block_2', B, H, W, cur, cur)
+        for lv in reversed(range(nlev)):
+            cout = cfg.ch * cfg.ch_mult[lv]
+            for b in range(cfg.num_res_blocks + 1):
+                h = self._resblock(h, f'decoder.up.{lv}.block.{b}', B, H, W, cur, cout)
+                cur = cout
+                if lv == nlev - 1:
+                    h = self._attnblock(h, f'decoder.up.{lv}.attn.{b}', B, H * W, cur)
+            if lv != 0:
+                h, H, W = self._conv(h, f'decoder.up.{lv}.upsample.conv', B, H, W, up=1)
+        h = self._gn(h, 'decoder.norm_out', B, H * W, cur)
+        y, _, _ = self._conv(h, 'decoder.conv_out', B, H, W, out_dtype=torch.float32)      # (B*HW, 3) fp32
+        out = torch.empty(B, 3, H, W, device=f_hat.device, dtype=torch.float32)
+        ops.nhwc_to_nchw(y, 3, out, B, 3, H * W, lo, hi, mul, add)
+        return out
+
+    # ---- quantizer helpers
+    def _split(self, flat: torch.Tensor, mf: int = 1) -> List[torch.Tensor]:
+        outs, o = [], 0
+        for pn in self.cfg.patch_nums:
+            n = mf * pn * pn
+            outs.append(flat[:, o:o + n])
+            o += n
+        return outs
+
+    def _ms_encode(self, f: torch.Tensor, want_fhat=False, want_margin=False):
+        P = self._pack()
+        B = f.shape[0]
+        pns = self.cfg.patch_nums
+        Ltot = sum(p * p for p in pns)
+        idx = torch.empty(B, Ltot, device=f.device, dtype=torch.int32)
+        fh = torch.empty_like(f) if want_fhat else None
+        mg = torch.empty(B, Ltot, device=f.device, dtype=torch.float32) if want_margin else None
+        ops.ms_encode(f.contiguous(), P['E'], self.V, P['phi_w'], P['phi_b'], P['phi_map'], list(pns), P['up'], P['down'], idx, fh, mg,
+                      B, pns[-1], self.Cvae)
+        return idx, fh, mg
+
+    def _next_input(self, si: int, idx: torch.Tensor, f_hat: torch.Tensor, nb: int, nmaps: int, want_tok: bool):
+        """one scale step for all (nb, nmaps) maps: f_hat updated in place, returns tokens of the next scale or None"""
+        P = self._pack()
+        pns = self.cfg.patch_nums
+        pn = pns[si]
+        last = si == len(pns) - 1
+        pn_next = pns[si + 1] if not last else pn
+        tok = torch.empty(nb, nmaps * pn_next * pn_next, self.Cvae, device=f_hat.device, dtype=torch.float32) if (want_tok and not last) else None
+        ops.ms_next_input(idx, P['E'], P['phi_w'], P['phi_b'], P['up'], P['down'], f_hat, tok, nb, nmaps, pn, pn_next, pns[-1], self.Cvae,
+                          P['phi_map'][si], P['tab_off'][si], P['tab_off'][si + 1] if not last else 0)
+        return tok
+
+    # ---- public API (same names / meaning as models/vqvae.py)
+    @torch.no_grad()
+    def img_to_idxBl(self, inp_img_no_grad: torch.Tensor, v_patch_nums=None) -> List[torch.Tensor]:
+        """vqvae.py:73-75 -> list of (B, pn*pn) int64 ids, coarse to fine"""
+        if v_patch_nums is not None and tuple(v_patch_nums) != tuple(self.cfg.patch_nums):
+            raise NotImplementedError('v_patch_nums must equal the constructor patch_nums')
+        idx, _, _ = self._ms_encode(self._encode_f(inp_img_no_grad))
+        return [t.long() for t in self._split(idx)]
+
+    @torch.no_grad()
+    def idxBl_to_h(self, gt_ms_idx_Bl: List[torch.Tensor]) -> List[torch.Tensor]:
+        """vqvae.py:77-78 / quant.py:217-240 -> teacher-forcing inputs, list of (B, pn_{k+1}^2, Cvae) fp32"""
+        B = gt_ms_idx_Bl[0].shape[0]
+        dev = gt_ms_idx_Bl[0].device
+        S = self.cfg.patch_nums[-1]
+        f_hat = torch.zeros(B, 1, self.Cvae, S, S, device=dev, dtype=torch.float32)
+        outs = []
+        for si in range(len(self.cfg.patch_nums) - 1):
+            outs.append(self._next_input(si, gt_ms_idx_Bl[si].to(torch.int32).contiguous(), f_hat, B, 1, True))
+        return outs
+
+    def _idx_to_fhat(self, ms_idx_Bl: List[torch.Tensor]) -> torch.Tensor:
+        B = ms_idx_Bl[0].shape[0]
+        S = self.cfg.patch_nums[-1]
+        f_hat = torch.zeros(B, 1, self.Cvae, S, S, device=ms_idx_Bl[0].device, dtype=torch.float32)
+        for si in range(len(self.cfg.patch_nums)):
+            self._next_input(si, ms_idx_Bl[si].to(torch.int32).contiguous(), f_hat, B, 1, False)
+        return f_hat[:, 0]
+
+    @torch.no_grad()
+    def fhat_to_img(self, f_hat: torch.Tensor) -> torch.Tensor:
+        """vqvae.py:88-89"""
+        return self._decode(f_hat)
+
+    @torch.no_grad()
+    def idxBl_to_img(self, ms_idx_Bl: List[torch.Tensor], same_shape: bool = True, last_one: bool = False):
+        """vqvae.py:97-104 (same_shape=True path)"""
+        if not same_shape:
+            raise NotImplementedError('all_to_max_scale=False is an experimental visualisation path upstream (quant.py:171-180)')
+        if last_one:
+            return self._decode(self._idx_to_fhat(ms_idx_Bl))
+        B = ms_idx_Bl[0].shape[0]
+        S = self.cfg.patch_nums[-1]
+        f_hat = torch.zeros(B, 1, self.Cvae, S, S, device=ms_idx_Bl[0].device, dtype=torch.float32)
+        outs = []
+        for si in range(len(self.cfg.patch_nums)):
+            self._next_input(si, ms_idx_Bl[si].to(torch.int32).contiguous(), f_hat, B, 1, False)
+            outs.append(self._decode(f_hat[:, 0]))
+        return outs
+
+    @torch.no_grad()
+    def img_to_recon(self, x, v_patch_nums=None, last_one=False):
+        """vqvae.py:80-86"""
+        idx, fh, _ = self._ms_encode(self._encode_f(x), want_fhat=True)
+        if last_one:
+            return self._decode(fh, lo=-3.0e38, hi=3.0e38)
+        return self._recon_all(idx)
+
+    def _recon_all(self, idx):
+        ms = self._split(idx)
+        B = idx.shape[0]
+        S = self.cfg.patch_nums[-1]
+        f_hat = torch.zeros(B, 1, self.Cvae, S, S, device=idx.device, dtype=torch.float32)
+        outs = []
+        for si in range(len(self.cfg.patch_nums)):
+            self._next_input(si, ms[si].contiguous(), f_hat, B, 1, False)
+            outs.append(self._decode(f_hat[:, 0], lo=-3.0e38, hi=3.0e38))
+        return outs
+
+    def forward(self, *a, **k):
+        raise NotImplementedError('VQVAE training (vqvae.py:56-59, losses/) is out of scope: the tokenizer is frozen on the hot path')
+
+
+# =====================================================================================
+# ControlVAR / VAR
+# =====================================================================================
+class ControlVAR(nn.Module):
+    """Joint (control, image) next-scale transformer (reference: models/control_var.py:23-689).
+
+    Only the configuration every shipped yaml uses is built: aln=1 (AdaLNSABlock), shared_aln=False,
+    separator = bidirectional = separate_decoding = type_pos = indep = False; multi_cond as given.
+    """
+    _control = True
+
+    def __init__(self, vae_local: VQVAE, num_classes=1000, norm_eps=1e-6, aln=1, aln_gamma_init=1e-3, shared_aln=False,
+                 cond_drop_rate=0.1, depth=16, embed_dim=1024, num_heads=16, mlp_ratio=4., drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0., layer_scale=-1., tau=4, cos_attn=False, patch_nums=DEFAULT_PATCH_NUMS,
+                 flash_if_available=True, fused_if_available=True, mask_factor=2, bidirectional=False, separate_decoding=False,
+                 separator=False, type_pos=False, indep=False, multi_cond=False,
+                 compute_dtype=None, init_seed: int = 0):
+        super().__init__()
+        if aln < 0 or shared_aln or separator or bidirectional or separate_decoding or type_pos or indep:
+            raise NotImplementedError('non-default model variants (SURVEY.md 8f N4) are not built')
+        if self._control and mask_factor == 2 and not multi_cond:
+            raise NotImplementedError('mask_factor=2 requires multi_cond=True (every shipped config)')
+        if embed_dim // num_heads != 64:
+            raise NotImplementedError('head_dim must be 64')
+        self.cfg = VarConfig(depth=depth, mask_factor=mask_factor, multi_cond=bool(multi_cond) and self._control and mask_factor == 2,
+                             control=self._control, patch_nums=tuple(patch_nums), vocab=vae_local.vocab_size, cvae=vae_local.Cvae,
+                             num_classes=num_classes, embed_dim=embed_dim, num_heads=num_heads, norm_eps=norm_eps, tau=float(tau),
+                             cos_attn=bool(cos_attn), mlp_ratio=mlp_ratio, cond_drop_rate=cond_drop_rate)
+        cfg = self.cfg
+        self.Cvae, self.V = cfg.cvae, cfg.vocab
+        self.depth, self.C, self.D, self.num_heads = depth, cfg.C, cfg.C, cfg.H
+        self.patch_nums, self.mask_factor, self.multi_cond = tuple(patch_nums), mask_factor, cfg.multi_cond
+        py = cfg.pyramid
+        self.L, self.first_l = py.L, py.first_l
+        self.begin_ends = list(zip(py.begin, py.end))
+        self.num_stages_minus_1 = len(patch_nums) - 1
+        self.num_classes = num_classes
+        self.cond_drop_rate = cond_drop_rate
+        self.prog_si = -1
+        self.vae_proxy: Tuple[VQVAE] = (vae_local,)                  # tuple proxy: not a submodule (control_var.py:72-73)
+        self.vae_quant_proxy = (vae_local.quantize,)
+        self.compute_dtype = _compute_dtype(compute_dtype) if compute_dtype is not None else vae_local.compute_dtype
+        _register_tree(self, var_state_shapes(cfg), synth_var_state(cfg, init_seed), requires_grad=True)
+        self._packed = None
+        self._arena = None
+        self.last_trace: Optional[dict] = None
+
+    # ---- plumbing
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        self._packed = None
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        self._arena = None
+        return super()._apply(fn, *a, **k)
+
+    @property
+    def device(self):
+        return self.pos_1LC.device
+
+    def _pack(self):
+        if self._packed is not None:
+            return self._packed
+        dev, T, cfg = self.device, self.compute_dtype, self.cfg
+        if dev.type != 'cuda':
+            raise RuntimeError('controlvar_amd models compute on the GPU only; call .to("cuda") first')
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        C, depth = cfg.C, cfg.depth
+        P: Dict[str, Any] = {}
+        blk = lambda i, s: sd[f'blocks.{i}.{s}']
+        P['w_qkv'] = torch.stack([blk(i, 'attn.mat_qkv.weight') for i in range(depth)]).to(T).contiguous()
+        P['b_qkv'] = torch.stack([torch.cat((blk(i, 'attn.q_bias'), torch.zeros_like(blk(i, 'attn.q_bias')), blk(i, 'attn.v_bias')))
+                                  for i in range(depth)]).float().contiguous()
+        P['w_proj'] = torch.stack([blk(i, 'attn.proj.weight') for i in range(depth)]).to(T).contiguous()
+        P['b_proj'] = torch.stack([blk(i, 'attn.proj.bias') for i in range(depth)]).float().contiguous()
+        P['w_fc1'] = torch.stack([blk(i, 'ffn.fc1.weight') for i in range(depth)]).to(T).contiguous()
+        P['b_fc1'] = torch.stack([blk(i, 'ffn.fc1.bias') for i in range(depth)]).float().contiguous()
+        P['w_fc2'] = torch.stack([blk(i, 'ffn.fc2.weight') for i in range(depth)]).to(T).contiguous()
+        P['b_fc2'] = torch.stack([blk(i, 'ffn.fc2.bias') for i in range(depth)]).float().contiguous()
+        # every ada_lin of the model in ONE weight: rows [i*6C,(i+1)*6C) = block i, last 2C rows = head_nm
+        P['w_ada'] = torch.cat([blk(i, 'ada_lin.1.weight') for i in range(depth)] + [sd['head_nm.ada_lin.1.weight']]).to(T).contiguous()
+        P['b_ada'] = torch.cat([blk(i, 'ada_lin.1.bias') for i in range(depth)] + [sd['head_nm.ada_lin.1.bias']]).float().contiguous()
+        P['n_ada'] = depth * 6 * C + 2 * C
+        P['w_head'] = sd['head.weight'].to(T).contiguous()
+        P['b_head'] = sd['head.bias'].float().contiguous()
+        P['w_we'] = sd['word_embed.weight'].float().contiguous()
+        P['b_we'] = sd['word_embed.bias'].float().contiguous()
+        P['lvl_pos'] = (sd['lvl_embed.weight'][sd['lvl_1L'][0]] + sd['pos_1LC'][0]).float().contiguous()      # (L, C)
+        P['pos_start'] = sd['pos_start'][0].float().contiguous()
+        P['class_emb'] = sd['class_emb.weight'].float().contiguous()
+        P['cond_embed'] = sd['cond_embed.weight'].float().contiguous() if 'cond_embed.weight' in sd else None
+        if cfg.uses_cos_attn:
+            P['scale_mul'] = torch.stack([blk(i, 'attn.scale_mul_1H11').reshape(-1) for i in range(depth)]).float().contiguous()
+        self._packed = P
+        return P
+
+    def _get_arena(self, R: int, Lmax: int):
+        key = (R, Lmax, self.compute_dtype)
+        if self._arena is None or self._arena[0] != key:
+            self._arena = (key, torch.empty(self.cfg.depth, R, Lmax, 3 * self.cfg.C, device=self.device, dtype=self.compute_dtype))
+        return self._arena[1]
+
+    # ---- one pass of all blocks + head over l new tokens per sequence
+    def _blocks_and_head(self, x, ada, R: int, l: int, q_off: int, Lmax: int, arena, lvl_end=None):
+        """x: (R*l, C) fp32 residual stream (updated in place).  Returns logits (R*l, V) fp32."""
+        P, cfg = self._pack(), self.cfg
+        C, H, T = cfg.C, cfg.H, self.compute_dtype
+        M = R * l
+        hid = P['w_fc1'].shape[1]
+        n_ada = P['n_ada']
+        dev = x.device
+        u = torch.empty(M, C, device=dev, dtype=T)
+        o = torch.empty(M, C, device=dev, dtype=T)
+        hbuf = torch.empty(M, hid, device=dev, dtype=T)
+        arena_stride = R * Lmax * 3 * C
+        for i in range(cfg.depth):
+            a0 = i * 6 * C
+            ops.ln_modulate(x, ada, a0 + 2 * C, a0 + 4 * C, n_ada, l, u, M, C, cfg.norm_eps)
+            ops.gemm(u, P['w_qkv'], arena, M=M, N=3 * C, K=C, w_off=i * 3 * C * C, bias=P['b_qkv'][i], c_off=i * arena_stride,
+                     ldc=3 * C, remap=(l, Lmax, q_off))
+            if cfg.uses_cos_attn:
+                ops.cos_qk_norm(arena, R, H, Lmax, q_off, l, P['scale_mul'], qkv_off=i * arena_stride, sm_off=i * H)
+            ops.attention(arena, o, R, H, Lmax, q_off, l, float(cfg.attn_scale), lvl_end, qkv_off=i * arena_stride)
+            ops.gemm(o, P['w_proj'], x, M=M, N=C, K=C, w_off=i * C * C, bias=P['b_proj'][i], gate=ada, gate_off=a0, ldg=n_ada, gate_rows=l,
+                     residual=x)
+            ops.ln_modulate(x, ada, a0 + 3 * C, a0 + 5 * C, n_ada, l, u, M, C, cfg.norm_eps)
+            ops.gemm(u, P['w_fc1'], hbuf, M=M, N=hid, K=C, w_off=i * hid * C, bias=P['b_fc1'][i], act=ACT_GELU_TANH)
+            ops.gemm(hbuf, P['w_fc2'], x, M=M, N=C, K=hid, w_off=i * C * hid, bias=P['b_fc2'][i], gate=ada, gate_off=a0 + C, ldg=n_ada,
+                     gate_rows=l, residual=x)
+        ah = cfg.depth * 6 * C
+        ops.ln_modulate(x, ada, ah, ah + C, n_ada, l, u, M, C, cfg.norm_eps)
+        logits = torch.empty(M, cfg.vocab, device=dev, dtype=torch.float32)
+        ops.gemm(u, P['w_head'], logits, M=M, N=cfg.vocab, K=C, bias=P['b_head'])
+        return logits
+
+    def _ada(self, cond: torch.Tensor, R: int):
+        P = self._pack()
+        cs = torch.empty(R, self.cfg.C, device=cond.device, dtype=self.compute_dtype)
+        ops.silu_cast(cond, cs)
+        ada = torch.empty(R, P['n_ada'], device=cond.device, dtype=torch.float32)
+        ops.gemm(cs, P['w_ada'], ada, M=R, N=P['n_ada'], K=self.cfg.C, bias=P['b_ada'])
+        return ada
+
+    def _as_labels(self, B, label_B, seed):
+        dev = self.device
+        if label_B is None:
+            g = torch.Generator(device='cpu').manual_seed(seed)
+            label_B = torch.randint(0, self.num_classes, (B,), generator=g)
+        elif isinstance(label_B, int):
+            label_B = torch.full((B,), self.num_classes if label_B < 0 else label_B)
+        return label_B.to(device=dev, dtype=torch.int32)
+
+    def _as_types(self, B, cond_type, seed, allow_none=True):
+        dev = self.device
+        if cond_type is None:
+            if B == 4:
+                cond_type = torch.tensor([0, 1, 2, 3])                      # control_var.py:387-389
+            else:
+                g = torch.Generator(device='cpu').manual_seed(seed + 1)
+                cond_type = torch.randint(0, 4, (B,), generator=g)
+        elif isinstance(cond_type, int):
+            assert 0 < cond_type <= 3                                      # control_var.py:395
+            cond_type = torch.full((B,), cond_type)
+        return cond_type.to(device=dev, dtype=torch.int32)
+
+    @torch.no_grad()
+    def _generate(self, B, label_B, g_seed, cfg_scale, top_k, top_p, more_smooth, cond_type, four_way, c_mask, c_img,
+                  force_idx=None, trace: bool = False):
+        if more_smooth:
+            raise NotImplementedError('more_smooth (Gumbel visualisation path) is not built (SURVEY.md 8f N4)')
+        cfg, P = self.cfg, self._pack()
+        vae: VQVAE = self.vae_proxy[0]
+        py, mf, C = cfg.pyramid, cfg.mask_factor, cfg.C
+        dev = self.device
+        seed = int(g_seed) if g_seed is not None else int(torch.empty((), dtype=torch.int64).random_().item())
+        labels = self._as_labels(B, label_B, seed)
+        empty = torch.full_like(labels, self.num_classes)
+        nrep = 4 if four_way else 2
+        R = nrep * B
+        labels_all = torch.cat([labels] + [empty] * (nrep - 1)).contiguous()
+        types_all = None
+        if mf == 2:
+            types = self._as_types(B, cond_type, seed)
+            e4 = torch.full_like(types, 4)
+            types_all = (torch.cat([types, types, e4, e4]) if four_way else torch.cat([types, e4])).contiguous()
+        nb = R if four_way else B
+        x = torch.empty(R * py.l[-1], C, device=dev, dtype=torch.float32)
+        cond = torch.empty(R, C, device=dev, dtype=torch.float32)
+        ops.first_tokens(P['class_emb'], P['cond_embed'], labels_all, types_all, P['pos_start'], P['lvl_pos'], x, cond, R, py.first_l, C, py.first_l)
+        ada = self._ada(cond, R)
+        arena = self._get_arena(R, py.L)
+        S = py.patch_nums[-1]
+        f_hat = torch.zeros(nb, mf, cfg.cvae, S, S, device=dev, dtype=torch.float32)
+        tr = {'idx': [], 'margin': [], 'logits': []} if trace else None
+        nstage = len(py.patch_nums)
+        for si, pn in enumerate(py.patch_nums):
+            l = py.l[si]
+            ratio = si / (nstage - 1)
+            logits = self._blocks_and_head(x[:R * l], ada, R, l, py.begin[si], py.L, arena)
+            if four_way:
+                t1, t2, t3 = [c * ratio for c in cfg_scale]
+                coef = [1 + t1, t2 - t1, t3 - t2, -t3]
+            else:
+                t = cfg_scale * ratio
+                coef = [1 + t, -t]
+            n_draw = 4 if four_way else 1
+            idx = torch.empty(n_draw * B, l, device=dev, dtype=torch.int32)
+            comb = torch.empty(B, l, cfg.vocab, device=dev, dtype=torch.float32) if trace else None
+            mg = torch.empty(B, l, device=dev, dtype=torch.float32) if trace else None
+            ops.cfg_sample(logits, B, nrep, l, cfg.vocab, coef, top_k, top_p, seed, si, n_draw, idx, comb, mg)
+            if trace:
+                tr['idx'].append(idx.clone()); tr['margin'].append(mg); tr['logits'].append(comb)
+            if force_idx is not None:
+                idx = force_idx[si].to(device=dev, dtype=torch.int32).contiguous()
+            if four_way:                                                 # teacher forcing (control_var.py:309-324)
+                if c_mask is not None:
+                    idx[:3 * B, :pn * pn] = c_mask[si].to(device=dev, dtype=torch.int32).repeat(3, 1)
+                if c_img is not None:
+                    idx[:3 * B, pn * pn:] = c_img[si].to(device=dev, dtype=torch.int32).repeat(3, 1)
+            tok = vae._next_input(si, idx, f_hat, nb, mf, True)
+            if si != nstage - 1:
+                ln = py.l[si + 1]
+                ops.word_embed(tok, P['w_we'], P['b_we'], P['lvl_pos'], x, nb, 1 if four_way else 2, ln, cfg.cvae, C, ln, 0, lvl_off=py.end[si])
+        if trace:
+            tr['f_hat'] = f_hat[:B].clone()
+            self.last_trace = tr
+        return f_hat[:B]
+
+    def _decode_pair(self, f_hat: torch.Tensor) -> torch.Tensor:
+        vae: VQVAE = self.vae_proxy[0]
+        imgs = [vae._decode(f_hat[:, m].contiguous(), lo=-1.0, hi=1.0, mul=0.5, add=0.5) for m in range(f_hat.shape[1])]
+        return imgs[0] if len(imgs) == 1 else torch.cat(imgs, dim=2)
+
+    # ---- public API
+    @torch.no_grad()
+    def autoregressive_infer_cfg(self, B: int, label_B, g_seed: Optional[int] = None, cfg=1.5, top_k=0, top_p=0.0,
+                                 more_smooth=False, cond_type=None, _force_idx=None, _trace=False) -> torch.Tensor:
+        """control_var.py:356-565: returns (B, 3, 512, 256) in [0,1] (control image on top, RGB below)."""
+        f_hat = self._generate(B, label_B, g_seed, cfg, top_k, top_p, more_smooth, cond_type, False, None, None, _force_idx, _trace)
+        return self._decode_pair(f_hat)
+
+    @torch.no_grad()
+    def conditional_infer_cfg(self, B: int, label_B, g_seed: Optional[int] = None, cfg=(1.5, 1.5, 1.5), top_k=0, top_p=0.0,
+                              more_smooth=False, cond_type=None, c_mask=None, c_img=None, _force_idx=None, _trace=False) -> torch.Tensor:
+        """control_var.py:223-354: 4-branch CFG with teacher forcing of the control (c_mask) or image (c_img) ids."""
+        if self.mask_factor != 2:
+            raise NotImplementedError('conditional_infer_cfg needs mask_factor == 2 (control_var.py:333)')
+        f_hat = self._generate(B, label_B, g_seed, tuple(cfg), top_k, top_p, more_smooth, cond_type, True, c_mask, c_img, _force_idx, _trace)
+        return self._decode_pair(f_hat)
+
+    @torch.no_grad()
+    def forward(self, label_B: torch.LongTensor, x_BLCv_wo_first_l: torch.Tensor, cond_type=None, mask_first=True) -> torch.Tensor:
+        """control_var.py:568-651 teacher-forced logits (B, L, V) fp32.  Inference-only this round: label /
+        cond-type dropout follows ``self.training`` (torch.rand, as the reference), DropPath and autograd are not built."""
+        cfg, P = self.cfg, self._pack()
+        py, C = cfg.pyramid, cfg.C
+        dev = self.device
+        if not mask_first:
+            raise NotImplementedError('mask_first=False only occurs with bidirectional=True')
+        B = x_BLCv_wo_first_l.shape[0]
+        labels = label_B.to(dev)
+        if self.training and cfg.cond_drop_rate > 0:
+            labels = torch.where(torch.rand(B, device=dev) < cfg.cond_drop_rate, self.num_classes, labels)
+        types = None
+        if cfg.mask_factor == 2:
+            types = cond_type.to(dev)
+            if self.training and cfg.cond_drop_rate > 0:
+                types = torch.where(torch.rand(B, device=dev) < cfg.cond_drop_rate, 4, types)
+            types = types.to(torch.int32).contiguous()
+        labels = labels.to(torch.int32).contiguous()
+        x = torch.empty(B * py.L, C, device=dev, dtype=torch.float32)
+        cond = torch.empty(B, C, device=dev, dtype=torch.float32)
+        ops.first_tokens(P['class_emb'], P['cond_embed'], labels, types, P['pos_start'], P['lvl_pos'], x, cond, B, py.first_l, C, py.L)
+        tok = x_BLCv_wo_first_l.to(device=dev, dtype=torch.float32).contiguous()
+        ops.word_embed(tok, P['w_we'], P['b_we'], P['lvl_pos'], x, B, 1, py.L - py.first_l, cfg.cvae, C, py.L, py.first_l, lvl_off=py.first_l)
+        ada = self._ada(cond, B)
+        arena = self._get_arena(B, py.L)
+        logits = self._blocks_and_head(x, ada, B, py.L, 0, py.L, arena, lvl_end=list(py.end))
+        return logits.view(B, py.L, cfg.vocab)
+
+
+class VAR(ControlVAR):
+    """Plain class-conditional VAR (reference: models/var.py:20-291): mask_factor 1, L = 680."""
+    _control = False
+
+    def __init__(self, vae_local: VQVAE, num_classes=1000, norm_eps=1e-6, aln=1, aln_gamma_init=1e-3, shared_aln=False,
+                 cond_drop_rate=0.1, depth=16, embed_dim=1024, num_heads=16, mlp_ratio=4., drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0., layer_scale=-1., tau=4, cos_attn=False, patch_nums=DEFAULT_PATCH_NUMS,
+                 flash_if_available=True, fused_if_available=True, compute_dtype=None, init_seed: int = 0):
+        super().__init__(vae_local, num_classes=num_classes, norm_eps=norm_eps, aln=aln, aln_gamma_init=aln_gamma_init,
+                         shared_aln=shared_aln, cond_drop_rate=cond_drop_rate, depth=depth, embed_dim=embed_dim, num_heads=num_heads,
+                         mlp_ratio=mlp_ratio, drop_rate=drop_rate, attn_drop_rate=attn_drop_rate, drop_path_rate=drop_path_rate,
+                         layer_scale=layer_scale, tau=tau, cos_attn=cos_attn, patch_nums=patch_nums,
+                         flash_if_available=flash_if_available, fused_if_available=fused_if_available, mask_factor=1,
+                         multi_cond=False, compute_dtype=compute_dtype, init_seed=init_seed)
+
+    @torch.no_grad()
+    def autoregressive_infer_cfg(self, B: int, label_B, g_seed: Optional[int] = None, cfg=1.5, top_k=0, top_p=0.0,
+                                 more_smooth=False, _force_idx=None, _trace=False) -> torch.Tensor:
+        """var.py:143-207: returns (B, 3, 256, 256) in [0,1]."""
+        f_hat = self._generate(B, label_B, g_seed, cfg, top_k, top_p, more_smooth, None, False, None, None, _force_idx, _trace)
+        return self._decode_pair(f_hat)
+
+    def conditional_infer_cfg(self, *a, **k):
+        raise NotImplementedError('plain VAR has no conditional_infer_cfg (var.py)')
+
+    @torch.no_grad()
+    def forward(self, label_B, x_BLCv_wo_first_l, cond_type=None, mask_first=True):
+        return super().forward(label_B, x_BLCv_wo_first_l, None, True)
+
+
+# =====================================================================================
+# factories (models/__init__.py:6-45)
+# =====================================================================================
+def build_vae(vocab_size=4096, z_channels=32, ch=160, share_quant_resi=4, v_patch_nums=DEFAULT_PATCH_NUMS, test_mode=True, **kw) -> VQVAE:
+    """The VQVAE every script builds (train_control_var_hpu.py:581-582)."""
+    return VQVAE(vocab_size=vocab_size, z_channels=z_channels, ch=ch, test_mode=test_mode, share_quant_resi=share_quant_resi,
+                 v_patch_nums=v_patch_nums, **kw)
+
+
+def build_var(vae: VQVAE, depth: int, patch_nums=DEFAULT_PATCH_NUMS, aln=1, aln_gamma_init=1e-3, shared_aln=False, layer_scale=-1,
+              tau=4, cos_attn=False, flash_if_available=True, fused_if_available=True, **kw) -> VAR:
+    return VAR(vae_local=vae, patch_nums=patch_nums, depth=depth, embed_dim=depth * 64, num_heads=depth, drop_path_rate=0.1 * depth / 24,
+               aln=aln, aln_gamma_init=aln_gamma_init, shared_aln=shared_aln, layer_scale=layer_scale, tau=tau, cos_attn=cos_attn,
+               flash_if_available=flash_if_available, fused_if_available=fused_if_available, **kw)
+
+
+def build_control_var(vae: VQVAE, depth: int, patch_nums=DEFAULT_PATCH_NUMS, aln=1, aln_gamma_init=1e-3, shared_aln=False, layer_scale=-1,
+                      tau=4, cos_attn=False, flash_if_available=True, fused_if_available=True, mask_type='replace', cond_drop_rate=0.1,
+                      bidirectional=False, separate_decoding=False, separator=False, type_pos=False, indep=False, multi_cond=False,
+                      **kw) -> ControlVAR:
+    if mask_type == 'replace':
+        mask_factor = 1
+    elif mask_type == 'interleave_append':
+        mask_factor = 2
+    else:
+        raise NotImplementedError
+    return ControlVAR(vae_local=vae, patch_nums=patch_nums, depth=depth, embed_dim=depth * 64, num_heads=depth,
+                      drop_path_rate=0.1 * depth / 24, aln=aln, aln_gamma_init=aln_gamma_init, shared_aln=shared_aln,
+                      layer_scale=layer_scale, tau=tau, cos_attn=cos_attn, cond_drop_rate=cond_drop_rate,
+                      flash_if_available=flash_if_available, fused_if_available=fused_if_available, mask_factor=mask_factor,
+                      bidirectional=bidirectional, separate_decoding=separate_decoding, separator=separator, type_pos=type_pos,
+                      indep=indep, multi_cond=multi_cond, **kw)

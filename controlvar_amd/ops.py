@@ -1,0 +1,165 @@
+"""Tensor-facing wrappers over the C ABI (include/cvar.h).
+
+torch is plumbing here: it owns device memory and the stream; every computation is a call
+into libcvar_hip.so with raw pointers.  All functions are asynchronous on the current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU_TANH, ACT_NONE, CVAR_BF16, CVAR_F32, GemmDesc, check
+
+_DT = {torch.float32: CVAR_F32, torch.bfloat16: CVAR_BF16}
+
+
+def dt(t_or_dtype) -> int:
+    d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
+    try:
+        return _DT[d]
+    except KeyError:
+        raise TypeError(f'unsupported dtype {d}') from None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.CvarError('controlvar_amd ops need device tensors (no CPU fallback)')
+    return t.data_ptr()
+
+
+def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, lda: int = 0, ldw: int = 0, ldc: int = 0,
+         bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, alpha: float = 1.0,
+         gate: Optional[torch.Tensor] = None, ldg: int = 0, gate_rows: int = 1, gate_off: int = 0,
+         residual: Optional[torch.Tensor] = None, ldr: int = 0,
+         remap: Optional[Sequence[int]] = None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0, strideR: int = 0,
+         conv: Optional[dict] = None, a_off: int = 0, w_off: int = 0, c_off: int = 0):
+    """C = epilogue(A @ W^T).  Offsets (*_off) are in elements of the respective tensor."""
+    d = GemmDesc()
+    d.M, d.N, d.K, d.dtype = M, N, K, dt(A)
+    if W.dtype != A.dtype:
+        raise TypeError('A and W must share a dtype')
+    d.A = _ptr(A) + a_off * A.element_size()
+    d.W = _ptr(W) + w_off * W.element_size()
+    d.lda, d.ldw = lda or K, ldw or K
+    d.batch, d.strideA, d.strideW, d.strideC, d.strideR = batch, strideA, strideW, strideC, strideR
+    if conv:
+        d.conv = 1
+        d.Hin, d.Win, d.Cin, d.Hout, d.Wout = conv['Hin'], conv['Win'], conv['Cin'], conv['Hout'], conv['Wout']
+        d.stride, d.up = conv.get('stride', 1), conv.get('up', 0)
+    d.alpha = alpha
+    d.bias = _ptr(bias)
+    d.act = act
+    if gate is not None:
+        d.gate = _ptr(gate) + gate_off * 4
+        d.ldg, d.gate_rows = ldg, gate_rows
+    if residual is not None:
+        d.residual, d.res_dtype, d.ldr = _ptr(residual), dt(residual), ldr or N
+    d.C = _ptr(out) + c_off * out.element_size()
+    d.out_dtype, d.ldc = dt(out), ldc or N
+    if remap is not None:
+        d.remap_l, d.remap_L, d.remap_off = remap
+    check(_lib.load().cvar_gemm(C.byref(d), _stream()), 'cvar_gemm')
+    return out
+
+
+def ln_modulate(x: torch.Tensor, ada: torch.Tensor, scale_off: int, shift_off: int, ld_ada: int, rows_per: int,
+                out: torch.Tensor, M: int, Cdim: int, eps: float):
+    base = _ptr(ada)
+    check(_lib.load().cvar_ln_modulate(_ptr(x), base + 4 * scale_off, base + 4 * shift_off, ld_ada, rows_per,
+                                       _ptr(out), dt(out), M, Cdim, eps, _stream()), 'cvar_ln_modulate')
+    return out
+
+
+def silu_cast(x: torch.Tensor, out: torch.Tensor):
+    check(_lib.load().cvar_silu_cast(_ptr(x), _ptr(out), dt(out), x.numel(), _stream()), 'cvar_silu_cast')
+    return out
+
+
+def attention(qkv: torch.Tensor, out: torch.Tensor, R: int, H: int, Lmax: int, q_off: int, l: int, scale: float,
+              lvl_end: Optional[Sequence[int]] = None, qkv_off: int = 0):
+    n = len(lvl_end) if lvl_end else 0
+    arr = (C.c_int * max(n, 1))(*(lvl_end or [0]))
+    check(_lib.load().cvar_attention(_ptr(qkv) + qkv_off * qkv.element_size(), dt(qkv), R, H, Lmax, q_off, l, scale,
+                                     arr, n, _ptr(out), _stream()), 'cvar_attention')
+    return out
+
+
+def cos_qk_norm(qkv: torch.Tensor, R: int, H: int, Lmax: int, q_off: int, l: int, scale_mul: torch.Tensor,
+                qkv_off: int = 0, sm_off: int = 0):
+    check(_lib.load().cvar_cos_qk_norm(_ptr(qkv) + qkv_off * qkv.element_size(), dt(qkv), R, H, Lmax, q_off, l,
+                                       _ptr(scale_mul) + 4 * sm_off, _stream()), 'cvar_cos_qk_norm')
+
+
+def cfg_sample(logits: torch.Tensor, B: int, nrep: int, l: int, V: int, coef: Sequence[float], top_k: int, top_p: float,
+               seed: int, stage: int, n_draw: int, idx_out: torch.Tensor, combined: Optional[torch.Tensor] = None,
+               margin: Optional[torch.Tensor] = None, kept: Optional[torch.Tensor] = None):
+    arr = (C.c_float * 4)(*(list(coef) + [0.0] * (4 - len(coef))))
+    check(_lib.load().cvar_cfg_sample(_ptr(logits), B, nrep, l, V, arr, top_k, float(top_p), int(seed) & (2 ** 64 - 1), stage, n_draw,
+                                      _ptr(idx_out), _ptr(combined), _ptr(margin), _ptr(kept), _stream()), 'cvar_cfg_sample')
+    return idx_out
+
+
+def ms_next_input(idx: torch.Tensor, codebook, phi_w, phi_b, up, down, f_hat, tok_out, nb, nmaps, pn, pn_next, S, Cvae,
+                  phi_k: int, up_off: int, down_off: int):
+    lib = _lib.load()
+    pw = _ptr(phi_w) + 4 * phi_k * Cvae * 9 * Cvae
+    pb = _ptr(phi_b) + 4 * phi_k * Cvae
+    check(lib.cvar_ms_next_input(_ptr(idx), _ptr(codebook), pw, pb, _ptr(up) + 4 * up_off, _ptr(down) + 4 * down_off,
+                                 _ptr(f_hat), _ptr(tok_out), nb, nmaps, pn, pn_next, S, Cvae, _stream()), 'cvar_ms_next_input')
+
+
+def ms_encode(f, codebook, V, phi_w, phi_b, phi_map, patch_nums, up, down, idx_out, f_hat_out, margin_out, B, S, Cvae):
+    n = len(patch_nums)
+    pm = (C.c_int * n)(*phi_map)
+    pn = (C.c_int * n)(*patch_nums)
+    check(_lib.load().cvar_ms_encode(_ptr(f), _ptr(codebook), V, _ptr(phi_w), _ptr(phi_b), pm, pn, n, _ptr(up), _ptr(down),
+                                     _ptr(idx_out), _ptr(f_hat_out), _ptr(margin_out), B, S, Cvae, _stream()), 'cvar_ms_encode')
+
+
+def word_embed(tok, W, bias, lvl_pos, x, nb, nrep, l, Cvae, Cdim, x_rows, x_off, lvl_off: int = 0):
+    check(_lib.load().cvar_word_embed(_ptr(tok), _ptr(W), _ptr(bias), _ptr(lvl_pos) + 4 * lvl_off * Cdim, _ptr(x), nb, nrep, l, Cvae, Cdim,
+                                      x_rows, x_off, _stream()), 'cvar_word_embed')
+
+
+def first_tokens(class_emb, cond_embed, labels, types, pos_start, lvl_pos, x, cond, R, first_l, Cdim, x_rows):
+    check(_lib.load().cvar_first_tokens(_ptr(class_emb), _ptr(cond_embed), _ptr(labels), _ptr(types), _ptr(pos_start), _ptr(lvl_pos),
+                                        _ptr(x), _ptr(cond), R, first_l, Cdim, x_rows, _stream()), 'cvar_first_tokens')
+
+
+def groupnorm_ws_bytes(B, HW, Cdim) -> int:
+    return int(_lib.load().cvar_groupnorm_ws_bytes(B, HW, Cdim))
+
+
+def groupnorm_silu(x, weight, bias, out, B, HW, Cdim, groups, eps, silu, ws):
+    check(_lib.load().cvar_groupnorm_silu(_ptr(x), dt(x), _ptr(weight), _ptr(bias), _ptr(out), B, HW, Cdim, groups, eps, int(silu),
+                                          _ptr(ws), _stream()), 'cvar_groupnorm_silu')
+    return out
+
+
+def softmax_rows(s, p, rows, cols):
+    check(_lib.load().cvar_softmax_rows(_ptr(s), _ptr(p), dt(p), rows, cols, _stream()), 'cvar_softmax_rows')
+    return p
+
+
+def transpose(inp, out, B, n, c, ld_in, in_off: int = 0):
+    check(_lib.load().cvar_transpose(_ptr(inp) + in_off * inp.element_size(), _ptr(out), dt(inp), B, n, c, ld_in, _stream()), 'cvar_transpose')
+    return out
+
+
+def nchw_to_nhwc(inp, out, B, Cdim, HW, Cpad):
+    check(_lib.load().cvar_nchw_to_nhwc(_ptr(inp), _ptr(out), dt(out), B, Cdim, HW, Cpad, _stream()), 'cvar_nchw_to_nhwc')
+    return out
+
+
+def nhwc_to_nchw(inp, ld_in, out, B, Cdim, HW, lo=-3.0e38, hi=3.0e38, mul=1.0, add=0.0):
+    check(_lib.load().cvar_nhwc_to_nchw(_ptr(inp), dt(inp), ld_in, _ptr(out), B, Cdim, HW, lo, hi, mul, add, _stream()), 'cvar_nhwc_to_nchw')
+    return out

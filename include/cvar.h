@@ -1,0 +1,154 @@
+/* cvar.h - C ABI of libcvar_hip.so: the MI355X (gfx950) hot path of lxa9867/ControlVAR.
+ *
+ * The reference has no FFI; its operator boundary is Python:
+ *   L2 model API  models/__init__.py:6-45, models/control_var.py:223-651, models/vqvae.py:73-104
+ *   L0 op slots   models/basic_var.py:15-29 (flash_attn_func, fused_mlp_func, slow_attn, ...)
+ * Each entry point below replaces the ATen / fused-op sequence cited next to it, and is what a
+ * ctypes stub on the reference side binds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (no allocation inside the library), except the
+ *     small parameter arrays suffixed `_host` (copied into the launch); row-major, dims passed explicitly; `stream` is a hipStream_t passed as void* (NULL = default);
+ *   - all calls are asynchronous on `stream`, re-entrant, no global mutable state;
+ *   - return 0 on success, a negative cvar_status otherwise (never aborts across the ABI);
+ *   - dtype codes: CVAR_F32 (parity mode, exact-f32 MFMA) or CVAR_BF16 (throughput mode, f32 accumulate).
+ */
+#ifndef CVAR_H
+#define CVAR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { CVAR_OK = 0, CVAR_EINVAL = -1, CVAR_EUNSUPPORTED = -2, CVAR_ELAUNCH = -3 } cvar_status;
+typedef enum { CVAR_F32 = 0, CVAR_BF16 = 1 } cvar_dtype;
+typedef enum { CVAR_ACT_NONE = 0, CVAR_ACT_GELU_TANH = 1 } cvar_act;
+
+int cvar_abi_version(void);                 /* bumps on any signature change */
+const char* cvar_status_str(int status);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue, optionally an implicit-GEMM 3x3 convolution over NHWC activations.
+ *   C[row(m), n] = cast( residual[m,n] + gate[m / gate_rows, n] * act(alpha * sum_k A[m,k] W[n,k] + bias[n]) )
+ * Replaces: F.linear qkv/proj/fc1/fc2/head/ada_lin (basic_var.py:51,92,119,207; control_var.py:221,700),
+ *           fused_mlp_func slot (basic_var.py:44-49), the gated residual x + gamma*f(x) (basic_var.py:208-209),
+ *           nn.Conv2d 3x3/1x1 of the VQVAE (vae_modules.py:25,34,48-53,69-71,113,142,180,208; vqvae.py:48-49).
+ * A and W have element type `dtype`, K contiguous.  conv: A is X[B][Hin][Win][Cin], W is [N][ky][kx][Cin]
+ * (K = 9*Cin), output pixel m=(b,oy,ox); `up`=1 reads X through a nearest x2 upsample (vae_modules.py:28),
+ * `stride`=2 is the asymmetric (0,1,0,1)-padded downsample (vae_modules.py:37).
+ * Output row remap (remap_l > 0): row(m) = (m / remap_l) * remap_L + remap_off + m % remap_l  - used to write
+ * the qkv rows of one scale straight into the per-sequence KV arena [R][Lmax][3C] (replaces torch.cat,
+ * basic_var.py:106-108). */
+typedef struct {
+    int M, N, K;
+    int dtype;                       /* cvar_dtype of A and W */
+    const void* A; int64_t lda;      /* plain mode: row stride in elements (ignored for conv) */
+    const void* W; int64_t ldw;
+    int batch;                       /* >= 1; grid.z */
+    int64_t strideA, strideW, strideC, strideR;   /* per-batch strides in elements */
+    /* conv mode */
+    int conv;                        /* 0 plain GEMM, 1 implicit 3x3 conv */
+    int Hin, Win, Cin, Hout, Wout, stride, up;
+    /* epilogue */
+    float alpha;
+    const float* bias;               /* [N] or NULL */
+    int act;                         /* cvar_act */
+    const float* gate; int64_t ldg; int gate_rows;   /* gate[(m / gate_rows) * ldg + n] or NULL */
+    const void* residual; int res_dtype; int64_t ldr;
+    void* C; int out_dtype; int64_t ldc;
+    int remap_l, remap_L, remap_off;
+} cvar_gemm_desc;
+int cvar_gemm(const cvar_gemm_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * adaLN: out[m,:] = cast( LN(x[m,:]) * (1 + scale[m / rows_per, :]) + shift[m / rows_per, :] ), LN over C with
+ * biased variance, no affine.  Replaces ln_wo_grad(x).mul(scale.add(1)).add_(shift) (basic_var.py:208-209;
+ * control_var.py:701).  x fp32 [M,C]; scale/shift fp32 rows of stride ld_ada. */
+int cvar_ln_modulate(const float* x, const float* scale, const float* shift, int64_t ld_ada, int rows_per,
+                     void* out, int out_dtype, int M, int C, float eps, void* stream);
+
+/* SiLU + cast (the nn.SiLU in front of every ada_lin, basic_var.py:198): out = cast(x * sigmoid(x)). */
+int cvar_silu_cast(const float* x, void* out, int out_dtype, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Multi-scale KV-cached attention (slow_attn / flash_attn_func slots, basic_var.py:106-117).
+ * qkv arena: [R][Lmax][3*H*64] of `dtype` (q | k | v thirds, head-major inside a third), written by cvar_gemm
+ * with the row remap.  Queries are rows [q_off, q_off+l) of every sequence, keys rows [0, kv_len(q)).
+ * kv_len: if n_lvl == 0 every query sees [0, q_off+l) (inference, attn_bias=None); otherwise lvl_end[] holds the
+ * n_lvl cumulative scale ends and a query at position p sees keys < lvl_end[level(p)] - the block-causal
+ * attn_bias_for_masking of training (control_var.py:158-168).  out: [R*l][H*64] of `dtype`. */
+int cvar_attention(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
+                   const int* lvl_end_host, int n_lvl, void* out, void* stream);
+
+/* cos-attention pre-pass (basic_var.py:99-104), in place on rows [q_off, q_off+l) of the arena:
+ * q = normalize(q) * exp(min(scale_mul[h], log 100)),  k = normalize(k). */
+int cvar_cos_qk_norm(void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, const float* scale_mul,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * CFG combine + sampling (control_var.py:295-307,501-505; helpers.py:6-19).
+ * logits: [nrep*B][l][V] fp32 (row groups: cond, then unconditional variants); coef[nrep] combine weights
+ * ((1+t, -t) or the 4-branch form).  top_k == 1: greedy argmax (lowest index on ties).  Otherwise top-k /
+ * top-p filtering as the reference, then one draw per row of `n_draw` independent rows from a counter-based
+ * generator keyed by (seed, stage, row).  idx_out: [n_draw*B][l] int32.  Optional outputs (may be NULL):
+ * combined [B][l][V] fp32, margin [B][l] fp32 (top1 - top2 of the combined logits), kept [B][l] int32. */
+int cvar_cfg_sample(const float* logits, int B, int nrep, int l, int V, const float* coef_host,
+                    int top_k, float top_p, uint64_t seed, int stage, int n_draw,
+                    int32_t* idx_out, float* combined, float* margin, int32_t* kept, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Token-pyramid helpers of VectorQuantizer2 (models/quant.py).
+ * Operator tables (host-computed, device-resident fp32): up[k]  = bicubic (S x pn_k), down[k] = area (pn_k x S),
+ * packed back to back in pyramid order (see controlvar_amd/pyramid.py).
+ *
+ * cvar_ms_next_input: get_next_autoregressive_input (quant.py:243-260) for `nmaps` maps per batch row:
+ *   f_hat[b][map] += phi_si( bicubic( E[idx[b][map*pn^2 ...]] ) );  tok_out[b][map*pn'^2 + t][:] = area(f_hat, pn')
+ *   (tok_out may be NULL at the last scale).  idx int32 [nb][nmaps*pn*pn]; f_hat fp32 [nb][nmaps][Cvae][S][S]. */
+int cvar_ms_next_input(const int32_t* idx, const float* codebook, const float* phi_w, const float* phi_b,
+                       const float* up_mat, const float* down_mat, float* f_hat, float* tok_out,
+                       int nb, int nmaps, int pn, int pn_next, int S, int Cvae, void* stream);
+
+/* cvar_ms_encode: f_to_idxBl_or_fhat (quant.py:184-215): 10-stage residual nearest-code quantisation of
+ * f [B][Cvae][S][S] fp32.  idx_out int32 [B][sum pn^2] (scale-major); f_hat_out (optional) [B][Cvae][S][S];
+ * margin_out (optional) [B][sum pn^2] = second-best minus best distance. */
+int cvar_ms_encode(const float* f, const float* codebook, int V, const float* phi_w, const float* phi_b,
+                   const int* phi_map_host, const int* patch_nums_host, int nscale, const float* up_mats,
+                   const float* down_mats, int32_t* idx_out, float* f_hat_out, float* margin_out,
+                   int B, int S, int Cvae, void* stream);
+
+/* word_embed + level/position embedding of the next scale (control_var.py:534-560):
+ * x[rep*nb + b][x_off + t][:] = tok[b][t][:] @ W^T + bias + lvl_pos[t][:], for rep in [0, nrep); x has x_rows
+ * rows per sequence (x_rows = l, x_off = 0 for one scale; x_rows = L for the teacher-forced forward).  fp32. */
+int cvar_word_embed(const float* tok, const float* W, const float* bias, const float* lvl_pos, float* x,
+                    int nb, int nrep, int l, int Cvae, int C, int x_rows, int x_off, void* stream);
+
+/* first-scale tokens (control_var.py:381-409): x[r][j][:] = src_j[id_j[r]][:] + pos_start[j][:] + lvl_pos[j][:]
+ * with src_0 = cond_embed / class_emb(mf=1), src_1 = class_emb; also cond[r][:] = class_emb[labels[r]][:]. */
+int cvar_first_tokens(const float* class_emb, const float* cond_embed, const int32_t* labels, const int32_t* types,
+                      const float* pos_start, const float* lvl_pos, float* x, float* cond, int R, int first_l,
+                      int C, int x_rows, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * VQVAE conv-stack helpers (models/vae_modules.py).
+ * GroupNorm(32 groups, eps, affine) [+ SiLU] over NHWC activations (vae_modules.py:18-19,58-59):
+ * ws: caller workspace of cvar_groupnorm_ws_bytes(B, HW, C) bytes (per-chunk partial sums, reduced in a fixed
+ * order: the result is bit-reproducible run to run). */
+int64_t cvar_groupnorm_ws_bytes(int B, int HW, int C);
+int cvar_groupnorm_silu(const void* x, int dtype, const float* weight, const float* bias, void* out,
+                        int B, int HW, int C, int groups, float eps, int silu, void* ws, void* stream);
+/* row softmax of fp32 scores -> dtype probabilities (AttnBlock, vae_modules.py:84). */
+int cvar_softmax_rows(const float* s, void* p, int out_dtype, int rows, int cols, void* stream);
+/* [B][n][c] -> [B][c][n] transpose of `dtype` (V operand of AttnBlock's second bmm, vae_modules.py:87-89). */
+int cvar_transpose(const void* in, void* out, int dtype, int B, int n, int c, int64_t ld_in, void* stream);
+/* NCHW fp32 -> NHWC dtype with channel padding to Cpad (zero filled). */
+int cvar_nchw_to_nhwc(const float* in, void* out, int dtype, int B, int C, int HW, int Cpad, void* stream);
+/* NHWC (ld = ldc) -> NCHW fp32 with y = clamp(x, lo, hi) * mul + add  (vqvae.py:89; control_var.py:563-564). */
+int cvar_nhwc_to_nchw(const void* in, int dtype, int64_t ld_in, float* out, int B, int C, int HW,
+                      float lo, float hi, float mul, float add, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVAR_H */

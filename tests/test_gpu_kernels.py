@@ -1,0 +1,270 @@
+"""Per-kernel numerics of libcvar_hip.so on a real MI355X, each against a plain torch fp32
+computation of the same op (CPU).  All calls go through the C ABI (controlvar_amd.ops)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from controlvar_amd import ops  # noqa: E402
+from controlvar_amd._lib import ACT_GELU_TANH  # noqa: E402
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def to_dev(t, dtype, dev):
+    return t.to(dtype).to(dev).contiguous()
+
+
+def tol(dtype):
+    return (2e-5, 2e-5) if dtype == torch.float32 else (2e-2, 2e-2)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('M,N,K', [(200, 130, 72), (256, 256, 256), (64, 384, 128), (3, 5, 8), (1000, 96, 1536)])
+def test_gemm_plain(gpu_device, dtype, M, N, K):
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    Ad, Wd = to_dev(A, dtype, gpu_device), to_dev(W, dtype, gpu_device)
+    out = torch.empty(M, N, device=gpu_device, dtype=torch.float32)
+    ops.gemm(Ad, Wd, out, M=M, N=N, K=K, bias=b.to(gpu_device))
+    ref = Ad.float().cpu() @ Wd.float().cpu().t() + b
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < (1e-4 if dtype == torch.float32 else 2e-3) * math.sqrt(K), err
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(gpu_device, dtype):
+    M, N, K, l = 192, 160, 64, 48           # 4 sequences of 48 rows
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    gate = rnd(M // l, 3 * N, seed=4)        # gate lives at column offset N of a wider table
+    x = rnd(M, N, seed=5)
+    Ad, Wd = to_dev(A, dtype, gpu_device), to_dev(W, dtype, gpu_device)
+    acc = Ad.float().cpu() @ Wd.float().cpu().t() + b
+    # bias + gelu -> compute dtype
+    out = torch.empty(M, N, device=gpu_device, dtype=dtype)
+    ops.gemm(Ad, Wd, out, M=M, N=N, K=K, bias=b.to(gpu_device), act=ACT_GELU_TANH)
+    ref = F.gelu(acc, approximate='tanh')
+    assert (out.float().cpu() - ref).abs().max() < (1e-4 if dtype == torch.float32 else 3e-2)
+    # gated residual in place (fp32 residual stream)
+    xd = x.to(gpu_device).clone()
+    ops.gemm(Ad, Wd, xd, M=M, N=N, K=K, bias=b.to(gpu_device), gate=gate.to(gpu_device), gate_off=N, ldg=3 * N, gate_rows=l, residual=xd)
+    g = gate[:, N:2 * N].repeat_interleave(l, dim=0)
+    ref = x + acc * g
+    assert (xd.cpu() - ref).abs().max() < (2e-4 if dtype == torch.float32 else 3e-2)
+    # row remap into an arena [R][Lmax][N]
+    R, Lmax, off = M // l, 100, 7
+    arena = torch.zeros(R, Lmax, N, device=gpu_device, dtype=dtype)
+    ops.gemm(Ad, Wd, arena, M=M, N=N, K=K, bias=b.to(gpu_device), remap=(l, Lmax, off))
+    got = arena[:, off:off + l].reshape(M, N).float().cpu()
+    assert (got - acc).abs().max() < (1e-4 if dtype == torch.float32 else 3e-2)
+    assert arena[:, :off].abs().max() == 0 and arena[:, off + l:].abs().max() == 0
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gemm_batched_strided(gpu_device, dtype):
+    B, n, c = 3, 96, 64
+    qkv = rnd(B, n, 3 * c, seed=7)
+    qd = to_dev(qkv, dtype, gpu_device)
+    s = torch.empty(B, n, n, device=gpu_device, dtype=torch.float32)
+    ops.gemm(qd, qd, s, M=n, N=n, K=c, lda=3 * c, ldw=3 * c, w_off=c, alpha=0.125, batch=B, strideA=n * 3 * c, strideW=n * 3 * c, strideC=n * n)
+    q, k = qd.float().cpu()[..., :c], qd.float().cpu()[..., c:2 * c]
+    ref = torch.bmm(q, k.transpose(1, 2)) * 0.125
+    assert (s.cpu() - ref).abs().max() < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('mode', ['s1', 'up', 's2'])
+@pytest.mark.parametrize('cin,cout', [(32, 48), (160, 160), (8, 24)])
+def test_conv3x3(gpu_device, dtype, mode, cin, cout):
+    B, H, W = 2, 12, 10
+    x = rnd(B, cin, H, W, seed=11)
+    w = rnd(cout, cin, 3, 3, seed=12, scale=1.0 / math.sqrt(9 * cin))
+    b = rnd(cout, seed=13)
+    res = None
+    xr = x.to(dtype).float()
+    wr = w.to(dtype).float()
+    if mode == 's1':
+        ref = F.conv2d(xr, wr, b, padding=1); Ho, Wo = H, W
+        res = rnd(B, cout, H, W, seed=14)
+        ref = ref + res.to(dtype).float()
+    elif mode == 'up':
+        ref = F.conv2d(F.interpolate(xr, scale_factor=2, mode='nearest'), wr, b, padding=1); Ho, Wo = 2 * H, 2 * W
+    else:
+        ref = F.conv2d(F.pad(xr, (0, 1, 0, 1)), wr, b, stride=2, padding=0); Ho, Wo = H // 2, W // 2
+    xd = to_dev(x.permute(0, 2, 3, 1).reshape(B * H * W, cin), dtype, gpu_device)
+    wd = to_dev(w.permute(0, 2, 3, 1).reshape(cout, 9 * cin), dtype, gpu_device)
+    resd = to_dev(res.permute(0, 2, 3, 1).reshape(B * Ho * Wo, cout), dtype, gpu_device) if res is not None else None
+    out = torch.empty(B * Ho * Wo, cout, device=gpu_device, dtype=torch.float32)
+    ops.gemm(xd, wd, out, M=B * Ho * Wo, N=cout, K=9 * cin, bias=b.to(gpu_device), residual=resd,
+             conv=dict(Hin=H, Win=W, Cin=cin, Hout=Ho, Wout=Wo, stride=2 if mode == 's2' else 1, up=1 if mode == 'up' else 0))
+    got = out.cpu().reshape(B, Ho, Wo, cout).permute(0, 3, 1, 2)
+    assert (got - ref).abs().max() < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize('out_dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('C', [128, 768, 1920])
+def test_ln_modulate(gpu_device, out_dtype, C):
+    R, l = 3, 7
+    x = rnd(R * l, C, seed=1, scale=2.0) + 0.5
+    ada = rnd(R, 6 * C, seed=2, scale=0.3)
+    out = torch.empty(R * l, C, device=gpu_device, dtype=out_dtype)
+    ops.ln_modulate(x.to(gpu_device), ada.to(gpu_device), 2 * C, 4 * C, 6 * C, l, out, R * l, C, 1e-6)
+    sc = ada[:, 2 * C:3 * C].repeat_interleave(l, 0)
+    sh = ada[:, 4 * C:5 * C].repeat_interleave(l, 0)
+    ref = F.layer_norm(x, (C,), eps=1e-6) * (1 + sc) + sh
+    assert (out.float().cpu() - ref).abs().max() < (2e-5 if out_dtype == torch.float32 else 3e-2)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('masked', [False, True])
+def test_attention(gpu_device, dtype, masked):
+    R, H, c = 2, 3, 64
+    lvl_end = [2, 10, 28, 60]
+    Lmax = 60
+    C3 = 3 * H * c
+    qkv = rnd(R, Lmax, C3, seed=5)
+    qd = to_dev(qkv, dtype, gpu_device)
+    qf = qd.float().cpu().view(R, Lmax, 3, H, c)
+    scale = 0.03125
+    if masked:
+        q_off, l = 0, Lmax
+    else:
+        q_off, l = 28, 32
+    out = torch.empty(R * l, H * c, device=gpu_device, dtype=dtype)
+    ops.attention(qd, out, R, H, Lmax, q_off, l, scale, lvl_end if masked else None)
+    q = qf[:, q_off:q_off + l, 0].permute(0, 2, 1, 3)
+    k = qf[:, :q_off + l, 1].permute(0, 2, 1, 3)
+    v = qf[:, :q_off + l, 2].permute(0, 2, 1, 3)
+    s = q @ k.transpose(-1, -2) * scale
+    if masked:
+        lvl = torch.cat([torch.full((e - b,), i) for i, (b, e) in enumerate(zip([0] + lvl_end[:-1], lvl_end))])
+        s = s + torch.where(lvl.view(-1, 1) >= lvl.view(1, -1), 0., -torch.inf)
+    ref = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(R * l, H * c)
+    assert (out.float().cpu() - ref).abs().max() < (2e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_cos_qk_norm(gpu_device, dtype):
+    R, H, Lmax, q_off, l = 2, 3, 20, 5, 9
+    qkv = rnd(R, Lmax, 3 * H * 64, seed=3)
+    sm = torch.tensor([0.2, 1.4, 5.0])
+    qd = to_dev(qkv, dtype, gpu_device)
+    before = qd.float().cpu().clone()
+    ops.cos_qk_norm(qd, R, H, Lmax, q_off, l, sm.to(gpu_device))
+    after = qd.float().cpu().view(R, Lmax, 3, H, 64)
+    b5 = before.view(R, Lmax, 3, H, 64)
+    ref = b5.clone()
+    ref[:, q_off:q_off + l, 0] = F.normalize(b5[:, q_off:q_off + l, 0], dim=-1) * sm.clamp_max(math.log(100)).exp().view(1, 1, H, 1)
+    ref[:, q_off:q_off + l, 1] = F.normalize(b5[:, q_off:q_off + l, 1], dim=-1)
+    assert (after - ref).abs().max() < (1e-5 if dtype == torch.float32 else 0.2)
+    assert torch.equal(after[:, :q_off], b5[:, :q_off]) and torch.equal(after[:, :, 2], b5[:, :, 2])
+
+
+def test_cfg_greedy_and_combine(gpu_device):
+    B, l, V = 3, 5, 4096
+    logits = rnd(2 * B, l, V, seed=9, scale=3.0)
+    t = 4.0 * 3 / 9
+    idx = torch.empty(B, l, device=gpu_device, dtype=torch.int32)
+    comb = torch.empty(B, l, V, device=gpu_device)
+    mg = torch.empty(B, l, device=gpu_device)
+    ops.cfg_sample(logits.to(gpu_device), B, 2, l, V, [1 + t, -t], 1, 0.0, 0, 3, 1, idx, comb, mg)
+    ref = (1 + t) * logits[:B] - t * logits[B:]
+    assert torch.equal(comb.cpu(), ref)                       # same evaluation order -> bit identical
+    assert torch.equal(idx.cpu().long(), ref.argmax(-1))
+    t2 = ref.topk(2, dim=-1).values
+    assert torch.allclose(mg.cpu(), t2[..., 0] - t2[..., 1])
+    # 4-branch form
+    lg4 = rnd(4 * B, l, V, seed=10)
+    c = [1 + 1.0, 0.5 - 1.0, 0.25 - 0.5, -0.25]
+    idx4 = torch.empty(4 * B, l, device=gpu_device, dtype=torch.int32)
+    ops.cfg_sample(lg4.to(gpu_device), B, 4, l, V, c, 1, 0.0, 0, 0, 4, idx4, comb, None)
+    np32 = np.float32
+    ref4 = (np32(c[0]) * lg4[:B] + np32(c[1]) * lg4[B:2 * B] + np32(c[2]) * lg4[2 * B:3 * B]) + np32(c[3]) * lg4[3 * B:]
+    assert torch.equal(comb.cpu(), ref4)
+    assert torch.equal(idx4.cpu().long(), ref4.argmax(-1).repeat(4, 1))
+
+
+def test_cfg_sample_topk_topp(gpu_device):
+    """kept-set size equals the reference filter's; draws stay inside the kept set and follow its distribution."""
+    from oracle.var_ref import topk_topp_mask_
+    B, l, V = 2, 4, 4096
+    logits = rnd(2 * B, l, V, seed=21, scale=2.5)
+    t = 1.7
+    ref = (1 + t) * logits[:B] - t * logits[B:]
+    for (k, p) in [(900, 0.96), (0, 0.5), (50, 0.0)]:
+        masked = topk_topp_mask_(ref.clone(), k, p)
+        kept_ref = torch.isfinite(masked)
+        kept = torch.empty(B, l, device=gpu_device, dtype=torch.int32)
+        idx = torch.empty(B, l, device=gpu_device, dtype=torch.int32)
+        counts = torch.zeros(B, l, V)
+        n_rounds = 300
+        for s in range(n_rounds):
+            ops.cfg_sample(logits.to(gpu_device), B, 2, l, V, [1 + t, -t], k, p, 1234 + s, 2, 1, idx, None, None, kept)
+            i = idx.cpu().long()
+            assert kept_ref.gather(-1, i.unsqueeze(-1)).all(), 'draw outside the reference kept set'
+            counts.scatter_add_(-1, i.unsqueeze(-1), torch.ones(B, l, 1))
+        assert (kept.cpu().long() - kept_ref.sum(-1)).abs().max() <= 1
+        probs = masked.softmax(-1)
+        top = probs.argmax(-1, keepdim=True)
+        p_top = probs.gather(-1, top).squeeze(-1)
+        f_top = counts.gather(-1, top).squeeze(-1) / n_rounds
+        assert (f_top - p_top).abs().max() < 5 * (p_top * (1 - p_top) / n_rounds).sqrt().max() + 0.02
+
+
+def test_word_embed_first_tokens(gpu_device):
+    nb, l, Cv, C = 3, 8, 32, 128
+    tok, W, b = rnd(nb, l, Cv, seed=1), rnd(C, Cv, seed=2), rnd(C, seed=3)
+    lvl = rnd(40, C, seed=4)
+    x = torch.zeros(2 * nb, l, C, device=gpu_device)
+    ops.word_embed(tok.to(gpu_device), W.to(gpu_device), b.to(gpu_device), lvl.to(gpu_device), x, nb, 2, l, Cv, C, l, 0, lvl_off=10)
+    ref = F.linear(tok, W, b) + lvl[10:10 + l]
+    assert (x.cpu() - ref.repeat(2, 1, 1)).abs().max() < 1e-5
+    R = 4
+    ce, cd = rnd(1001, C, seed=5), rnd(5, C, seed=6)
+    ps = rnd(2, C, seed=7)
+    labels = torch.tensor([3, 1000, 999, 0], dtype=torch.int32)
+    types = torch.tensor([0, 4, 2, 3], dtype=torch.int32)
+    x0 = torch.empty(R, 2, C, device=gpu_device)
+    cond = torch.empty(R, C, device=gpu_device)
+    ops.first_tokens(ce.to(gpu_device), cd.to(gpu_device), labels.to(gpu_device), types.to(gpu_device), ps.to(gpu_device), lvl.to(gpu_device), x0, cond, R, 2, C, 2)
+    ref0 = torch.stack([cd[types.long()], ce[labels.long()]], 1) + ps + lvl[:2]
+    assert (x0.cpu() - ref0).abs().max() < 1e-6 and torch.equal(cond.cpu(), ce[labels.long()])
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('C,HW', [(160, 1024), (640, 256), (32, 4096)])
+def test_groupnorm_silu(gpu_device, dtype, C, HW):
+    B = 2
+    x = rnd(B, HW, C, seed=1, scale=1.5) + 0.7
+    w, b = rnd(C, seed=2, scale=0.1) + 1, rnd(C, seed=3, scale=0.1)
+    xd = to_dev(x, dtype, gpu_device)
+    out = torch.empty_like(xd)
+    ws = torch.empty(ops.groupnorm_ws_bytes(B, HW, C), device=gpu_device, dtype=torch.uint8)
+    ops.groupnorm_silu(xd, w.to(gpu_device), b.to(gpu_device), out, B, HW, C, 32, 1e-6, True, ws)
+    ref = F.silu(F.group_norm(xd.float().cpu().permute(0, 2, 1), 32, w, b, eps=1e-6)).permute(0, 2, 1)
+    assert (out.float().cpu() - ref).abs().max() < (2e-5 if dtype == torch.float32 else 3e-2)
+
+
+def test_softmax_transpose_layout(gpu_device):
+    s = rnd(12, 256, seed=1, scale=3)
+    p = torch.empty(12, 256, device=gpu_device)
+    ops.softmax_rows(s.to(gpu_device), p, 12, 256)
+    assert (p.cpu() - s.softmax(-1)).abs().max() < 1e-6
+    x = rnd(2, 50, 3 * 40, seed=2)
+    out = torch.empty(2, 40, 50, device=gpu_device)
+    ops.transpose(x.to(gpu_device), out, 2, 50, 40, 120, in_off=80)
+    assert torch.equal(out.cpu(), x[:, :, 80:].transpose(1, 2))
+    img = rnd(2, 3, 64, seed=3)
+    o = torch.empty(2 * 64, 8, device=gpu_device, dtype=torch.bfloat16)
+    ops.nchw_to_nhwc(img.to(gpu_device), o, 2, 3, 64, 8)
+    oc = o.float().cpu().view(2, 64, 8)
+    assert torch.equal(oc[..., :3], img.to(torch.bfloat16).float().permute(0, 2, 1)) and oc[..., 3:].abs().max() == 0
+    back = torch.empty(2, 3, 64, device=gpu_device)
+    ops.nhwc_to_nchw(o, 8, back, 2, 3, 64, -0.5, 0.5, 0.5, 0.5)
+    assert torch.allclose(back.cpu(), img.to(torch.bfloat16).float().clamp(-0.5, 0.5) * 0.5 + 0.5)
