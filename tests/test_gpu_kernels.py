@@ -22,8 +22,12 @@ def to_dev(t, dtype, dev):
     return t.to(dtype).to(dev).contiguous()
 
 
-def tol(dtype):
-    return (2e-5, 2e-5) if dtype == torch.float32 else (2e-2, 2e-2)
+def close(got, ref, dtype, f32_tol=1e-4, bf16_rel=1e-2):
+    """fp32: absolute tolerance; bf16 outputs: 1e-2 * (|ref| + 1) (bf16 has 8 mantissa bits)"""
+    got, ref = got.float().cpu(), ref.float()
+    if dtype == torch.float32:
+        return bool(((got - ref).abs() <= f32_tol * (ref.abs() + 1)).all())
+    return bool(((got - ref).abs() <= bf16_rel * (ref.abs() + 1)).all())
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
@@ -50,19 +54,19 @@ def test_gemm_epilogues(gpu_device, dtype):
     out = torch.empty(M, N, device=gpu_device, dtype=dtype)
     ops.gemm(Ad, Wd, out, M=M, N=N, K=K, bias=b.to(gpu_device), act=ACT_GELU_TANH)
     ref = F.gelu(acc, approximate='tanh')
-    assert (out.float().cpu() - ref).abs().max() < (1e-4 if dtype == torch.float32 else 3e-2)
+    assert close(out, ref, dtype)
     # gated residual in place (fp32 residual stream)
     xd = x.to(gpu_device).clone()
     ops.gemm(Ad, Wd, xd, M=M, N=N, K=K, bias=b.to(gpu_device), gate=gate.to(gpu_device), gate_off=N, ldg=3 * N, gate_rows=l, residual=xd)
     g = gate[:, N:2 * N].repeat_interleave(l, dim=0)
     ref = x + acc * g
-    assert (xd.cpu() - ref).abs().max() < (2e-4 if dtype == torch.float32 else 3e-2)
+    assert close(xd, ref, dtype, 2e-4)
     # row remap into an arena [R][Lmax][N]
     R, Lmax, off = M // l, 100, 7
     arena = torch.zeros(R, Lmax, N, device=gpu_device, dtype=dtype)
     ops.gemm(Ad, Wd, arena, M=M, N=N, K=K, bias=b.to(gpu_device), remap=(l, Lmax, off))
     got = arena[:, off:off + l].reshape(M, N).float().cpu()
-    assert (got - acc).abs().max() < (1e-4 if dtype == torch.float32 else 3e-2)
+    assert close(got, acc, dtype)
     assert arena[:, :off].abs().max() == 0 and arena[:, off + l:].abs().max() == 0
 
 
@@ -75,7 +79,7 @@ def test_gemm_batched_strided(gpu_device, dtype):
     ops.gemm(qd, qd, s, M=n, N=n, K=c, lda=3 * c, ldw=3 * c, w_off=c, alpha=0.125, batch=B, strideA=n * 3 * c, strideW=n * 3 * c, strideC=n * n)
     q, k = qd.float().cpu()[..., :c], qd.float().cpu()[..., c:2 * c]
     ref = torch.bmm(q, k.transpose(1, 2)) * 0.125
-    assert (s.cpu() - ref).abs().max() < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert close(s, ref, dtype)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
@@ -104,7 +108,7 @@ def test_conv3x3(gpu_device, dtype, mode, cin, cout):
     ops.gemm(xd, wd, out, M=B * Ho * Wo, N=cout, K=9 * cin, bias=b.to(gpu_device), residual=resd,
              conv=dict(Hin=H, Win=W, Cin=cin, Hout=Ho, Wout=Wo, stride=2 if mode == 's2' else 1, up=1 if mode == 'up' else 0))
     got = out.cpu().reshape(B, Ho, Wo, cout).permute(0, 3, 1, 2)
-    assert (got - ref).abs().max() < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert close(got, ref, dtype)
 
 
 @pytest.mark.parametrize('out_dtype', [torch.float32, torch.bfloat16])
@@ -118,7 +122,7 @@ def test_ln_modulate(gpu_device, out_dtype, C):
     sc = ada[:, 2 * C:3 * C].repeat_interleave(l, 0)
     sh = ada[:, 4 * C:5 * C].repeat_interleave(l, 0)
     ref = F.layer_norm(x, (C,), eps=1e-6) * (1 + sc) + sh
-    assert (out.float().cpu() - ref).abs().max() < (2e-5 if out_dtype == torch.float32 else 3e-2)
+    assert close(out, ref, out_dtype, 2e-5)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
@@ -146,7 +150,7 @@ def test_attention(gpu_device, dtype, masked):
         lvl = torch.cat([torch.full((e - b,), i) for i, (b, e) in enumerate(zip([0] + lvl_end[:-1], lvl_end))])
         s = s + torch.where(lvl.view(-1, 1) >= lvl.view(1, -1), 0., -torch.inf)
     ref = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(R * l, H * c)
-    assert (out.float().cpu() - ref).abs().max() < (2e-5 if dtype == torch.float32 else 2e-2)
+    assert close(out, ref, dtype, 2e-5, 2e-2)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
@@ -162,7 +166,7 @@ def test_cos_qk_norm(gpu_device, dtype):
     ref = b5.clone()
     ref[:, q_off:q_off + l, 0] = F.normalize(b5[:, q_off:q_off + l, 0], dim=-1) * sm.clamp_max(math.log(100)).exp().view(1, 1, H, 1)
     ref[:, q_off:q_off + l, 1] = F.normalize(b5[:, q_off:q_off + l, 1], dim=-1)
-    assert (after - ref).abs().max() < (1e-5 if dtype == torch.float32 else 0.2)
+    assert close(after, ref, dtype, 1e-5, 1e-2)
     assert torch.equal(after[:, :q_off], b5[:, :q_off]) and torch.equal(after[:, :, 2], b5[:, :, 2])
 
 
@@ -248,7 +252,7 @@ def test_groupnorm_silu(gpu_device, dtype, C, HW):
     ws = torch.empty(ops.groupnorm_ws_bytes(B, HW, C), device=gpu_device, dtype=torch.uint8)
     ops.groupnorm_silu(xd, w.to(gpu_device), b.to(gpu_device), out, B, HW, C, 32, 1e-6, True, ws)
     ref = F.silu(F.group_norm(xd.float().cpu().permute(0, 2, 1), 32, w, b, eps=1e-6)).permute(0, 2, 1)
-    assert (out.float().cpu() - ref).abs().max() < (2e-5 if dtype == torch.float32 else 3e-2)
+    assert close(out, ref, dtype, 2e-5, 2e-2)
 
 
 def test_softmax_transpose_layout(gpu_device):
