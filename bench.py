@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s of 256^2 ControlVAR d24 `autoregressive_infer_cfg` (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one full generation pass over a synthetic batch of B class/condition labels per GPU:
+10 coarse-to-fine scales x depth blocks with the multi-scale KV arena, 2-way CFG, top-k/top-p
+sampling over the 4096-way codebook, token->feature pyramid, and BOTH VQVAE decodes (control + image).
+Inputs (labels, condition types, synthetic weights) are resident in HBM before the timed region.
+Inference shards by sample: no data-path collective ("scaling": "weak").
+
+The JSON line also carries
+  roofline     - the dominant kernel (the MFMA GEMM / implicit-conv kernel): algorithmic FLOPs of its launches
+                 divided by their HIP-event-timed duration inside the timed region, against the 2.5 PFLOP/s bf16 peak;
+  cpu_baseline - the CPU oracle (this repo's restatement of the reference, validated against it) timed on the
+                 host cores of rank 0 on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--depth', type=int, default=24)
+    ap.add_argument('--batch', type=int, default=64, help='samples per GPU per step')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--cfg', type=float, default=4.0)
+    ap.add_argument('--top_k', type=int, default=900)      # the reference's sampling defaults (train_control_var_hpu.py:338)
+    ap.add_argument('--top_p', type=float, default=0.96)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-depth', type=int, default=0, help='depth of the CPU baseline model (0 = same as --depth)')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline(depth: int, seed: int = 0):
+    """The oracle (kind 'port': own restatement, pinned to the reference by tests/golden) on the host cores:
+    ONE full d{depth} generation with B=1 (2 CFG rows) incl. both VAE decodes, fp32, greedy."""
+    from controlvar_amd.spec import DEFAULT_PATCH_NUMS as PN, VaeConfig, VarConfig, phi_index_map
+    from controlvar_amd.synth import synth_vae_state, synth_var_state
+    from oracle import var_ref
+    from oracle.vqvae_ref import MSQuant
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = VarConfig(depth=depth)
+    sdv = synth_vae_state(VaeConfig(ch=160), seed)
+    sd = synth_var_state(cfg, seed)
+    msq = MSQuant(sdv, PN, phi_index_map(10))
+    t0 = time.time()
+    with torch.no_grad():
+        f = var_ref.generate(sd, cfg, msq, 1, torch.tensor([7]), 4.0, top_k=1, cond_type=torch.tensor([1]))
+        var_ref.decode_fhat(sdv, f)
+    dt = time.time() - t0
+    return dict(value=1.0 / dt, unit='images/s', cores=cores, kind='port',
+                sample=f'1 full d{depth} generation, B=1 (2 CFG rows), fp32 torch-CPU oracle, greedy, {dt:.1f}s')
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
+    if a.gpus != world and world > 1 and rank == 0:
+        print(f'[bench] --gpus {a.gpus} != WORLD_SIZE {world}; using WORLD_SIZE', file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+
+    from controlvar_amd import models, ops, _lib
+    from controlvar_amd.spec import VarConfig, algorithmic_gflop_per_row, VAE_DECODE_GFLOP
+    _lib.load()
+    T = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
+    t_build = time.time()
+    vae = models.build_vae(ch=160, compute_dtype=T).to(dev)
+    var = models.build_control_var(vae, depth=a.depth, mask_type='interleave_append', multi_cond=True, compute_dtype=T).to(dev).eval()
+    B = a.batch
+    g = torch.Generator().manual_seed(1234 + rank)
+    labels = torch.randint(0, 1000, (B,), generator=g).to(dev)
+    types = (torch.arange(B) % 4).to(dev)
+    var._pack(); vae._pack()
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(f'[bench] built d{a.depth} + VQVAE ch160 ({a.dtype}) in {time.time() - t_build:.1f}s; B={B}/GPU, world={world}', file=sys.stderr)
+
+    def step(seed):
+        return var.autoregressive_infer_cfg(B, labels, g_seed=seed, cfg=a.cfg, top_k=a.top_k, top_p=a.top_p, cond_type=types)
+
+    for w in range(a.warmup):
+        step(w)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    prof = None if a.no_kernel_timing else []
+    ops.GEMM_PROFILE = prof
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(a.steps):
+        img = step(100 + s)
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    ops.GEMM_PROFILE = None
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert img.shape == (B, 3, 512, 256)
+
+    if rank == 0:
+        cfg = VarConfig(depth=a.depth)
+        fl = algorithmic_gflop_per_row(cfg, n_ada=1)
+        per_sample_tf = (2 * fl['total'] + 2 * VAE_DECODE_GFLOP) / 1e3
+        value = world * B * a.steps / dt
+        out = {
+            'metric': 'images/sec (256^2 autoregressive_infer_cfg, d%d)' % a.depth, 'value': round(value, 3), 'unit': 'images/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 2),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            'config': {'workload': f'ControlVAR d{a.depth} autoregressive_infer_cfg 256^2 (control+image), CFG={a.cfg}, '
+                                   f'top_k={a.top_k}, top_p={a.top_p}, incl. 2 VQVAE decodes; synthetic weights/labels',
+                       'batch_per_gpu': B, 'global_batch': B * world, 'seq_len': cfg.pyramid.L, 'parallelism': f'dp{world} (sample-sharded, no collective)'},
+            'algorithmic_tflop_per_image': round(per_sample_tf, 3),
+            'end_to_end_tflops_per_gpu': round(per_sample_tf * B * a.steps / dt, 1),
+        }
+        if prof:
+            ms = sum(s.elapsed_time(e) for s, e, _ in prof)
+            flops = sum(f for _, _, f in prof)
+            ach = flops / (ms * 1e-3) / 1e12
+            peak = 2500.0 if a.dtype == 'bf16' else 157.3
+            traffic = None
+            tpath = os.path.join(ROOT, 'profiles', 'gemm_hbm_traffic.json')
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get('bytes_per_launch')
+                except Exception:
+                    traffic = None
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'cvar_gemm_kernel (all GEMM + implicit-conv launches)',
+                               'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                               'traffic': traffic, 'launches': len(prof), 'avg_launch_ms': round(ms / len(prof), 4),
+                               'gemm_share_of_step': round(ms * 1e-3 / dt, 3)}
+        if not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(a.cpu_depth or a.depth)
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -109,17 +109,188 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p) {
     }
 }
 
-extern "C" int cvar_attention(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
-                              const int* lvl_end_host, int n_lvl, void* out, void* stream) {
+__global__ void attn_mfma_bf16_kernel(const AttnParams p);
+
+// impl: 0 = auto (MFMA flash kernel for bf16, row-wise exact kernel for fp32), 1 = row-wise
+static int cvar_attention_impl(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
+                               const int* lvl_end_host, int n_lvl, void* out, void* stream, int impl) {
     if (!qkv || !out || R <= 0 || H <= 0 || l <= 0 || q_off < 0 || q_off + l > Lmax) return CVAR_EINVAL;
     if (n_lvl < 0 || n_lvl > 16 || (n_lvl > 0 && !lvl_end_host)) return CVAR_EINVAL;
     AttnParams p;
     p.qkv = qkv; p.out = out; p.R = R; p.H = H; p.Lmax = Lmax; p.q_off = q_off; p.l = l; p.scale = scale; p.n_lvl = n_lvl;
     for (int i = 0; i < 16; ++i) p.lvl_end[i] = i < n_lvl ? lvl_end_host[i] : 0;
+    if (dtype == CVAR_BF16 && impl == 0) {
+        hipLaunchKernelGGL(attn_mfma_bf16_kernel, dim3(cdiv(l, 128), H, R), dim3(256), 0, as_stream(stream), p);
+        CVAR_CHECK_LAUNCH();
+        return CVAR_OK;
+    }
     dim3 grid(cdiv(l, 256), H, R), block(256);
     if (dtype == CVAR_BF16) hipLaunchKernelGGL(attn_rowwise_kernel<bf16_t>, grid, block, 0, as_stream(stream), p);
     else if (dtype == CVAR_F32) hipLaunchKernelGGL(attn_rowwise_kernel<float>, grid, block, 0, as_stream(stream), p);
     else return CVAR_EUNSUPPORTED;
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;
+}
+
+// ================================================================================================
+// attn_mfma_bf16_kernel: flash-style attention on the matrix cores (bf16 in, fp32 accumulate), head_dim 64.
+//
+// Per workgroup: 4 waves x 32 queries; KV tiles of 64 keys.  Per wave and tile (16 MFMA 32x32x16):
+//   S^T = K . Q^T   (swapped product: each lane then holds 32 scores of ONE query -> the row max / row sum are
+//                    31 in-lane ops + one cross-half shuffle, no LDS)
+//   P   = exp(S*scale - m)  in fp32, packed to bf16 straight into the B-operand layout of the next product
+//   O^T += V^T . P^T        (V is transposed on its way into LDS: two keys packed per ds_write_b32,
+//                            rows of 68 elements -> conflict-free b64 fragment reads)
+// K tile: row-major 128-B rows with the 16-B chunk index XOR-swizzled by (key>>1)&7 (conflict-free ds_read_b128).
+// Global -> register prefetch of tile i+1 is issued before the MFMA work on tile i and written to LDS after it.
+// ================================================================================================
+constexpr int FA_VT_STRIDE = 68;      // elements per V^T row (64 keys + pad): 136 B, 8-B aligned, 2-way-free writes
+
+__global__ __launch_bounds__(256) void attn_mfma_bf16_kernel(const AttnParams p) {
+    constexpr int D = 64, KT = 64;
+    __shared__ __attribute__((aligned(16))) char Ks[KT * 128];
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[D * FA_VT_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lrow = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
+    const int h = blockIdx.y;
+    const long r = blockIdx.z;
+    const int C3 = 3 * p.H * D;
+    const bf16_t* base = (const bf16_t*)p.qkv + r * (long)p.Lmax * C3;
+    const bf16_t* kbase = base + p.H * D + h * D;
+    const bf16_t* vbase = kbase + p.H * D;
+
+    const int q0 = blockIdx.x * 128 + w * 32;
+    const int qi = q0 + lrow;
+    const int qrow = min(qi, p.l - 1);
+    const int kvlen = kv_len_of(p, p.q_off + qrow);
+    const int wave_min_kv = kv_len_of(p, p.q_off + min(q0, p.l - 1));
+    const int kv_end = kv_len_of(p, p.q_off + min(p.l, (int)(blockIdx.x + 1) * 128) - 1);
+
+    bf16x8_t qf[4];
+    {
+        const bf16_t* qp = base + (long)(p.q_off + qrow) * C3 + h * D;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qp + (2 * ks + hi) * 8);
+    }
+    // staging maps
+    const int k_key = tid >> 3, k_chunk = tid & 7;                       // K: keys k_key and k_key+32, chunk k_chunk
+    const int v_kp = 16 * (w >> 1) + (lane & 15), v_chunk = 4 * (w & 1) + (lane >> 4);   // V: keys 2*v_kp, 2*v_kp+1
+    bf16x8_t kreg[2], vreg[2];
+    auto load_tile = [&](int kt0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = kt0 + k_key + 32 * i;
+            bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+            kreg[i] = key < kv_end ? *(const bf16x8_t*)(kbase + (long)key * C3 + k_chunk * 8) : z;
+            const int vkey = kt0 + 2 * v_kp + i;
+            vreg[i] = vkey < kv_end ? *(const bf16x8_t*)(vbase + (long)vkey * C3 + v_chunk * 8) : z;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = k_key + 32 * i;
+            *(bf16x8_t*)(Ks + key * 128 + ((k_chunk ^ ((key >> 1) & 7)) << 4)) = kreg[i];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned packed = (unsigned)(unsigned short)vreg[0][e] | ((unsigned)(unsigned short)vreg[1][e] << 16);
+            *(unsigned*)(Vt + (v_chunk * 8 + e) * FA_VT_STRIDE + 2 * v_kp) = packed;
+        }
+    };
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+    float m = -INFINITY, lsum = 0.f;
+
+    load_tile(0);
+    for (int kt0 = 0; kt0 < kv_end; kt0 += KT) {
+        store_tile();
+        __syncthreads();
+        if (kt0 + KT < kv_end) load_tile(kt0 + KT);
+        // ---- S^T = K Q^T
+        f32x16_t s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8_t kf = *(const bf16x8_t*)(Ks + (32 * kb + lrow) * 128 + (((2 * ks + hi) ^ sw) << 4));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+            }
+        }
+        const bool need_mask = kt0 + KT > wave_min_kv;
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = s[kb][i] * p.scale;
+                if (need_mask) {
+                    const int key = kt0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hi;
+                    if (key >= kvlen) v = -INFINITY;
+                }
+                s[kb][i] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m, tmax);                 // finite from the first tile on (key 0 is always visible)
+        const float alpha = __expf(m - m_new);
+        m = m_new;
+        lsum *= alpha;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+        bf16x8_t pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pr = __expf(s[kb][i] - m_new);
+                lsum += pr;
+                pf[kb][i >> 3][i & 7] = (short)f32_to_bf16(pr);
+            }
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const bf16_t* vp = Vt + (32 * db + lrow) * FA_VT_STRIDE + 32 * kb + 16 * t + 4 * hi;
+                    const bf16x4_t v0 = *(const bf16x4_t*)vp;
+                    const bf16x4_t v1 = *(const bf16x4_t*)(vp + 8);
+                    const bf16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][t], o[db], 0, 0, 0);
+                }
+        __syncthreads();
+    }
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (qi < p.l) {
+        const float inv = 1.0f / lsum;
+        bf16_t* op = (bf16_t*)p.out + (r * p.l + qi) * (long)(p.H * D) + h * D;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4_t pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = (short)f32_to_bf16(o[db][4 * g + e] * inv);
+                *(bf16x4_t*)(op + 32 * db + 8 * g + 4 * hi) = pk;
+            }
+    }
+}
+
+extern "C" int cvar_attention_rowwise(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
+                                      const int* lvl_end_host, int n_lvl, void* out, void* stream) {
+    return cvar_attention_impl(qkv, dtype, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, out, stream, 1);
+}
+extern "C" int cvar_attention(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
+                              const int* lvl_end_host, int n_lvl, void* out, void* stream) {
+    return cvar_attention_impl(qkv, dtype, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, out, stream, 0);
 }

@@ -15,6 +15,9 @@ from ._lib import ACT_GELU_TANH, ACT_NONE, CVAR_BF16, CVAR_F32, GemmDesc, check
 
 _DT = {torch.float32: CVAR_F32, torch.bfloat16: CVAR_BF16}
 
+# bench.py sets this to a list to collect (start_event, end_event, algorithmic_flops) per GEMM launch
+GEMM_PROFILE = None
+
 
 def dt(t_or_dtype) -> int:
     d = t_or_dtype.dtype if isinstance(t_or_dtype, torch.Tensor) else t_or_dtype
@@ -67,7 +70,14 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
     d.out_dtype, d.ldc = dt(out), ldc or N
     if remap is not None:
         d.remap_l, d.remap_L, d.remap_off = remap
-    check(_lib.load().cvar_gemm(C.byref(d), _stream()), 'cvar_gemm')
+    if GEMM_PROFILE is None:
+        check(_lib.load().cvar_gemm(C.byref(d), _stream()), 'cvar_gemm')
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().cvar_gemm(C.byref(d), _stream()), 'cvar_gemm')
+        e1.record()
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K * batch))
     return out
 
 
@@ -85,10 +95,11 @@ def silu_cast(x: torch.Tensor, out: torch.Tensor):
 
 
 def attention(qkv: torch.Tensor, out: torch.Tensor, R: int, H: int, Lmax: int, q_off: int, l: int, scale: float,
-              lvl_end: Optional[Sequence[int]] = None, qkv_off: int = 0):
+              lvl_end: Optional[Sequence[int]] = None, qkv_off: int = 0, rowwise: bool = False):
     n = len(lvl_end) if lvl_end else 0
     arr = (C.c_int * max(n, 1))(*(lvl_end or [0]))
-    check(_lib.load().cvar_attention(_ptr(qkv) + qkv_off * qkv.element_size(), dt(qkv), R, H, Lmax, q_off, l, scale,
+    fn = _lib.load().cvar_attention_rowwise if rowwise else _lib.load().cvar_attention
+    check(fn(_ptr(qkv) + qkv_off * qkv.element_size(), dt(qkv), R, H, Lmax, q_off, l, scale,
                                      arr, n, _ptr(out), _stream()), 'cvar_attention')
     return out
 

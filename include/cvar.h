@@ -81,6 +81,10 @@ int cvar_silu_cast(const float* x, void* out, int out_dtype, int64_t n, void* st
  * attn_bias_for_masking of training (control_var.py:158-168).  out: [R*l][H*64] of `dtype`. */
 int cvar_attention(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
                    const int* lvl_end_host, int n_lvl, void* out, void* stream);
+/* same contract, always the exact row-per-lane fp32-math kernel (the parity-mode implementation; also the in-library
+ * reference the bf16 MFMA flash kernel is A/B-tested against). */
+int cvar_attention_rowwise(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
+                           const int* lvl_end_host, int n_lvl, void* out, void* stream);
 
 /* cos-attention pre-pass (basic_var.py:99-104), in place on rows [q_off, q_off+l) of the arena:
  * q = normalize(q) * exp(min(scale_mul[h], log 100)),  k = normalize(k). */

@@ -272,3 +272,32 @@ def test_softmax_transpose_layout(gpu_device):
     back = torch.empty(2, 3, 64, device=gpu_device)
     ops.nhwc_to_nchw(o, 8, back, 2, 3, 64, -0.5, 0.5, 0.5, 0.5)
     assert torch.allclose(back.cpu(), img.to(torch.bfloat16).float().clamp(-0.5, 0.5) * 0.5 + 0.5)
+
+
+@pytest.mark.parametrize('q_off,l,masked', [(0, 2, False), (10, 18, False), (310, 200, False), (848, 512, False), (0, 1360, True)])
+def test_attention_mfma_flash_bf16(gpu_device, q_off, l, masked):
+    """bf16 MFMA flash kernel vs (a) the exact row-wise kernel of the same library and (b) torch fp32 math."""
+    from controlvar_amd.spec import Pyramid
+    py = Pyramid()
+    R, H, c, Lmax = 2, 2, 64, 1360
+    C3 = 3 * H * c
+    qkv = rnd(R, Lmax, C3, seed=5, scale=1.5)
+    qd = to_dev(qkv, torch.bfloat16, gpu_device)
+    scale = 0.03125 * 4
+    lvl_end = list(py.end) if masked else None
+    out = torch.empty(R * l, H * c, device=gpu_device, dtype=torch.bfloat16)
+    out_rw = torch.empty_like(out)
+    ops.attention(qd, out, R, H, Lmax, q_off, l, scale, lvl_end)
+    ops.attention(qd, out_rw, R, H, Lmax, q_off, l, scale, lvl_end, rowwise=True)
+    qf = qd.float().cpu().view(R, Lmax, 3, H, c)
+    q = qf[:, q_off:q_off + l, 0].permute(0, 2, 1, 3)
+    k = qf[:, :q_off + l, 1].permute(0, 2, 1, 3)
+    v = qf[:, :q_off + l, 2].permute(0, 2, 1, 3)
+    s = q @ k.transpose(-1, -2) * scale
+    if masked:
+        lvl = torch.from_numpy(py.level_of_token())
+        s = s + torch.where(lvl.view(-1, 1) >= lvl.view(1, -1), 0., -torch.inf)
+    ref = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(R * l, H * c)
+    assert close(out_rw, ref, torch.bfloat16, bf16_rel=2e-2)
+    assert close(out, ref, torch.bfloat16, bf16_rel=2e-2)
+    assert (out.float() - out_rw.float()).abs().max() < 2e-2
