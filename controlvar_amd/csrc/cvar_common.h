@@ -58,10 +58,11 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ float gelu_tanh_f(float t) {
-    // 0.5 t (1 + tanh(sqrt(2/pi) (t + 0.044715 t^3)))   (nn.GELU(approximate='tanh'), basic_var.py:39)
-    const float k = 0.7978845608028654f;
-    float u = k * (t + 0.044715f * t * t * t);
-    return 0.5f * t * (1.0f + tanhf(u));
+    // 0.5 t (1 + tanh(u)), u = sqrt(2/pi) (t + 0.044715 t^3)   (nn.GELU(approximate='tanh'), basic_var.py:39)
+    // evaluated as t * sigmoid(2u) = t / (1 + exp(-2u)): one v_exp_f32 + one v_rcp_f32 instead of tanhf's long path
+    const float k2 = 2.0f * 0.7978845608028654f;
+    const float u2 = k2 * (t + 0.044715f * t * t * t);
+    return t / (1.0f + __expf(-u2));
 }
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }

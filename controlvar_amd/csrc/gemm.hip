@@ -207,31 +207,97 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
         __builtin_amdgcn_s_barrier();
     }
 
-    // ---- epilogue (C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+    // ---- epilogue: accumulators -> LDS (per-wave region, 32 rows at a time) -> row-major 8-wide vectors, so that
+    // bias / gate / residual loads and the C stores are 16-byte and coalesced (128-B rows per 8 lanes).
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    constexpr int EROW = SUB_N + 4;                       // fp32 row stride of the staging region (16-B aligned)
+    constexpr int LPR = SUB_N / 8;                        // lanes per output row
+    constexpr int RPP = 64 / LPR;                         // rows per pass
+    static_assert(NW * 32 * EROW * 4 <= 2 * STAGE, "epilogue staging must fit the pipeline LDS");
+    float* stg = (float*)smem + wave * (32 * EROW);
     char* Cb = (char*)p.C;
     const long cz = zb * p.strideC, rz = zb * p.strideR;
+    const int erow = lane / LPR, ecol = (lane % LPR) * 8;
+    const bool vec_ok = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && ((p.strideC & 7) == 0) && (((uintptr_t)p.C & 15) == 0) &&
+                        (!p.residual || (((p.ldr & 7) == 0) && ((p.strideR & 7) == 0) && (((uintptr_t)p.residual & 15) == 0))) &&
+                        (!p.gate || (((p.ldg & 3) == 0) && (((uintptr_t)p.gate & 15) == 0))) &&
+                        (!p.bias || (((uintptr_t)p.bias & 15) == 0));
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * SUB_M + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (m >= p.M) continue;
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stg[((r & 3) + 8 * (r >> 2) + 4 * hi) * EROW + j * 32 + lrow] = acc[i][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < 32 / RPP; ++ps) {
+            const int rr = ps * RPP + erow;
+            const int m = m0 + wm * SUB_M + i * 32 + rr;
+            const int n = n0 + wn * SUB_N + ecol;
+            if (m >= p.M || n >= p.N) continue;
+            float v[8];
+            {
+                const f32x4_t a0 = *(const f32x4_t*)(stg + rr * EROW + ecol);
+                const f32x4_t a1 = *(const f32x4_t*)(stg + rr * EROW + ecol + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = a0[e] * p.alpha; v[4 + e] = a1[e] * p.alpha; }
+            }
             long orow = m;
             if (p.remap_l > 0) {
-                const int s = m / p.remap_l;
-                orow = (long)s * p.remap_L + p.remap_off + (m - s * p.remap_l);
+                const int sq = m / p.remap_l;
+                orow = (long)sq * p.remap_L + p.remap_off + (m - sq * p.remap_l);
             }
             const float* grow = p.gate ? p.gate + (long)(m / p.gate_rows) * p.ldg : nullptr;
+            if (vec_ok) {
+                if (p.bias) {
+                    const f32x4_t b0 = *(const f32x4_t*)(p.bias + n), b1 = *(const f32x4_t*)(p.bias + n + 4);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = n0 + wn * SUB_N + j * 32 + lrow;
-                if (n >= p.N) continue;
-                float v = acc[i][j][r] * p.alpha;
-                if (p.bias) v += p.bias[n];
-                if (p.act == CVAR_ACT_GELU_TANH) v = gelu_tanh_f(v);
-                if (grow) v *= grow[n];
-                if (p.residual) v += ld_any(p.residual, p.res_dtype, rz + (long)m * p.ldr + n);
-                st_any(Cb, p.out_dtype, cz + orow * p.ldc + n, v);
+                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+                }
+                if (p.act == CVAR_ACT_GELU_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                }
+                if (grow) {
+                    const f32x4_t g0 = *(const f32x4_t*)(grow + n), g1 = *(const f32x4_t*)(grow + n + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] *= g0[e]; v[4 + e] *= g1[e]; }
+                }
+                if (p.residual) {
+                    if (p.res_dtype == CVAR_BF16) {
+                        const bf16x8_t rv = *(const bf16x8_t*)((const bf16_t*)p.residual + rz + (long)m * p.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rv[e]);
+                    } else {
+                        const float* rp = (const float*)p.residual + rz + (long)m * p.ldr + n;
+                        const f32x4_t r0 = *(const f32x4_t*)rp, r1 = *(const f32x4_t*)(rp + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                    }
+                }
+                if (p.out_dtype == CVAR_BF16) {
+                    bf16x8_t o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16(v[e]);
+                    *(bf16x8_t*)((bf16_t*)Cb + cz + orow * p.ldc + n) = o;
+                } else {
+                    float* cp = (float*)Cb + cz + orow * p.ldc + n;
+                    const f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                    *(f32x4_t*)cp = o0;
+                    *(f32x4_t*)(cp + 4) = o1;
+                }
+            } else {
+                for (int e = 0; e < 8; ++e) {
+                    if (n + e >= p.N) break;
+                    float x = v[e];
+                    if (p.bias) x += p.bias[n + e];
+                    if (p.act == CVAR_ACT_GELU_TANH) x = gelu_tanh_f(x);
+                    if (grow) x *= grow[n + e];
+                    if (p.residual) x += ld_any(p.residual, p.res_dtype, rz + (long)m * p.ldr + n + e);
+                    st_any(Cb, p.out_dtype, cz + orow * p.ldc + n + e, x);
+                }
             }
         }
     }

@@ -243,27 +243,30 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     }
 }
 
-// per (b, c): a = rstd_g * w_c, d = bias_c - mean_g * rstd_g * w_c
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, const float* __restrict__ weight,
-                                   const float* __restrict__ bias, float* __restrict__ coef, int HW, int C, int groups, float eps) {
-    const int b = blockIdx.x;
+// per (b, group): one wave reduces the chunk partials of the group's channels in double (fixed shuffle order ->
+// reproducible), then writes a = rstd_g * w_c, d = bias_c - mean_g * rstd_g * w_c for its channels.
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, const float* __restrict__ weight,
+                                                        const float* __restrict__ bias, float* __restrict__ coef, int HW, int C, int groups, float eps) {
+    const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
     const int cpg = C / groups;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int g = c / cpg;
-        double s = 0.0, q = 0.0;
-        for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc)
-            for (int k = 0; k < nchunk; ++k) {
-                s += (double)partial[(((long)b * nchunk + k) * C + cc) * 2];
-                q += (double)partial[(((long)b * nchunk + k) * C + cc) * 2 + 1];
-            }
-        const double n = (double)HW * cpg;
-        const double mean = s / n;
-        double var = q / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float a = rstd * weight[c];
-        coef[((long)b * C + c) * 2] = a;
-        coef[((long)b * C + c) * 2 + 1] = bias[c] - (float)mean * a;
+    double s = 0.0, q = 0.0;
+    const int items = cpg * nchunk;
+    for (int it = lane; it < items; it += 64) {
+        const int k = it / cpg, cc = g * cpg + it % cpg;
+        s += (double)partial[(((long)b * nchunk + k) * C + cc) * 2];
+        q += (double)partial[(((long)b * nchunk + k) * C + cc) * 2 + 1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    const double n = (double)HW * cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int cc = g * cpg + lane; cc < (g + 1) * cpg; cc += 64) {
+        const float a = rstd * weight[cc];
+        coef[((long)b * C + cc) * 2] = a;
+        coef[((long)b * C + cc) * 2 + 1] = bias[cc] - (float)mean * a;
     }
 }
 
@@ -322,7 +325,7 @@ static int groupnorm_typed(const T* x, const float* weight, const float* bias, T
     float* coef = partial + (size_t)B * nchunk * C * 2;
     const int PL = 256 / (C / VEC);
     hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(nchunk, B), dim3(256), (size_t)PL * C * 2 * sizeof(float), st, x, partial, HW, C, ppb);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, st, partial, nchunk, weight, bias, coef, HW, C, groups, eps);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, st, partial, nchunk, weight, bias, coef, HW, C, groups, eps);
     const long nvec = (long)B * HW * C / VEC;
     hipLaunchKernelGGL(gn_apply_kernel<T>, dim3((unsigned)min((long)4096, (nvec + 255) / 256)), dim3(256), 0, st, x, coef, out, nvec, HW, C, silu);
     CVAR_CHECK_LAUNCH();
