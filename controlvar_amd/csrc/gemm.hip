@@ -15,6 +15,7 @@
 //     optional nearest x2 upsample folded into the address);
 //   * blockIdx -> tile mapping is XCD-aware (contiguous tile ranges per XCD L2) and grouped along M.
 #include "cvar_common.h"
+#include <stdlib.h>
 
 __device__ __attribute__((aligned(16))) unsigned int cvar_zero_chunk[4] = {0u, 0u, 0u, 0u};
 
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     const char* a_ptr[A_PER_W];      // plain: row base + chunk offset (nullptr if row out of range)
     int a_k0[A_PER_W];               // element offset of this lane's chunk inside a K tile
     int a_b[A_PER_W], a_oy[A_PER_W], a_ox[A_PER_W];   // conv: decoded output pixel (a_b < 0: invalid)
+    int a_tap[A_PER_W], a_ci[A_PER_W];                // conv: (tap, channel) of this lane's chunk in the NEXT tile to issue
 #pragma unroll
     for (int jj = 0; jj < A_PER_W; ++jj) {
         const int j = wave + jj * NW;
@@ -87,8 +89,10 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
         const int chunk = slot ^ ((row >> 1) & 7);
         a_k0[jj] = chunk * KCH;
         const int m = m0 + row;
+        a_tap[jj] = 0; a_ci[jj] = 0;
         if (CONV) {
             a_ptr[jj] = nullptr;
+            a_tap[jj] = a_k0[jj] / p.Cin; a_ci[jj] = a_k0[jj] - a_tap[jj] * p.Cin;
             if (m < p.M) {
                 const int hw = p.Hout * p.Wout;
                 const int b = m / hw, rem = m - b * hw;
@@ -113,17 +117,19 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
         w_ptr[jj] = (n < p.N) ? Wbase + ((long)n * p.ldw + w_k0[jj]) * ES : nullptr;
     }
 
-    auto issue_tile = [&](int kt, int stage) {
+    // one 1-KiB DMA piece of tile kt: idx < A_PER_W -> A operand, else W operand
+    auto issue_one = [&](int kt, int stage, int idx) {
         char* sbase = smem + stage * STAGE;
-#pragma unroll
-        for (int jj = 0; jj < A_PER_W; ++jj) {
+        if (idx < A_PER_W) {
+            const int jj = idx;
             const int j = wave + jj * NW;
             const int k = kt * KT + a_k0[jj];
             const char* src = zero;
             if (CONV) {
-                if (a_b[jj] >= 0 && k < p.K) {
-                    const int tap = k / p.Cin, ci = k - tap * p.Cin;
-                    const int ky = tap / 3, kx = tap - ky * 3;
+                // pieces of one lane are issued in increasing kt, so (tap, ci) advance incrementally: no division in the loop
+                const int tap = a_tap[jj], ci = a_ci[jj];
+                if (a_b[jj] >= 0 && tap < 9) {
+                    const int ky = (tap * 11) >> 5, kx = tap - ky * 3;        // tap / 3, tap % 3 for tap < 9
                     int iy, ix;
                     bool ok;
                     if (p.stride == 1) {
@@ -136,13 +142,15 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                     }
                     if (ok) src = Abase + ((((long)a_b[jj] * p.Hin + iy) * p.Win + ix) * p.Cin + ci) * ES;
                 }
+                int nci = ci + KT, ntap = tap;
+                while (nci >= p.Cin) { nci -= p.Cin; ++ntap; }
+                a_ci[jj] = nci; a_tap[jj] = ntap;
             } else {
                 if (a_ptr[jj] != nullptr && k < p.K) src = a_ptr[jj] + (long)kt * 128;
             }
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + j * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int jj = 0; jj < B_PER_W; ++jj) {
+        } else {
+            const int jj = idx - A_PER_W;
             const int j = wave + jj * NW;
             const int k = kt * KT + w_k0[jj];
             const char* src = zero;
@@ -150,6 +158,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + BM * 128 + j * 1024), 16, 0, 0);
         }
     };
+    constexpr int NL = A_PER_W + B_PER_W;     // DMA pieces per wave per tile
 
     f32x16_t acc[MI][NJ];
 #pragma unroll
@@ -162,15 +171,14 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     const int lrow = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
     const int nk = (p.K + KT - 1) / KT;
 
-    issue_tile(0, 0);
+    // Pipeline: the DMA pieces of tile kt+1 are spread over the four k-steps of tile kt and issued right behind that
+    // k-step's fragment reads, so their issue cost overlaps the MFMAs already queued on the matrix pipe.
+#pragma unroll
+    for (int idx = 0; idx < NL; ++idx) issue_one(0, 0, idx);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            issue_tile(kt + 1, cur ^ 1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_PER_W + B_PER_W) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        const bool more = kt + 1 < nk;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         const char* As = smem + cur * STAGE + (wm * SUB_M + lrow) * 128;
         const char* Bs = smem + cur * STAGE + BM * 128 + (wn * SUB_N + lrow) * 128;
@@ -183,6 +191,10 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                 for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8_t*)(As + i * 32 * 128 + c);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) b[j] = *(const bf16x8_t*)(Bs + j * 32 * 128 + c);
+                if (more) {
+#pragma unroll
+                    for (int idx = ks * NL / 4; idx < (ks + 1) * NL / 4; ++idx) issue_one(kt + 1, cur ^ 1, idx);
+                }
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -194,6 +206,10 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                 for (int i = 0; i < MI; ++i) a[i] = *(const f32x4_t*)(As + i * 32 * 128 + c);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) b[j] = *(const f32x4_t*)(Bs + j * 32 * 128 + c);
+                if (more) {
+#pragma unroll
+                    for (int idx = ks * NL / 4; idx < (ks + 1) * NL / 4; ++idx) issue_one(kt + 1, cur ^ 1, idx);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -212,9 +228,10 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     constexpr int EROW = SUB_N + 4;                       // fp32 row stride of the staging region (16-B aligned)
     constexpr int LPR = SUB_N / 8;                        // lanes per output row
-    constexpr int RPP = 64 / LPR;                         // rows per pass
-    static_assert(NW * 32 * EROW * 4 <= 2 * STAGE, "epilogue staging must fit the pipeline LDS");
-    float* stg = (float*)smem + wave * (32 * EROW);
+    constexpr int RPP = 64 / LPR;                         // rows per pass (lanes >= RPP*LPR idle when LPR does not divide 64)
+    constexpr int NPASS = (16 + RPP - 1) / RPP;
+    static_assert(NW * 16 * EROW * 4 <= 2 * STAGE, "epilogue staging must fit the pipeline LDS");
+    float* stg = (float*)smem + wave * (16 * EROW);
     char* Cb = (char*)p.C;
     const long cz = zb * p.strideC, rz = zb * p.strideR;
     const int erow = lane / LPR, ecol = (lane % LPR) * 8;
@@ -222,21 +239,22 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                         (!p.residual || (((p.ldr & 7) == 0) && ((p.strideR & 7) == 0) && (((uintptr_t)p.residual & 15) == 0))) &&
                         (!p.gate || (((p.ldg & 3) == 0) && (((uintptr_t)p.gate & 15) == 0))) &&
                         (!p.bias || (((uintptr_t)p.bias & 15) == 0));
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
+#pragma clang loop unroll(full)
+    for (int ih = 0; ih < 2 * MI; ++ih) {
+        const int i = ih >> 1, half = ih & 1;             // rows 16*half .. 16*half+15 of block i <-> regs 8*half .. 8*half+7
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                stg[((r & 3) + 8 * (r >> 2) + 4 * hi) * EROW + j * 32 + lrow] = acc[i][j][r];
+            for (int r8 = 0; r8 < 8; ++r8)
+                stg[((r8 & 3) + 8 * (r8 >> 2) + 4 * hi) * EROW + j * 32 + lrow] = acc[i][j][8 * half + r8];
         __syncthreads();
 #pragma unroll
-        for (int ps = 0; ps < 32 / RPP; ++ps) {
+        for (int ps = 0; ps < NPASS; ++ps) {
             const int rr = ps * RPP + erow;
-            const int m = m0 + wm * SUB_M + i * 32 + rr;
+            const int m = m0 + wm * SUB_M + i * 32 + 16 * half + rr;
             const int n = n0 + wn * SUB_N + ecol;
-            if (m >= p.M || n >= p.N) continue;
+            if (erow >= RPP || rr >= 16 || m >= p.M || n >= p.N) continue;
             float v[8];
             {
                 const f32x4_t a0 = *(const f32x4_t*)(stg + rr * EROW + ecol);
@@ -323,10 +341,22 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     return CVAR_OK;
 }
 
+static int gemm_cfg_override() {
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("CVAR_GEMM_CFG"); v = e ? atoi(e) : -1; }
+    return v;
+}
+
 template <typename T>
 static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     // small-M problems (early scales, ada_lin) use a 64-row tile to put more blocks on the chip
     if (p.M <= 64) return launch_cfg<T, 64, 128, 1, 4>(p, batch, st);
+    // channel counts of the VQVAE (160, 320) are multiples of 160 but not of 128: a 160-wide tile wastes no MFMA work
+    if (p.N % 160 == 0 && p.N % 128 != 0 && p.M >= 4096) return launch_cfg<T, 128, 160, 4, 1>(p, batch, st);
+    // large streaming GEMMs: 256x256 tile, 8 waves (2x4) - halves the operand bytes per flop and doubles the MFMA work
+    // per barrier; measured +10..15 % over 128x128 on the d24 shapes.  CVAR_GEMM_CFG=0 forces the 128x128 tile (A/B runs).
+    const int ov = gemm_cfg_override();
+    if (ov != 0 && p.M >= 2048 && p.N % 256 == 0) return launch_cfg<T, 256, 256, 2, 4>(p, batch, st);
     return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
 }
 

@@ -62,7 +62,7 @@ class VQVAE(nn.Module):
 
     def __init__(self, vocab_size=4096, z_channels=32, ch=128, dropout=0.0, beta=0.25, using_znorm=False, quant_conv_ks=3,
                  quant_resi=0.5, share_quant_resi=4, default_qresi_counts=0, v_patch_nums=DEFAULT_PATCH_NUMS, test_mode=True,
-                 compute_dtype=torch.bfloat16, init_seed: int = 0, decode_chunk: int = 16):
+                 compute_dtype=torch.bfloat16, init_seed: int = 0, decode_chunk: int = 64):
         super().__init__()
         if using_znorm or quant_conv_ks != 3 or abs(quant_resi - 0.5) > 1e-9 or share_quant_resi != 4 or dropout != 0.0:
             raise NotImplementedError('only the shipped VQVAE configuration (vqvae.py:18-27 defaults, share_quant_resi=4) is built')
