@@ -46,37 +46,50 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(depth: int, seed: int = 0):
-    """The oracle (kind 'port': own restatement, pinned to the reference by tests/golden) on the host cores:
-    ONE full d{depth} generation with B=1 (2 CFG rows) incl. both VAE decodes, fp32, greedy."""
-    from controlvar_amd.spec import DEFAULT_PATCH_NUMS as PN, VaeConfig, VarConfig, phi_index_map
+def cpu_baseline(depth: int, seed: int = 0, budget_s: float = 20.0, max_threads: int = 32):
+    """The oracle (kind 'port': own restatement, pinned to the reference by tests/golden) on the host cores.
+    Sample: ONE d{depth} generation with B=1 (2 CFG rows), fp32, greedy - run scale by scale until `budget_s` seconds
+    are spent; the rate is extrapolated by the share of the sample's algorithmic FLOPs completed (both VAE decodes
+    are included only if every scale finished inside the budget)."""
+    from controlvar_amd.spec import DEFAULT_PATCH_NUMS as PN, VAE_DECODE_GFLOP, VaeConfig, VarConfig, phi_index_map
     from controlvar_amd.synth import synth_vae_state, synth_var_state
     from oracle import var_ref
     from oracle.vqvae_ref import MSQuant
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, max_threads)
     torch.set_num_threads(cores)
     cfg = VarConfig(depth=depth)
+    py, C, V = cfg.pyramid, cfg.C, cfg.vocab
+    per_scale = [2 * (depth * (24 * C * C * l + 4 * C * l * e) + 2 * C * V * l) / 1e9 for l, e in zip(py.l, py.end)]   # 2 CFG rows
+    total = sum(per_scale) + 2 * VAE_DECODE_GFLOP
     sdv = synth_vae_state(VaeConfig(ch=160), seed)
     sd = synth_var_state(cfg, seed)
     msq = MSQuant(sdv, PN, phi_index_map(10))
+    done = {'n': 0}
     t0 = time.time()
+
+    def hook(si):
+        done['n'] = si + 1
+        return (time.time() - t0) > budget_s
+
     with torch.no_grad():
-        f = var_ref.generate(sd, cfg, msq, 1, torch.tensor([7]), 4.0, top_k=1, cond_type=torch.tensor([1]))
-        var_ref.decode_fhat(sdv, f)
+        f = var_ref.generate(sd, cfg, msq, 1, torch.tensor([7]), 4.0, top_k=1, cond_type=torch.tensor([1]), stage_hook=hook)
+        gf = sum(per_scale[:done['n']])
+        if done['n'] == len(per_scale):
+            var_ref.decode_fhat(sdv, f)
+            gf += 2 * VAE_DECODE_GFLOP
     dt = time.time() - t0
-    return dict(value=1.0 / dt, unit='images/s', cores=cores, kind='port',
-                sample=f'1 full d{depth} generation, B=1 (2 CFG rows), fp32 torch-CPU oracle, greedy, {dt:.1f}s')
+    return dict(value=(gf / total) / dt, unit='images/s', cores=cores, kind='port',
+                sample=f'd{depth} B=1 (2 CFG rows) fp32 torch-CPU oracle, greedy: {done["n"]}/10 scales'
+                       f'{" + 2 VAE decodes" if done["n"] == 10 else ""} = {100 * gf / total:.1f}% of the per-image FLOPs in {dt:.1f}s '
+                       f'on {cores} threads (rate extrapolated by FLOP share)')
 
 
 def main():
     a = parse()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local))
+    from controlvar_amd.launcher import dist_env, init_dist, sharded_timed_run
+    rank, local, world = dist_env()
+    torch.cuda.set_device(local)
+    init_dist('nccl', torch.device('cuda', local))
     if a.gpus != world and world > 1 and rank == 0:
         print(f'[bench] --gpus {a.gpus} != WORLD_SIZE {world}; using WORLD_SIZE', file=sys.stderr)
     torch.cuda.set_device(local)
@@ -101,29 +114,17 @@ def main():
     def step(seed):
         return var.autoregressive_infer_cfg(B, labels, g_seed=seed, cfg=a.cfg, top_k=a.top_k, top_p=a.top_p, cond_type=types)
 
-    for w in range(a.warmup):
-        step(w)
-    torch.cuda.synchronize()
-
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-
     prof = None if a.no_kernel_timing else []
-    ops.GEMM_PROFILE = prof
-    barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(a.steps):
-        img = step(100 + s)
-    torch.cuda.synchronize(); barrier()
-    dt = time.perf_counter() - t0
+    last = {}
+
+    def timed_step(i):
+        if i == a.warmup:
+            ops.GEMM_PROFILE = prof                     # kernel events only inside the timed region
+        last['img'] = step(100 + i)
+
+    _, dt = sharded_timed_run(timed_step, a.steps, a.warmup, B, sync=torch.cuda.synchronize)
     ops.GEMM_PROFILE = None
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    img = last['img']
     assert img.shape == (B, 3, 512, 256)
 
     if rank == 0:

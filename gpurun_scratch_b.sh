@@ -1,5 +1,8 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_parity.py -m gpu -q --timeout=300 2>&1 | tail -3
-python bench.py --depth 24 --batch 64 --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline'])"
+( time python bench.py ) > gpurun_out/bench_default.log 2>&1
+tail -5 gpurun_out/bench_default.log
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r01 -o d24_b64 -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing > gpurun_out/prof_r01.log 2>&1
+ls -la gpurun_out/prof_r01/
+rm -f gpurun_out/prof_r01/*kernel_trace.csv
