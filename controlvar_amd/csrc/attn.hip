@@ -205,6 +205,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bf16_kernel(const AttnParams p)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
     float m = -INFINITY, lsum = 0.f;
+    const float c2 = p.scale * 1.4426950408889634f;
 
     load_tile(0);
     for (int kt0 = 0; kt0 < kv_end; kt0 += KT) {
@@ -223,37 +224,42 @@ __global__ __launch_bounds__(256) void attn_mfma_bf16_kernel(const AttnParams p)
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
             }
         }
+        // softmax bookkeeping in the exp2 domain: p = 2^(s*c - m), c = scale*log2(e)  (one fma + one v_exp_f32 per score)
         const bool need_mask = kt0 + KT > wave_min_kv;
         float tmax = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                float v = s[kb][i] * p.scale;
                 if (need_mask) {
                     const int key = kt0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hi;
-                    if (key >= kvlen) v = -INFINITY;
+                    if (key >= kvlen) s[kb][i] = -INFINITY;
                 }
-                s[kb][i] = v;
-                tmax = fmaxf(tmax, v);
+                tmax = fmaxf(tmax, s[kb][i]);
             }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float m_new = fmaxf(m, tmax);                 // finite from the first tile on (key 0 is always visible)
-        const float alpha = __expf(m - m_new);
-        m = m_new;
-        lsum *= alpha;
+        const float m_new = fmaxf(m, tmax * c2);            // c2 > 0; finite from the first tile on (key 0 is always visible)
+        if (!__all(m_new == m)) {                           // rescale only when some row's running max moved (exact skip)
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+            lsum *= alpha;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+                for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+            m = m_new;
+        }
         bf16x8_t pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float pr = __expf(s[kb][i] - m_new);
-                lsum += pr;
-                pf[kb][i >> 3][i & 7] = (short)f32_to_bf16(pr);
+            for (int t = 0; t < 2; ++t) {
+                float pr[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    pr[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][8 * t + j], c2, -m));
+                    lsum += pr[j];
+                }
+                pf[kb][t] = pack_bf16x8(pr);
             }
         // ---- O^T += V^T P^T
 #pragma unroll
@@ -278,10 +284,10 @@ __global__ __launch_bounds__(256) void attn_mfma_bf16_kernel(const AttnParams p)
         for (int db = 0; db < 2; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                bf16x4_t pk;
+                float ov[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = (short)f32_to_bf16(o[db][4 * g + e] * inv);
-                *(bf16x4_t*)(op + 32 * db + 8 * g + 4 * hi) = pk;
+                for (int e = 0; e < 4; ++e) ov[e] = o[db][4 * g + e] * inv;
+                *(bf16x4_t*)(op + 32 * db + 8 * g + 4 * hi) = pack_bf16x4(ov);
             }
     }
 }

@@ -18,12 +18,27 @@ typedef unsigned short bf16_t;                                  // raw bf16 bits
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
 
-// round-to-nearest-even, NaN preserved (same rounding as torch's .to(bfloat16))
+// f32 -> bf16, round-to-nearest-even (same rounding as torch's .to(bfloat16)): gfx950 has v_cvt_pk_bf16_f32
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2n_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    const __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    const bf16x2n_t r = __builtin_convertvector(v, bf16x2n_t);
+    return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ bf16x8_t pack_bf16x8(const float* v) {
+    const u32x4_t u = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+    return __builtin_bit_cast(bf16x8_t, u);
+}
+__device__ __forceinline__ bf16x4_t pack_bf16x4(const float* v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+    const u32x2_t u = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+    return __builtin_bit_cast(bf16x4_t, u);
 }
 
 template <typename T> struct Elem;

@@ -296,10 +296,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                     }
                 }
                 if (p.out_dtype == CVAR_BF16) {
-                    bf16x8_t o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (short)f32_to_bf16(v[e]);
-                    *(bf16x8_t*)((bf16_t*)Cb + cz + orow * p.ldc + n) = o;
+                    *(bf16x8_t*)((bf16_t*)Cb + cz + orow * p.ldc + n) = pack_bf16x8(v);
                 } else {
                     float* cp = (float*)Cb + cz + orow * p.ldc + n;
                     const f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};

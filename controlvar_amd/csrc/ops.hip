@@ -4,73 +4,94 @@
 // ------------------------------------------------------------------------------------------------
 // adaLN: out = LN(x) * (1 + scale) + shift.   One wave per row, values kept in registers.
 // ------------------------------------------------------------------------------------------------
-template <typename TO>
+// NV = float4 vectors per lane (C <= NV*256); TAIL = the last vector is only partly populated (C % 256 != 0).
+// All loads of a row are issued back to back (no per-vector branches), so a wave has NV 16-byte loads in flight.
+template <typename TO, int NV, bool TAIL>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                          const float* __restrict__ shift, long ld_ada, int rows_per,
                                                          TO* __restrict__ out, int M, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    constexpr int MAXV = 8;                        // C <= 2048
     const float* xr = x + (long)row * C;
-    f32x4_t v[MAXV];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < C) {
-            v[i] = *(const f32x4_t*)(xr + c);
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        }
-    }
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < C) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[i][e] -= mean; q += v[i][e] * v[i][e]; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
     const long g = row / rows_per;
     const float* sc = scale + g * ld_ada;
     const float* sh = shift + g * ld_ada;
+    f32x4_t v[NV], a[NV], b[NV];
+    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        const bool ok = !(TAIL && i == NV - 1) || c < C;
+        v[i] = ok ? *(const f32x4_t*)(xr + c) : zero4;
+        a[i] = ok ? *(const f32x4_t*)(sc + c) : zero4;
+        b[i] = ok ? *(const f32x4_t*)(sh + c) : zero4;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        const bool ok = !(TAIL && i == NV - 1) || c < C;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][e] = ok ? v[i][e] - mean : 0.f; q += v[i][e] * v[i][e]; }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
     TO* orow = out + (long)row * C;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
-        if (c < C) {
-            const f32x4_t a = *(const f32x4_t*)(sc + c), b = *(const f32x4_t*)(sh + c);
-            float y[4];
+        if (TAIL && i == NV - 1 && c >= C) continue;
+        float y[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] * rstd) * (1.0f + a[e]) + b[e];
-            if constexpr (sizeof(TO) == 4) {
-                f32x4_t o = {y[0], y[1], y[2], y[3]};
-                *(f32x4_t*)(orow + c) = o;
-            } else {
-                bf16x4_t o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (short)f32_to_bf16(y[e]);
-                *(bf16x4_t*)(orow + c) = o;
-            }
+        for (int e = 0; e < 4; ++e) y[e] = (v[i][e] * rstd) * (1.0f + a[i][e]) + b[i][e];
+        if constexpr (sizeof(TO) == 4) {
+            f32x4_t o = {y[0], y[1], y[2], y[3]};
+            *(f32x4_t*)(orow + c) = o;
+        } else {
+            *(bf16x4_t*)(orow + c) = pack_bf16x4(y);
         }
     }
+}
+
+template <typename TO, int NV>
+static void ln_launch(bool tail, dim3 grid, hipStream_t st, const float* x, const float* scale, const float* shift, long ld_ada,
+                      int rows_per, TO* out, int M, int C, float eps) {
+    if (tail) hipLaunchKernelGGL((ln_modulate_kernel<TO, NV, true>), grid, dim3(256), 0, st, x, scale, shift, ld_ada, rows_per, out, M, C, eps);
+    else hipLaunchKernelGGL((ln_modulate_kernel<TO, NV, false>), grid, dim3(256), 0, st, x, scale, shift, ld_ada, rows_per, out, M, C, eps);
+}
+
+template <typename TO>
+static int ln_dispatch(const float* x, const float* scale, const float* shift, long ld_ada, int rows_per, TO* out, int M, int C,
+                       float eps, hipStream_t st) {
+    const int nv = (C + 255) / 256;
+    const bool tail = (C % 256) != 0;
+    dim3 grid(cdiv(M, 4));
+    switch (nv) {
+        case 1: ln_launch<TO, 1>(tail, grid, st, x, scale, shift, ld_ada, rows_per, out, M, C, eps); break;
+        case 2: ln_launch<TO, 2>(tail, grid, st, x, scale, shift, ld_ada, rows_per, out, M, C, eps); break;
+        case 3: ln_launch<TO, 3>(tail, grid, st, x, scale, shift, ld_ada, rows_per, out, M, C, eps); break;
+        case 4: ln_launch<TO, 4>(tail, grid, st, x, scale, shift, ld_ada, rows_per, out, M, C, eps); break;
+        case 5: ln_launch<TO, 5>(tail, grid, st, x, scale, shift, ld_ada, rows_per, out, M, C, eps); break;
+        case 6: ln_launch<TO, 6>(tail, grid, st, x, scale, shift, ld_ada, rows_per, out, M, C, eps); break;
+        case 7: ln_launch<TO, 7>(tail, grid, st, x, scale, shift, ld_ada, rows_per, out, M, C, eps); break;
+        case 8: ln_launch<TO, 8>(tail, grid, st, x, scale, shift, ld_ada, rows_per, out, M, C, eps); break;
+        default: return CVAR_EUNSUPPORTED;
+    }
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
 }
 
 extern "C" int cvar_ln_modulate(const float* x, const float* scale, const float* shift, int64_t ld_ada, int rows_per,
                                 void* out, int out_dtype, int M, int C, float eps, void* stream) {
     if (!x || !scale || !shift || !out || M <= 0 || rows_per <= 0) return CVAR_EINVAL;
     if (C % 4 || C > 2048 || ld_ada % 4) return CVAR_EUNSUPPORTED;
-    dim3 grid(cdiv(M, 4)), block(256);
-    if (out_dtype == CVAR_BF16)
-        hipLaunchKernelGGL(ln_modulate_kernel<bf16_t>, grid, block, 0, as_stream(stream), x, scale, shift, (long)ld_ada, rows_per, (bf16_t*)out, M, C, eps);
-    else if (out_dtype == CVAR_F32)
-        hipLaunchKernelGGL(ln_modulate_kernel<float>, grid, block, 0, as_stream(stream), x, scale, shift, (long)ld_ada, rows_per, (float*)out, M, C, eps);
-    else return CVAR_EUNSUPPORTED;
-    CVAR_CHECK_LAUNCH();
-    return CVAR_OK;
+    if (out_dtype == CVAR_BF16) return ln_dispatch<bf16_t>(x, scale, shift, (long)ld_ada, rows_per, (bf16_t*)out, M, C, eps, as_stream(stream));
+    if (out_dtype == CVAR_F32) return ln_dispatch<float>(x, scale, shift, (long)ld_ada, rows_per, (float*)out, M, C, eps, as_stream(stream));
+    return CVAR_EUNSUPPORTED;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -296,10 +317,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
             for (int e = 0; e < VEC; ++e) y[e] = y[e] / (1.0f + __expf(-y[e]));
         }
         if constexpr (sizeof(T) == 2) {
-            bf16x8_t o;
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) o[e] = (short)f32_to_bf16(y[e]);
-            *(bf16x8_t*)(out + i * VEC) = o;
+            *(bf16x8_t*)(out + i * VEC) = pack_bf16x8(y);
         } else {
             f32x4_t o = {y[0], y[1], y[2], y[3]};
             *(f32x4_t*)(out + i * VEC) = o;
