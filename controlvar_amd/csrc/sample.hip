@@ -2,8 +2,8 @@
 //   combine: ((c0*l0 + c1*l1) + c2*l2) + c3*l3 with separately rounded products - the evaluation order of
 //            control_var.py:295-298 / 501-502, so the combined logits are bit-identical to the reference's.
 //   greedy : argmax, lowest index on ties, plus the top1-top2 margin (used for margin-aware parity checks).
-//   sample : bitonic sort (value desc, index asc) in LDS, top-k threshold (ties kept, helpers.py:9-10), nucleus cut
-//            on the ascending cumulative mass (helpers.py:12-15), inverse-CDF draw from a counter-based generator.
+//   sample : radix-select thresholds for top-k (ties kept, helpers.py:9-10) and the nucleus cut on the ascending
+//            cumulative mass (helpers.py:12-15), inverse-CDF draw from a counter-based generator (no sort).
 #include "cvar_common.h"
 
 struct SampleParams {
@@ -79,118 +79,177 @@ __global__ __launch_bounds__(256) void cfg_greedy_kernel(const SampleParams p) {
     }
 }
 
-__device__ __forceinline__ float block_sum(float v, float* scratch) {
-    v = wave_sum(v);
+// ---- top-k / top-p sampling without a sort ---------------------------------------------------------------------
+// Both filters of helpers.py:8-15 are VALUE thresholds: top-k keeps v >= (k-th largest value) (ties kept), the nucleus
+// cut keeps the elements whose ascending cumulative probability exceeds 1-p, i.e. v >= tau_p.  Each threshold is found
+// by a 4-pass byte-wise radix select over order-preserving integer keys (count histogram for top-k, probability-mass
+// histogram for top-p).  Masses are quantised to 2^-40 and accumulated as 64-bit integers: exact, order independent,
+// bit-reproducible.  The draw is an inverse-CDF lookup over the kept elements in a fixed (thread-major) order.
+__device__ __forceinline__ unsigned f2key(float f) {           // monotone: a < b  <=>  key(a) < key(b)
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <typename TV>
+__device__ __forceinline__ TV wave_incl_scan(TV v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const TV n = __shfl_up(v, o, 64); if (lane >= o) v += n; }
+    return v;
+}
+// exclusive prefix of one value per thread over the 256-thread block (+ block total through `total`)
+template <typename TV>
+__device__ __forceinline__ TV block_excl_scan(TV v, TV* wsum /*[4]*/, TV& total) {
+    const TV inc = wave_incl_scan(v);
+    const int w = threadIdx.x >> 6;
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 63) wsum[w] = inc;
     __syncthreads();
-    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+    TV base = 0;
+    for (int i = 0; i < w; ++i) base += wsum[i];
+    total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    return base + inc - v;
 }
 
 __global__ __launch_bounds__(256) void cfg_sample_kernel(const SampleParams p) {
-    constexpr int N = 4096, EPT = 16;
-    __shared__ float sv[N];
-    __shared__ int si[N];
-    __shared__ float chunk_tot[256];
-    __shared__ float scratch[4];
+    constexpr int EPT = 16;
+    typedef unsigned long long u64;
+    __shared__ int hist_cnt[256];
+    __shared__ u64 hist_mass[256];
+    __shared__ u64 wsum64[4];
+    __shared__ int wsum32[4];
+    __shared__ float wmaxs[4], wmax2[4];
+    __shared__ unsigned sel_digit;
+    __shared__ u64 sel_below;
+    __shared__ int sel_k;
     const int tid = threadIdx.x;
     const long bt = blockIdx.x;
     const long b = bt / p.l, t = bt % p.l;
-    for (int e = tid; e < N; e += 256) {
-        float v = -INFINITY;
+    float v[EPT];
+    unsigned key[EPT];
+    float best = -INFINITY, second = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = i * 256 + tid;                   // thread-strided ownership: coalesced loads
+        float x = -INFINITY;
         if (e < p.V) {
-            v = combine_logits(p, b, t, e);
-            if (p.combined) p.combined[bt * p.V + e] = v;
+            x = combine_logits(p, b, t, e);
+            if (p.combined) p.combined[bt * p.V + e] = x;
         }
-        sv[e] = v; si[e] = e;
+        v[i] = x; key[i] = f2key(x);
+        if (x > best) { second = best; best = x; } else if (x > second) second = x;
     }
-    __syncthreads();
-    // bitonic sort: value descending, index ascending on ties
-    for (int k = 2; k <= N; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < N; i += 256) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const float a = sv[i], c = sv[ixj];
-                    const int ia = si[i], ic = si[ixj];
-                    const bool a_before = (a > c) || (a == c && ia < ic);
-                    const bool want = ((i & k) == 0);
-                    if (a_before != want) { sv[i] = c; sv[ixj] = a; si[i] = ic; si[ixj] = ia; }
-                }
+    // block max (+ second max for the margin output)
+    {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64), os = __shfl_xor(second, o, 64);
+            second = fmaxf(fminf(best, ob), fmaxf(second, os));
+            best = fmaxf(best, ob);
+        }
+        if ((tid & 63) == 0) { wmaxs[tid >> 6] = best; wmax2[tid >> 6] = second; }
+        __syncthreads();
+        best = wmaxs[0]; second = wmax2[0];
+        for (int w = 1; w < 4; ++w) { second = fmaxf(fminf(best, wmaxs[w]), fmaxf(second, wmax2[w])); best = fmaxf(best, wmaxs[w]); }
+        if (p.margin && tid == 0) p.margin[bt] = best - second;
+    }
+    const float vmax = best;
+
+    // ---- top-k threshold key
+    unsigned tk = 0;
+    if (p.top_k > 0 && p.top_k < p.V) {
+        unsigned prefix = 0;
+        int kk = p.top_k;
+        for (int ps = 3; ps >= 0; --ps) {
+            hist_cnt[tid] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const bool match = (ps == 3) || ((key[i] >> (8 * (ps + 1))) == prefix);
+                if (match && i * 256 + tid < p.V) atomicAdd(&hist_cnt[(key[i] >> (8 * ps)) & 255], 1);
             }
             __syncthreads();
+            const int dd = 255 - tid;                              // thread t owns digit 255-t: suffix counts become a prefix scan
+            const int c = hist_cnt[dd];
+            int tot;
+            const int above = block_excl_scan<int>(c, wsum32, tot);   // elements with a larger digit
+            if (above < kk && above + c >= kk) { sel_digit = (unsigned)dd; sel_k = kk - above; }
+            __syncthreads();
+            prefix = (prefix << 8) | sel_digit;
+            kk = sel_k;
+            __syncthreads();
         }
+        tk = prefix;
     }
-    if (p.margin && tid == 0) p.margin[bt] = sv[0] - sv[1];
-    // top-k: keep everything >= the k-th largest value (ties kept)
-    int nk = p.V;
-    if (p.top_k > 0 && p.top_k < p.V) {
-        const float thr = sv[p.top_k - 1];
-        float cnt = 0.f;
-        for (int i = tid; i < p.V; i += 256) cnt += (sv[i] >= thr) ? 1.f : 0.f;
-        nk = (int)(block_sum(cnt, scratch) + 0.5f);
-    }
-    // exp weights + inclusive prefix sums over the sorted order (thread owns EPT consecutive entries)
-    const float vmax = sv[0];
-    float ex[EPT], run = 0.f;
+    // ---- quantised masses of the top-k set
+    u64 wq[EPT];
+    u64 local = 0;
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int i = tid * EPT + e;
-        const float w = (i < nk) ? __expf(sv[i] - vmax) : 0.f;
-        run += w; ex[e] = run;
+    for (int i = 0; i < EPT; ++i) {
+        const bool in = (i * 256 + tid < p.V) && key[i] >= tk;
+        wq[i] = in ? (u64)(__expf(v[i] - vmax) * 1099511627776.0f) : 0ull;      // 2^40
+        local += wq[i];
     }
-    __syncthreads();
-    chunk_tot[tid] = run;
-    __syncthreads();
-    if (tid < 64) {          // scan 256 chunk totals with one wave (4 per lane)
-        float c0 = chunk_tot[tid * 4], c1 = chunk_tot[tid * 4 + 1], c2 = chunk_tot[tid * 4 + 2], c3 = chunk_tot[tid * 4 + 3];
-        const float tot = ((c0 + c1) + c2) + c3;
-        float inc = tot;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const float n = __shfl_up(inc, o, 64); if (tid >= o) inc += n; }
-        const float excl = inc - tot;
-        chunk_tot[tid * 4] = excl; chunk_tot[tid * 4 + 1] = excl + c0; chunk_tot[tid * 4 + 2] = excl + c0 + c1; chunk_tot[tid * 4 + 3] = excl + c0 + c1 + c2;
-    }
-    __syncthreads();
-    const float off = chunk_tot[tid];
-    __syncthreads();
-    // reuse sv as the inclusive prefix mass P_i (values no longer needed except through P)
-    float prevP = off;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) { ex[e] += off; }
-    const float Zall = block_sum((tid == 255) ? ex[EPT - 1] : 0.f, scratch);       // total mass of the top-k set
-    int nkeep = nk;
+    u64 Z;
+    (void)block_excl_scan<u64>(local, wsum64, Z);
+    // ---- nucleus threshold key: smallest key whose ascending cumulative mass exceeds (1 - top_p) * Z
+    unsigned tp = 0;
     if (p.top_p > 0.f) {
-        const float lim = 1.0f - p.top_p;
-        float cnt = 0.f;
+        const u64 lim = (u64)((double)(1.0f - p.top_p) * (double)Z);
+        unsigned prefix = 0;
+        u64 below = 0;
+        for (int ps = 3; ps >= 0; --ps) {
+            hist_mass[tid] = 0ull;
+            __syncthreads();
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const int i = tid * EPT + e;
-            const float tail = Zall - prevP;              // mass of entries i.. in descending order
-            if (i < nk && (i == 0 || tail / Zall > lim)) cnt += 1.f;
-            prevP = ex[e];
+            for (int i = 0; i < EPT; ++i) {
+                const bool match = (ps == 3) || ((key[i] >> (8 * (ps + 1))) == prefix);
+                if (match && wq[i]) atomicAdd(&hist_mass[(key[i] >> (8 * ps)) & 255], wq[i]);
+            }
+            __syncthreads();
+            const u64 c = hist_mass[tid];
+            u64 tot;
+            const u64 before = below + block_excl_scan<u64>(c, wsum64, tot);   // mass of smaller digits (ascending)
+            if (before <= lim && before + c > lim) { sel_digit = (unsigned)tid; sel_below = before; }
+            __syncthreads();
+            prefix = (prefix << 8) | sel_digit;
+            below = sel_below;
+            __syncthreads();
         }
-        nkeep = (int)(block_sum(cnt, scratch) + 0.5f);
-        if (nkeep < 1) nkeep = 1;
+        tp = prefix;
     }
-    if (p.kept && tid == 0) p.kept[bt] = nkeep;
-    __syncthreads();
+    const unsigned thr = tk > tp ? tk : tp;
+    u64 keepsum = 0;
+    int nkeep = 0;
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) sv[tid * EPT + e] = ex[e];
-    __syncthreads();
-    const float Zkeep = sv[nkeep - 1];
+    for (int i = 0; i < EPT; ++i) {
+        if (!(key[i] >= thr && wq[i])) wq[i] = 0ull;
+        keepsum += wq[i];
+        nkeep += wq[i] ? 1 : 0;
+    }
+    u64 Zk;
+    const u64 excl = block_excl_scan<u64>(keepsum, wsum64, Zk);
+    if (p.kept) {
+        int tot;
+        (void)block_excl_scan<int>(nkeep, wsum32, tot);
+        if (tid == 0) p.kept[bt] = tot;
+    }
     for (int d = 0; d < p.n_draw; ++d) {
-        const float u = uniform01(p.seed, p.stage, (long)d * p.B + b, (int)t);
-        const float target = u * Zkeep;
-        float cnt = 0.f;
+        unsigned long long h = splitmix64(p.seed ^ 0xC0FFEE1234ull);
+        h = splitmix64(h ^ ((unsigned long long)p.stage << 48) ^ ((unsigned long long)((long)d * p.B + b) << 16) ^ (unsigned long long)t);
+        const double u = (double)(h >> 11) * (1.0 / 9007199254740992.0);       // 53 bits -> [0,1)
+        u64 target = (u64)(u * (double)Zk);
+        if (target >= Zk) target = Zk - 1;
+        if (excl <= target && target < excl + keepsum) {                        // exactly one thread
+            u64 run = excl;
+            int pick = tid;
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const int i = tid * EPT + e;
-            if (i < nkeep && ex[e] <= target) cnt += 1.f;
+            for (int i = 0; i < EPT; ++i) {
+                run += wq[i];
+                if (run > target) { pick = i * 256 + tid; break; }
+            }
+            p.idx_out[((long)d * p.B + b) * p.l + t] = pick;
         }
-        int pick = (int)(block_sum(cnt, scratch) + 0.5f);
-        if (pick > nkeep - 1) pick = nkeep - 1;
-        if (tid == 0) p.idx_out[((long)d * p.B + b) * p.l + t] = si[pick];
     }
 }
 
