@@ -293,6 +293,52 @@ def case_lr():
     save('lr_lin0', table=np.array(rows, dtype=np.float64), peak_lr=4e-5, wd=0.08, wd_end=0.08, wp_it=wp_it, max_it=max_it, wp0=0.005, wpe=0.01)
 
 
+def case_train_step():
+    """A20: one training step of the reference on a depth-2 ControlVAR + tiny VQVAE (train_control_var_hpu.py:157-250):
+    tokenise control + image, interleave (mask first), teacher-forced forward, CE mean, backward, clip 2.0, AdamW with
+    filter_params groups and lr_wd_annealing('lin0').  Dropouts off (cond_drop_rate=0, eval-mode DropPath)."""
+    import importlib.util
+    from itertools import chain
+    spec = importlib.util.spec_from_file_location('ref_lr_control', '/root/reference/utils/lr_control.py')
+    lrc = importlib.util.module_from_spec(spec); spec.loader.exec_module(lrc)
+    vae = make_vae(32)
+    cfg = VarConfig(depth=2)
+    m = make_cvar(vae, cfg)            # eval(): DropPath is identity; cond_drop_rate = 0
+    for p_ in m.parameters():
+        p_.requires_grad_(True)
+    images, masks = synth_images(2, 256, seed=6), synth_images(2, 256, seed=7)
+    cls, types = torch.tensor([17, 403]), torch.tensor([2, 0])
+    with torch.no_grad():
+        mask_ids = vae.img_to_idxBl(masks, v_patch_nums=PN); mask_h = vae.idxBl_to_h(mask_ids)
+        img_ids = vae.img_to_idxBl(images, v_patch_nums=PN); img_h = vae.idxBl_to_h(img_ids)
+    labels_list = list(chain.from_iterable(zip(mask_ids, img_ids)))
+    h_list = list(chain.from_iterable(zip(mask_h, img_h)))
+    x = torch.cat(h_list, dim=1)
+    labels = torch.cat(labels_list, dim=1)
+    logits = m(cls, x, types, True)
+    loss_tok = torch.nn.CrossEntropyLoss(reduction='none')(logits.view(-1, logits.size(-1)), labels.view(-1))
+    loss = loss_tok.mean()
+    loss.backward()
+    names = [n for n, _ in m.named_parameters()]
+    gnorms = torch.stack([p_.grad.norm() for _, p_ in m.named_parameters()])
+    sl = {}
+    for n, p_ in m.named_parameters():
+        g = p_.grad
+        sl['g:' + n] = g.reshape(-1)[:: max(1, g.numel() // 64)][:64].clone()
+    total_norm = torch.nn.utils.clip_grad_norm_(m.parameters(), 2.0)
+    _, paras, groups = lrc.filter_params(m, nowd_keys={'cls_token', 'start_token', 'task_token', 'cfg_uncond', 'pos_embed', 'pos_1LC',
+                                                        'pos_start', 'start_pos', 'lvl_embed', 'gamma', 'beta', 'ada_gss', 'moe_bias', 'scale_mul'})
+    nd_names = [n for n, p_ in m.named_parameters() if any(p_ is q for q in groups[[g['wd_sc'] for g in groups].index(0.)]['params'])]
+    opt = torch.optim.AdamW(groups, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.05)
+    lrs = lrc.lr_wd_annealing('lin0', opt, 2e-3, 0.05, 0.01, 7, 20, 1000, wp0=0.005, wpe=0.01)
+    opt.step()
+    after = {}
+    for n, p_ in m.named_parameters():
+        after['p:' + n] = p_.detach().reshape(-1)[:: max(1, p_.numel() // 64)][:64].clone()
+    save('train_step_d2', loss=loss.detach(), loss_tok=loss_tok.detach()[::17].clone(), labels=labels.to(torch.int16), x_sample=x[:, ::7].clone(),
+         names=np.array(names), nd_names=np.array(nd_names), gnorms=gnorms, total_norm=total_norm, lrs=np.array(lrs, dtype=np.float64), **sl, **after)
+
+
 CASES = {
     'interp': case_interp,
     'tok_tiny': lambda: case_tokenizer(32, 3, 'ch32'),
@@ -306,6 +352,7 @@ CASES = {
     'gen_d12': case_generate_d12,
     'sampler': case_sampler,
     'lr': case_lr,
+    'train': case_train_step,
 }
 
 if __name__ == '__main__':
