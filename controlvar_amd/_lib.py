@@ -11,7 +11,7 @@ import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'libcvar_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 CVAR_F32, CVAR_BF16 = 0, 1
 ACT_NONE, ACT_GELU_TANH = 0, 1
@@ -45,8 +45,9 @@ SIGNATURES = {
     'cvar_gemm': (c_i, [C.POINTER(GemmDesc), c_p]),
     'cvar_ln_modulate': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p, c_i, c_i, c_i, c_f, c_p]),
     'cvar_silu_cast': (c_i, [c_p, c_p, c_i, c_l, c_p]),
-    'cvar_attention': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, c_p, c_p]),
-    'cvar_attention_rowwise': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, c_p, c_p]),
+    'cvar_attention': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, c_p, c_p, c_p]),
+    'cvar_attention_rowwise': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, c_p, c_p, c_p]),
+    'cvar_attention_bwd': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, c_p, c_p, c_p]),
     'cvar_cos_qk_norm': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'cvar_cfg_sample': (c_i, [c_p, c_i, c_i, c_i, c_i, C.POINTER(c_f), c_i, c_f, C.c_uint64, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     'cvar_ms_next_input': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
@@ -56,9 +57,22 @@ SIGNATURES = {
     'cvar_groupnorm_ws_bytes': (c_l, [c_i, c_i, c_i]),
     'cvar_groupnorm_silu': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p]),
     'cvar_softmax_rows': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
-    'cvar_transpose': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_l, c_p]),
+    'cvar_transpose': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_l, c_l, c_p]),
     'cvar_nchw_to_nhwc': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     'cvar_nhwc_to_nchw': (c_i, [c_p, c_i, c_l, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_p]),
+    # training step
+    'cvar_gate_residual': (c_i, [c_p, c_p, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_p]),
+    'cvar_gated_grad': (c_i, [c_p, c_p, c_i, c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p]),
+    'cvar_gelu': (c_i, [c_p, c_p, c_i, c_l, c_p]),
+    'cvar_gelu_bwd': (c_i, [c_p, c_p, c_i, c_l, c_p]),
+    'cvar_ln_modulate_bwd': (c_i, [c_p, c_p, c_i, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_p, c_p]),
+    'cvar_colsum': (c_i, [c_p, c_i, c_l, c_p, c_l, c_i, c_i, c_p, c_p]),
+    'cvar_ce_fwd_bwd': (c_i, [c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_l, c_i, c_p]),
+    'cvar_scatter_add_rows': (c_i, [c_p, c_l, c_p, c_p, c_i, c_i, c_p]),
+    'cvar_silu_bwd': (c_i, [c_p, c_p, c_p, c_l, c_p]),
+    'cvar_adamw': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_p, c_f, c_p]),
+    'cvar_sumsq': (c_i, [c_p, c_l, c_p, c_p]),
+    'cvar_clip_coef': (c_i, [c_p, c_l, c_f, c_f, c_p, c_p]),
 }
 
 _lib = None

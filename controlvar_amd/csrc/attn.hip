@@ -13,6 +13,7 @@ struct AttnParams {
     float scale;
     int n_lvl;
     int lvl_end[16];
+    float* lse;          // optional [R][H][l] log-sum-exp of the scaled scores (saved for the backward pass)
 };
 
 __device__ __forceinline__ int kv_len_of(const AttnParams& p, int pos) {
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p) {
         T* op = (T*)p.out + (r * p.l + qi) * (long)(p.H * D) + h * D;
 #pragma unroll
         for (int d = 0; d < D; ++d) Elem<T>::st(op + d, o[d] * inv);
+        if (p.lse) p.lse[(r * p.H + h) * (long)p.l + qi] = m + logf(lsum);
     }
 }
 
@@ -113,11 +115,11 @@ __global__ void attn_mfma_bf16_kernel(const AttnParams p);
 
 // impl: 0 = auto (MFMA flash kernel for bf16, row-wise exact kernel for fp32), 1 = row-wise
 static int cvar_attention_impl(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
-                               const int* lvl_end_host, int n_lvl, void* out, void* stream, int impl) {
+                               const int* lvl_end_host, int n_lvl, void* out, float* lse, void* stream, int impl) {
     if (!qkv || !out || R <= 0 || H <= 0 || l <= 0 || q_off < 0 || q_off + l > Lmax) return CVAR_EINVAL;
     if (n_lvl < 0 || n_lvl > 16 || (n_lvl > 0 && !lvl_end_host)) return CVAR_EINVAL;
     AttnParams p;
-    p.qkv = qkv; p.out = out; p.R = R; p.H = H; p.Lmax = Lmax; p.q_off = q_off; p.l = l; p.scale = scale; p.n_lvl = n_lvl;
+    p.qkv = qkv; p.out = out; p.R = R; p.H = H; p.Lmax = Lmax; p.q_off = q_off; p.l = l; p.scale = scale; p.n_lvl = n_lvl; p.lse = lse;
     for (int i = 0; i < 16; ++i) p.lvl_end[i] = i < n_lvl ? lvl_end_host[i] : 0;
     if (dtype == CVAR_BF16 && impl == 0) {
         hipLaunchKernelGGL(attn_mfma_bf16_kernel, dim3(cdiv(l, 128), H, R), dim3(256), 0, as_stream(stream), p);
@@ -278,6 +280,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bf16_kernel(const AttnParams p)
     }
     lsum += __shfl_xor(lsum, 32, 64);
     if (qi < p.l) {
+        if (p.lse && hi == 0) p.lse[(r * p.H + h) * (long)p.l + qi] = (m + log2f(lsum)) * 0.6931471805599453f;
         const float inv = 1.0f / lsum;
         bf16_t* op = (bf16_t*)p.out + (r * p.l + qi) * (long)(p.H * D) + h * D;
 #pragma unroll
@@ -293,10 +296,223 @@ __global__ __launch_bounds__(256) void attn_mfma_bf16_kernel(const AttnParams p)
 }
 
 extern "C" int cvar_attention_rowwise(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
-                                      const int* lvl_end_host, int n_lvl, void* out, void* stream) {
-    return cvar_attention_impl(qkv, dtype, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, out, stream, 1);
+                                      const int* lvl_end_host, int n_lvl, void* out, float* lse, void* stream) {
+    return cvar_attention_impl(qkv, dtype, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, out, lse, stream, 1);
 }
 extern "C" int cvar_attention(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
-                              const int* lvl_end_host, int n_lvl, void* out, void* stream) {
-    return cvar_attention_impl(qkv, dtype, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, out, stream, 0);
+                              const int* lvl_end_host, int n_lvl, void* out, float* lse, void* stream) {
+    return cvar_attention_impl(qkv, dtype, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, out, lse, stream, 0);
+}
+
+// ================================================================================================
+// Backward of the (level-masked) attention, exact fp32 math, row-per-lane like attn_rowwise_kernel.
+//   D[q]   = sum_d dO[q,d] O[q,d]
+//   P      = exp(S*scale - lse)            (recomputed, never stored)
+//   dV[k] += P^T dO ;  dP = dO V^T ;  dS = P * (dP - D) ;  dQ = dS K * scale ;  dK = dS^T Q * scale
+// dqkv has the arena layout [R][Lmax][3*H*64] (q | k | v thirds).
+// ================================================================================================
+struct AttnBwdParams {
+    const void* qkv; const void* o; const void* dout; const float* lse; float* dsum; void* dqkv;
+    int R, H, Lmax, q_off, l;
+    float scale;
+    int n_lvl;
+    int lvl_end[16];
+};
+__device__ __forceinline__ int kv_len_of_b(const AttnBwdParams& p, int pos) {
+    if (p.n_lvl == 0) return p.q_off + p.l;
+    int e = p.lvl_end[p.n_lvl - 1];
+    for (int k = p.n_lvl - 1; k >= 0; --k)
+        if (pos < p.lvl_end[k]) e = p.lvl_end[k];
+    return e;
+}
+// first query position (relative to q_off) that can see key position `key`
+__device__ __forceinline__ int first_query_of(const AttnBwdParams& p, int key) {
+    if (p.n_lvl == 0) return 0;
+    int b = 0;
+    for (int k = 0; k < p.n_lvl; ++k) { if (key < p.lvl_end[k]) break; b = p.lvl_end[k]; }
+    return max(0, b - p.q_off);
+}
+
+template <typename T>
+__global__ void attn_bwd_prep_kernel(const AttnBwdParams p) {      // dsum[r][h][q] = sum_d dO * O
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // over R*l*H
+    const long total = (long)p.R * p.l * p.H;
+    if (i >= total) return;
+    const int h = (int)(i % p.H);
+    const long rq = i / p.H;
+    const T* op = (const T*)p.o + rq * (long)(p.H * 64) + h * 64;
+    const T* dp = (const T*)p.dout + rq * (long)(p.H * 64) + h * 64;
+    float a = 0.f;
+#pragma unroll
+    for (int d = 0; d < 64; ++d) a = fmaf(Elem<T>::ld(op + d), Elem<T>::ld(dp + d), a);
+    const long r = rq / p.l, q = rq % p.l;
+    p.dsum[(r * p.H + h) * (long)p.l + q] = a;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+    constexpr int D = 64, KT = 64;
+    constexpr int VEC = 16 / sizeof(T);
+    __shared__ __attribute__((aligned(16))) float Ks[KT][D];
+    __shared__ __attribute__((aligned(16))) float Vs[KT][D];
+    const int tid = threadIdx.x, h = blockIdx.y;
+    const long r = blockIdx.z;
+    const int C3 = 3 * p.H * D;
+    const T* base = (const T*)p.qkv + r * (long)p.Lmax * C3;
+    const int qi = blockIdx.x * 256 + tid;
+    const bool valid = qi < p.l;
+    const int qrow = valid ? qi : p.l - 1;
+    const int pos = p.q_off + qrow;
+    const int kvlen = kv_len_of_b(p, pos);
+    const int kv_end = kv_len_of_b(p, p.q_off + min(p.l, (int)(blockIdx.x + 1) * 256) - 1);
+    float q[D], dO[D], dq[D];
+    {
+        const T* qp = base + (long)pos * C3 + h * D;
+        const T* dp = (const T*)p.dout + (r * p.l + qrow) * (long)(p.H * D) + h * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { q[d] = Elem<T>::ld(qp + d); dO[d] = Elem<T>::ld(dp + d); dq[d] = 0.f; }
+    }
+    const float lse = p.lse[(r * p.H + h) * (long)p.l + qrow];
+    const float Dq = p.dsum[(r * p.H + h) * (long)p.l + qrow];
+    for (int kt0 = 0; kt0 < kv_end; kt0 += KT) {
+        for (int v = tid; v < KT * D / VEC; v += 256) {
+            const int kk = v / (D / VEC), d0 = (v % (D / VEC)) * VEC;
+            const int key = kt0 + kk;
+            if (key < kv_end) {
+                const T* kp = base + (long)key * C3 + p.H * D + h * D + d0;
+                const T* vp = kp + p.H * D;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { Ks[kk][d0 + e] = Elem<T>::ld(kp + e); Vs[kk][d0 + e] = Elem<T>::ld(vp + e); }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { Ks[kk][d0 + e] = 0.f; Vs[kk][d0 + e] = 0.f; }
+            }
+        }
+        __syncthreads();
+        for (int kk = 0; kk < KT; ++kk) {
+            if (kt0 + kk >= kvlen) break;                 // keys are visible as a prefix
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; d += 4) {
+                const f32x4_t kv = *(const f32x4_t*)&Ks[kk][d];
+                const f32x4_t vv = *(const f32x4_t*)&Vs[kk][d];
+                s = fmaf(q[d], kv[0], s); s = fmaf(q[d + 1], kv[1], s); s = fmaf(q[d + 2], kv[2], s); s = fmaf(q[d + 3], kv[3], s);
+                dp = fmaf(dO[d], vv[0], dp); dp = fmaf(dO[d + 1], vv[1], dp); dp = fmaf(dO[d + 2], vv[2], dp); dp = fmaf(dO[d + 3], vv[3], dp);
+            }
+            const float pr = __expf(s * p.scale - lse);
+            const float ds = pr * (dp - Dq);
+#pragma unroll
+            for (int d = 0; d < D; d += 4) {
+                const f32x4_t kv = *(const f32x4_t*)&Ks[kk][d];
+                dq[d] = fmaf(ds, kv[0], dq[d]); dq[d + 1] = fmaf(ds, kv[1], dq[d + 1]);
+                dq[d + 2] = fmaf(ds, kv[2], dq[d + 2]); dq[d + 3] = fmaf(ds, kv[3], dq[d + 3]);
+            }
+        }
+        __syncthreads();
+    }
+    if (valid) {
+        T* op = (T*)p.dqkv + (r * p.Lmax + pos) * (long)C3 + h * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) Elem<T>::st(op + d, dq[d] * p.scale);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
+    constexpr int D = 64, QT = 32;
+    constexpr int VEC = 16 / sizeof(T);
+    __shared__ __attribute__((aligned(16))) float Qs[QT][D];
+    __shared__ __attribute__((aligned(16))) float Os[QT][D];
+    __shared__ float Ls[QT], Ds[QT];
+    __shared__ int Kv[QT];
+    const int tid = threadIdx.x, h = blockIdx.y;
+    const long r = blockIdx.z;
+    const int C3 = 3 * p.H * D;
+    const T* base = (const T*)p.qkv + r * (long)p.Lmax * C3;
+    const int nkeys = p.q_off + p.l;
+    const int kj = blockIdx.x * 256 + tid;               // key position
+    const bool valid = kj < nkeys;
+    const int krow = valid ? kj : nkeys - 1;
+    float k[D], v[D], dk[D], dv[D];
+    {
+        const T* kp = base + (long)krow * C3 + p.H * D + h * D;
+        const T* vp = kp + p.H * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { k[d] = Elem<T>::ld(kp + d); v[d] = Elem<T>::ld(vp + d); dk[d] = 0.f; dv[d] = 0.f; }
+    }
+    const int q_begin = first_query_of(p, blockIdx.x * 256);        // first query that sees the block's first key
+    for (int qt0 = (q_begin / QT) * QT; qt0 < p.l; qt0 += QT) {
+        for (int vv = tid; vv < QT * D / VEC; vv += 256) {
+            const int qq = vv / (D / VEC), d0 = (vv % (D / VEC)) * VEC;
+            const int qi = qt0 + qq;
+            if (qi < p.l) {
+                const T* qp = base + (long)(p.q_off + qi) * C3 + h * D + d0;
+                const T* dp = (const T*)p.dout + (r * p.l + qi) * (long)(p.H * D) + h * D + d0;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { Qs[qq][d0 + e] = Elem<T>::ld(qp + e); Os[qq][d0 + e] = Elem<T>::ld(dp + e); }
+            } else {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) { Qs[qq][d0 + e] = 0.f; Os[qq][d0 + e] = 0.f; }
+            }
+        }
+        if (tid < QT) {
+            const int qi = qt0 + tid;
+            const bool ok = qi < p.l;
+            Ls[tid] = ok ? p.lse[(r * p.H + h) * (long)p.l + qi] : 0.f;
+            Ds[tid] = ok ? p.dsum[(r * p.H + h) * (long)p.l + qi] : 0.f;
+            Kv[tid] = ok ? kv_len_of_b(p, p.q_off + qi) : 0;
+        }
+        __syncthreads();
+        for (int qq = 0; qq < QT; ++qq) {
+            if (krow >= Kv[qq]) continue;                  // query does not see this key (or is padding)
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; d += 4) {
+                const f32x4_t qv = *(const f32x4_t*)&Qs[qq][d];
+                const f32x4_t ov = *(const f32x4_t*)&Os[qq][d];
+                s = fmaf(qv[0], k[d], s); s = fmaf(qv[1], k[d + 1], s); s = fmaf(qv[2], k[d + 2], s); s = fmaf(qv[3], k[d + 3], s);
+                dp = fmaf(ov[0], v[d], dp); dp = fmaf(ov[1], v[d + 1], dp); dp = fmaf(ov[2], v[d + 2], dp); dp = fmaf(ov[3], v[d + 3], dp);
+            }
+            const float pr = __expf(s * p.scale - Ls[qq]);
+            const float ds = pr * (dp - Ds[qq]);
+#pragma unroll
+            for (int d = 0; d < D; d += 4) {
+                const f32x4_t qv = *(const f32x4_t*)&Qs[qq][d];
+                const f32x4_t ov = *(const f32x4_t*)&Os[qq][d];
+                dv[d] = fmaf(pr, ov[0], dv[d]); dv[d + 1] = fmaf(pr, ov[1], dv[d + 1]); dv[d + 2] = fmaf(pr, ov[2], dv[d + 2]); dv[d + 3] = fmaf(pr, ov[3], dv[d + 3]);
+                dk[d] = fmaf(ds, qv[0], dk[d]); dk[d + 1] = fmaf(ds, qv[1], dk[d + 1]); dk[d + 2] = fmaf(ds, qv[2], dk[d + 2]); dk[d + 3] = fmaf(ds, qv[3], dk[d + 3]);
+            }
+        }
+        __syncthreads();
+    }
+    if (valid) {
+        T* kp = (T*)p.dqkv + (r * p.Lmax + kj) * (long)C3 + p.H * D + h * D;
+        T* vp = kp + p.H * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { Elem<T>::st(kp + d, dk[d] * p.scale); Elem<T>::st(vp + d, dv[d]); }
+    }
+}
+
+// ws: R*H*l floats (D = rowsum(dO * O))
+extern "C" int cvar_attention_bwd(const void* qkv, int dtype, const void* o, const void* dout, const float* lse, int R, int H, int Lmax,
+                                  int q_off, int l, float scale, const int* lvl_end_host, int n_lvl, void* dqkv, float* ws, void* stream) {
+    if (!qkv || !o || !dout || !lse || !dqkv || !ws || R <= 0 || H <= 0 || l <= 0 || q_off != 0 || l > Lmax) return CVAR_EINVAL;
+    if (n_lvl < 0 || n_lvl > 16 || (n_lvl > 0 && !lvl_end_host)) return CVAR_EINVAL;
+    AttnBwdParams p;
+    p.qkv = qkv; p.o = o; p.dout = dout; p.lse = lse; p.dsum = ws; p.dqkv = dqkv;
+    p.R = R; p.H = H; p.Lmax = Lmax; p.q_off = q_off; p.l = l; p.scale = scale; p.n_lvl = n_lvl;
+    for (int i = 0; i < 16; ++i) p.lvl_end[i] = i < n_lvl ? lvl_end_host[i] : 0;
+    const long tot = (long)R * l * H;
+    hipStream_t st = as_stream(stream);
+    if (dtype == CVAR_BF16) {
+        hipLaunchKernelGGL(attn_bwd_prep_kernel<bf16_t>, dim3(cdiv(tot, 256)), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, dim3(cdiv(l, 256), H, R), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, dim3(cdiv(l, 256), H, R), dim3(256), 0, st, p);
+    } else if (dtype == CVAR_F32) {
+        hipLaunchKernelGGL(attn_bwd_prep_kernel<float>, dim3(cdiv(tot, 256)), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, dim3(cdiv(l, 256), H, R), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<float>, dim3(cdiv(l, 256), H, R), dim3(256), 0, st, p);
+    } else return CVAR_EUNSUPPORTED;
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
 }

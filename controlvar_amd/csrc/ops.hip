@@ -399,7 +399,7 @@ extern "C" int cvar_softmax_rows(const float* s, void* p, int out_dtype, int row
 
 // [B][n][c] (row stride ld_in) -> [B][c][n]
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int n, int c, long ld_in) {
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int n, int c, long ld_in, long ld_out) {
     __shared__ T tile[32][33];
     const long b = blockIdx.z;
     const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -408,14 +408,14 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in
         if (n0 + r < n && c0 + tx < c) tile[r][tx] = in[(b * n + n0 + r) * ld_in + c0 + tx];
     __syncthreads();
     for (int r = ty; r < 32; r += 8)
-        if (c0 + r < c && n0 + tx < n) out[(b * c + c0 + r) * (long)n + n0 + tx] = tile[tx][r];
+        if (c0 + r < c && n0 + tx < n) out[(b * c + c0 + r) * ld_out + n0 + tx] = tile[tx][r];
 }
 
-extern "C" int cvar_transpose(const void* in, void* out, int dtype, int B, int n, int c, int64_t ld_in, void* stream) {
-    if (!in || !out || B <= 0 || n <= 0 || c <= 0) return CVAR_EINVAL;
+extern "C" int cvar_transpose(const void* in, void* out, int dtype, int B, int n, int c, int64_t ld_in, int64_t ld_out, void* stream) {
+    if (!in || !out || B <= 0 || n <= 0 || c <= 0 || ld_out < n) return CVAR_EINVAL;
     dim3 grid(cdiv(n, 32), cdiv(c, 32), B), block(256);
-    if (dtype == CVAR_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, block, 0, as_stream(stream), (const bf16_t*)in, (bf16_t*)out, n, c, (long)ld_in);
-    else if (dtype == CVAR_F32) hipLaunchKernelGGL(transpose_kernel<float>, grid, block, 0, as_stream(stream), (const float*)in, (float*)out, n, c, (long)ld_in);
+    if (dtype == CVAR_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, block, 0, as_stream(stream), (const bf16_t*)in, (bf16_t*)out, n, c, (long)ld_in, (long)ld_out);
+    else if (dtype == CVAR_F32) hipLaunchKernelGGL(transpose_kernel<float>, grid, block, 0, as_stream(stream), (const float*)in, (float*)out, n, c, (long)ld_in, (long)ld_out);
     else return CVAR_EUNSUPPORTED;
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;
@@ -472,7 +472,7 @@ extern "C" int cvar_nhwc_to_nchw(const void* in, int dtype, int64_t ld_in, float
     return CVAR_OK;
 }
 
-extern "C" int cvar_abi_version(void) { return 1; }
+extern "C" int cvar_abi_version(void) { return 2; }
 extern "C" const char* cvar_status_str(int status) {
     switch (status) {
         case CVAR_OK: return "ok";

@@ -1,0 +1,368 @@
+// Training-side kernels of the teacher-forced transformer step (SURVEY.md 8a rows A5 backward / A20):
+// gated residual + its gradient, GELU forward/backward, adaLN-modulated LayerNorm backward, column sums, fused
+// cross-entropy forward+backward, embedding scatter, SiLU backward, fused AdamW and the gradient-norm reduction.
+// All reductions are two-level with a fixed order (no atomics): results are bit-reproducible.
+#include "cvar_common.h"
+
+constexpr int RED_S = 8;      // row segments of the per-sequence column reductions
+
+// x[m,c] += gate[r,c] * rowscale[r] * f[m,c]          (x + drop_path(gamma * f(x)), basic_var.py:208-209)
+template <typename T>
+__global__ void gate_residual_kernel(float* __restrict__ x, const T* __restrict__ f, const float* __restrict__ gate, long ldg,
+                                     int gate_rows, const float* __restrict__ rowscale, long M, int C) {
+    const long nvec = M * (C / 4);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / (C / 4);
+        const int c = (int)(i % (C / 4)) * 4;
+        const long r = m / gate_rows;
+        const float rs = rowscale ? rowscale[r] : 1.0f;
+        const f32x4_t g = *(const f32x4_t*)(gate + r * ldg + c);
+        f32x4_t xv = *(f32x4_t*)(x + m * C + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[e] += (g[e] * rs) * Elem<T>::ld(f + m * C + c + e);
+        *(f32x4_t*)(x + m * C + c) = xv;
+    }
+}
+
+extern "C" int cvar_gate_residual(float* x, const void* f, int dtype, const float* gate, int64_t ldg, int gate_rows,
+                                  const float* rowscale, int64_t M, int C, void* stream) {
+    if (!x || !f || !gate || M <= 0 || C <= 0 || gate_rows <= 0) return CVAR_EINVAL;
+    if (C % 4 || ldg % 4) return CVAR_EUNSUPPORTED;
+    dim3 grid((unsigned)min((int64_t)8192, (M * (C / 4) + 255) / 256)), block(256);
+    if (dtype == CVAR_BF16) hipLaunchKernelGGL(gate_residual_kernel<bf16_t>, grid, block, 0, as_stream(stream), x, (const bf16_t*)f, gate, (long)ldg, gate_rows, rowscale, (long)M, C);
+    else if (dtype == CVAR_F32) hipLaunchKernelGGL(gate_residual_kernel<float>, grid, block, 0, as_stream(stream), x, (const float*)f, gate, (long)ldg, gate_rows, rowscale, (long)M, C);
+    else return CVAR_EUNSUPPORTED;
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// ---- GELU(tanh) forward / backward ---------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_tanh_grad(float t) {
+    // g(t) = t * sig(2u), u = k (t + 0.044715 t^3)  ->  g' = sig + t * sig * (1 - sig) * 2k (1 + 3*0.044715 t^2)
+    const float k2 = 2.0f * 0.7978845608028654f;
+    const float u2 = k2 * (t + 0.044715f * t * t * t);
+    const float sg = 1.0f / (1.0f + __expf(-u2));
+    return sg + t * sg * (1.0f - sg) * k2 * (1.0f + 0.134145f * t * t);
+}
+template <typename T, bool BWD>
+__global__ void gelu_kernel(const T* __restrict__ a, T* __restrict__ io, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float t = Elem<T>::ld(a + i);
+        if (BWD) Elem<T>::st(io + i, Elem<T>::ld(io + i) * gelu_tanh_grad(t));
+        else Elem<T>::st(io + i, gelu_tanh_f(t));
+    }
+}
+// h = gelu(a)
+extern "C" int cvar_gelu(const void* a, void* h, int dtype, int64_t n, void* stream) {
+    if (!a || !h || n <= 0) return CVAR_EINVAL;
+    dim3 grid((unsigned)min((int64_t)8192, (n + 255) / 256)), block(256);
+    if (dtype == CVAR_BF16) hipLaunchKernelGGL((gelu_kernel<bf16_t, false>), grid, block, 0, as_stream(stream), (const bf16_t*)a, (bf16_t*)h, (long)n);
+    else if (dtype == CVAR_F32) hipLaunchKernelGGL((gelu_kernel<float, false>), grid, block, 0, as_stream(stream), (const float*)a, (float*)h, (long)n);
+    else return CVAR_EUNSUPPORTED;
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+// dh <- dh * gelu'(a)
+extern "C" int cvar_gelu_bwd(const void* a, void* dh, int dtype, int64_t n, void* stream) {
+    if (!a || !dh || n <= 0) return CVAR_EINVAL;
+    dim3 grid((unsigned)min((int64_t)8192, (n + 255) / 256)), block(256);
+    if (dtype == CVAR_BF16) hipLaunchKernelGGL((gelu_kernel<bf16_t, true>), grid, block, 0, as_stream(stream), (const bf16_t*)a, (bf16_t*)dh, (long)n);
+    else if (dtype == CVAR_F32) hipLaunchKernelGGL((gelu_kernel<float, true>), grid, block, 0, as_stream(stream), (const float*)a, (float*)dh, (long)n);
+    else return CVAR_EUNSUPPORTED;
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// ---- per-sequence column reductions ----------------------------------------------------------------------------
+// grid (ceil(C/256), R, RED_S): thread = channel, block = one row segment of one sequence; partial[s][r][k][c]
+template <typename T>
+__global__ __launch_bounds__(256) void gated_grad_kernel(const float* __restrict__ dx, const T* __restrict__ f, const float* __restrict__ gate,
+                                                        long ldg, const float* __restrict__ rowscale, T* __restrict__ df,
+                                                        float* __restrict__ partial, int R, int l, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y, s = blockIdx.z;
+    if (c >= C) return;
+    const int seg = (l + RED_S - 1) / RED_S;
+    const int t0 = s * seg, t1 = min(l, t0 + seg);
+    const float g = gate[(long)r * ldg + c] * (rowscale ? rowscale[r] : 1.0f);
+    float acc = 0.f;
+    for (int t = t0; t < t1; ++t) {
+        const long i = ((long)r * l + t) * C + c;
+        const float d = dx[i];
+        acc += d * Elem<T>::ld(f + i);
+        Elem<T>::st(df + i, d * g);
+    }
+    partial[((long)s * R + r) * C + c] = acc;
+}
+// out[r*ldo + c] = scale_r * sum_s partial[s][r][c]
+__global__ void red_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, long ldo, const float* __restrict__ rowscale,
+                                    int R, int C, int nseg) {
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int s = 0; s < nseg; ++s) a += partial[((long)s * R + r) * C + c];
+    out[(long)r * ldo + c] = a * (rowscale ? rowscale[r] : 1.0f);
+}
+
+// df = dx * gate * rowscale (dtype);  dgate[r, c] = rowscale[r] * sum_{m in r} dx[m,c] * f[m,c]
+// ws: RED_S * R * C floats
+extern "C" int cvar_gated_grad(const float* dx, const void* f, int dtype, const float* gate, int64_t ldg, const float* rowscale,
+                               void* df, float* dgate, int64_t ldo, int R, int l, int C, float* ws, void* stream) {
+    if (!dx || !f || !gate || !df || !dgate || !ws || R <= 0 || l <= 0 || C <= 0) return CVAR_EINVAL;
+    dim3 grid(cdiv(C, 256), R, RED_S), block(256);
+    if (dtype == CVAR_BF16) hipLaunchKernelGGL(gated_grad_kernel<bf16_t>, grid, block, 0, as_stream(stream), dx, (const bf16_t*)f, gate, (long)ldg, rowscale, (bf16_t*)df, ws, R, l, C);
+    else if (dtype == CVAR_F32) hipLaunchKernelGGL(gated_grad_kernel<float>, grid, block, 0, as_stream(stream), dx, (const float*)f, gate, (long)ldg, rowscale, (float*)df, ws, R, l, C);
+    else return CVAR_EUNSUPPORTED;
+    hipLaunchKernelGGL(red_finalize_kernel, dim3(cdiv(C, 256), R), block, 0, as_stream(stream), ws, dgate, (long)ldo, rowscale, R, C, RED_S);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// ---- adaLN LayerNorm backward ----------------------------------------------------------------------------------
+// y = xhat * (1 + s) + b, xhat = (x - mu) * rstd.   Row kernel: dx_out = dx_in + rstd * (g - mean(g) - xhat * mean(g*xhat)),
+// g = dy * (1 + s); also stores (mu, rstd) per row for the column kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_row_kernel(const float* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ scale,
+                                                        long ld_ada, int rows_per, const float* __restrict__ dx_in, float* __restrict__ dx_out,
+                                                        float* __restrict__ stats, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (long)row * C;
+    const T* dyr = dy + (long)row * C;
+    const float* sc = scale + (long)(row / rows_per) * ld_ada;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mu; q += d * d; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    float sg = 0.f, sgx = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float g = Elem<T>::ld(dyr + c) * (1.0f + sc[c]);
+        const float xh = (xr[c] - mu) * rstd;
+        sg += g; sgx += g * xh;
+    }
+    const float mg = wave_sum(sg) / (float)C, mgx = wave_sum(sgx) / (float)C;
+    for (int c = lane; c < C; c += 64) {
+        const float g = Elem<T>::ld(dyr + c) * (1.0f + sc[c]);
+        const float xh = (xr[c] - mu) * rstd;
+        const float d = rstd * (g - mg - xh * mgx);
+        dx_out[(long)row * C + c] = (dx_in ? dx_in[(long)row * C + c] : 0.f) + d;
+    }
+    if (lane == 0) { stats[2 * (long)row] = mu; stats[2 * (long)row + 1] = rstd; }
+}
+// column kernel: partial[s][r][0][c] = sum dy * xhat, partial[s][r][1][c] = sum dy
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_col_kernel(const float* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ stats,
+                                                        float* __restrict__ partial, int R, int l, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.y, s = blockIdx.z;
+    if (c >= C) return;
+    const int seg = (l + RED_S - 1) / RED_S;
+    const int t0 = s * seg, t1 = min(l, t0 + seg);
+    float a = 0.f, b = 0.f;
+    for (int t = t0; t < t1; ++t) {
+        const long m = (long)r * l + t;
+        const float d = Elem<T>::ld(dy + m * C + c);
+        a += d * ((x[m * C + c] - stats[2 * m]) * stats[2 * m + 1]);
+        b += d;
+    }
+    partial[(((long)s * R + r) * 2 + 0) * C + c] = a;
+    partial[(((long)s * R + r) * 2 + 1) * C + c] = b;
+}
+__global__ void ln_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dscale, float* __restrict__ dshift, long ldo, int R, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int s = 0; s < RED_S; ++s) { a += partial[(((long)s * R + r) * 2 + 0) * C + c]; b += partial[(((long)s * R + r) * 2 + 1) * C + c]; }
+    dscale[(long)r * ldo + c] = a;
+    dshift[(long)r * ldo + c] = b;
+}
+
+// ws: M*2 floats (row stats) + RED_S*R*2*C floats
+extern "C" int cvar_ln_modulate_bwd(const float* x, const void* dy, int dtype, const float* scale, int64_t ld_ada, int rows_per,
+                                    const float* dx_in, float* dx_out, float* dscale, float* dshift, int64_t ldo,
+                                    int M, int C, float eps, float* ws, void* stream) {
+    if (!x || !dy || !scale || !dx_out || !dscale || !dshift || !ws || M <= 0 || C <= 0 || rows_per <= 0 || M % rows_per) return CVAR_EINVAL;
+    const int R = M / rows_per;
+    float* stats = ws;
+    float* partial = ws + 2 * (size_t)M;
+    dim3 b256(256);
+    if (dtype == CVAR_BF16) {
+        hipLaunchKernelGGL(ln_bwd_row_kernel<bf16_t>, dim3(cdiv(M, 4)), b256, 0, as_stream(stream), x, (const bf16_t*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps);
+        hipLaunchKernelGGL(ln_bwd_col_kernel<bf16_t>, dim3(cdiv(C, 256), R, RED_S), b256, 0, as_stream(stream), x, (const bf16_t*)dy, stats, partial, R, rows_per, C);
+    } else if (dtype == CVAR_F32) {
+        hipLaunchKernelGGL(ln_bwd_row_kernel<float>, dim3(cdiv(M, 4)), b256, 0, as_stream(stream), x, (const float*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps);
+        hipLaunchKernelGGL(ln_bwd_col_kernel<float>, dim3(cdiv(C, 256), R, RED_S), b256, 0, as_stream(stream), x, (const float*)dy, stats, partial, R, rows_per, C);
+    } else return CVAR_EUNSUPPORTED;
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(cdiv(C, 256), R), b256, 0, as_stream(stream), partial, dscale, dshift, (long)ldo, R, C);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// ---- column sum: out[n] (+)= sum_m A[m, n]   (bias gradients) ---------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ A, long lda, float* __restrict__ partial, long M, int N, int nseg) {
+    const int n = blockIdx.x * 256 + threadIdx.x, s = blockIdx.y;
+    if (n >= N) return;
+    const long seg = (M + nseg - 1) / nseg;
+    const long m0 = s * seg, m1 = min(M, m0 + seg);
+    float a = 0.f;
+    for (long m = m0; m < m1; ++m) a += Elem<T>::ld(A + m * lda + n);
+    partial[(long)s * N + n] = a;
+}
+__global__ void colsum_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int N, int nseg, int accumulate) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float a = 0.f;
+    for (int s = 0; s < nseg; ++s) a += partial[(long)s * N + n];
+    out[n] = accumulate ? out[n] + a : a;
+}
+// ws: 64 * N floats
+extern "C" int cvar_colsum(const void* A, int dtype, int64_t lda, float* out, int64_t M, int N, int accumulate, float* ws, void* stream) {
+    if (!A || !out || !ws || M <= 0 || N <= 0) return CVAR_EINVAL;
+    const int nseg = (int)min((int64_t)64, max((int64_t)1, M / 64));
+    dim3 grid(cdiv(N, 256), nseg), block(256);
+    if (dtype == CVAR_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, block, 0, as_stream(stream), (const bf16_t*)A, (long)lda, ws, (long)M, N, nseg);
+    else if (dtype == CVAR_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, as_stream(stream), (const float*)A, (long)lda, ws, (long)M, N, nseg);
+    else return CVAR_EUNSUPPORTED;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(N, 256)), block, 0, as_stream(stream), ws, out, N, nseg, accumulate);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// ---- fused cross-entropy forward + backward over the 4096-way vocabulary ------------------------------------------
+// loss_tok[m] = logsumexp(logits[m,:]) - logits[m, target[m]];  dlogits[m,v] = (softmax - onehot) * w[m] * gscale
+template <typename TO>
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int* __restrict__ target, const float* __restrict__ weight,
+                                                float gscale, float* __restrict__ loss_tok, TO* __restrict__ dlogits, int V) {
+    __shared__ float red[4];
+    const long m = blockIdx.x;
+    const float* lr = logits + m * V;
+    float mx = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += 256) mx = fmaxf(mx, lr[v]);
+    mx = wave_max(mx);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float se = 0.f;
+    for (int v = threadIdx.x; v < V; v += 256) se += __expf(lr[v] - mx);
+    se = wave_sum(se);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = se;
+    __syncthreads();
+    se = (red[0] + red[1]) + (red[2] + red[3]);
+    const int tg = target[m];
+    if (threadIdx.x == 0) loss_tok[m] = (logf(se) + mx) - lr[tg];
+    if (dlogits) {
+        const float w = (weight ? weight[m] : 1.0f) * gscale;
+        const float inv = 1.0f / se;
+        for (int v = threadIdx.x; v < V; v += 256) {
+            const float pr = __expf(lr[v] - mx) * inv;
+            Elem<TO>::st(dlogits + m * V + v, (pr - (v == tg ? 1.0f : 0.0f)) * w);
+        }
+    }
+}
+extern "C" int cvar_ce_fwd_bwd(const float* logits, const int32_t* target, const float* weight, float gscale, float* loss_tok,
+                               void* dlogits, int out_dtype, int64_t M, int V, void* stream) {
+    if (!logits || !target || !loss_tok || M <= 0 || V <= 1) return CVAR_EINVAL;
+    dim3 grid((unsigned)M), block(256);
+    if (!dlogits || out_dtype == CVAR_F32) hipLaunchKernelGGL(ce_kernel<float>, grid, block, 0, as_stream(stream), logits, target, weight, gscale, loss_tok, (float*)dlogits, V);
+    else if (out_dtype == CVAR_BF16) hipLaunchKernelGGL(ce_kernel<bf16_t>, grid, block, 0, as_stream(stream), logits, target, weight, gscale, loss_tok, (bf16_t*)dlogits, V);
+    else return CVAR_EUNSUPPORTED;
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// ---- embedding-row scatter (class_emb / cond_embed gradients): dst[idx[i], :] += src[i, :], rows applied in order ---
+__global__ void scatter_add_rows_kernel(const float* __restrict__ src, long lds, const int* __restrict__ idx, float* __restrict__ dst, int n, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    for (int i = 0; i < n; ++i) dst[(long)idx[i] * C + c] += src[(long)i * lds + c];
+}
+extern "C" int cvar_scatter_add_rows(const float* src, int64_t ld_src, const int32_t* idx, float* dst, int n, int C, void* stream) {
+    if (!src || !idx || !dst || n <= 0 || C <= 0) return CVAR_EINVAL;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(cdiv(C, 256)), dim3(256), 0, as_stream(stream), src, (long)ld_src, idx, dst, n, C);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// dcond = dsilu * silu'(cond),  silu'(x) = sig(x) * (1 + x * (1 - sig(x)))
+__global__ void silu_bwd_kernel(const float* __restrict__ cond, const float* __restrict__ dsilu, float* __restrict__ dcond, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float x = cond[i], sg = 1.0f / (1.0f + __expf(-x));
+        dcond[i] = dsilu[i] * (sg * (1.0f + x * (1.0f - sg)));
+    }
+}
+extern "C" int cvar_silu_bwd(const float* cond, const float* dsilu, float* dcond, int64_t n, void* stream) {
+    if (!cond || !dsilu || !dcond || n <= 0) return CVAR_EINVAL;
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3((unsigned)min((int64_t)2048, (n + 255) / 256)), dim3(256), 0, as_stream(stream), cond, dsilu, dcond, (long)n);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// ---- optimizer ----------------------------------------------------------------------------------------------------
+// torch.optim.AdamW step on one tensor: g' = g * gscale (all-reduce mean and clip folded in), p *= 1 - lr*wd,
+// m = b1 m + (1-b1) g', v = b2 v + (1-b2) g'^2, p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                             float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* __restrict__ gscale_dev, float gscale) {
+    const float gs = gscale * (gscale_dev ? gscale_dev[0] : 1.0f);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gr = g[i] * gs;
+        float pv = p[i] * (1.0f - lr * wd);
+        const float mv = b1 * m[i] + (1.0f - b1) * gr;
+        const float vv = b2 * v[i] + (1.0f - b2) * gr * gr;
+        pv -= (lr / bc1) * mv / (sqrtf(vv) / bc2_sqrt + eps);
+        p[i] = pv; m[i] = mv; v[i] = vv;
+    }
+}
+extern "C" int cvar_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int step, const float* gscale_dev, float gscale, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return CVAR_EINVAL;
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)min((int64_t)4096, (n + 255) / 256)), dim3(256), 0, as_stream(stream), p, g, m, v, (long)n, lr, beta1,
+                       beta2, eps, weight_decay, bc1, bc2s, gscale_dev, gscale);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// sum of squares of one tensor into 256 double partials at out[slot*256 ...] (fixed order)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, double* __restrict__ out) {
+    __shared__ double red[4];
+    double a = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { const double v = x[i]; a += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+extern "C" int cvar_sumsq(const float* x, int64_t n, double* partial256, void* stream) {
+    if (!x || !partial256 || n <= 0) return CVAR_EINVAL;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(256), dim3(256), 0, as_stream(stream), x, (long)n, partial256);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+// total = sum(partials[0..count)); norm = pre_scale * sqrt(total) (pre_scale = 1/world after a SUM all-reduce); clip_coef = min(1, max_norm / (norm + 1e-6))  (clip_grad_norm_)
+__global__ void clip_coef_kernel(const double* __restrict__ partials, long count, float pre_scale, float max_norm, float* __restrict__ out /*[2]: norm, coef*/) {
+    __shared__ double red[4];
+    double a = 0.0;
+    for (long i = threadIdx.x; i < count; i += 256) a += partials[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double nrm = sqrt((red[0] + red[1]) + (red[2] + red[3])) * (double)pre_scale;
+        out[0] = (float)nrm;
+        out[1] = max_norm > 0.f ? (float)fmin(1.0, (double)max_norm / (nrm + 1e-6)) : 1.0f;
+    }
+}
+extern "C" int cvar_clip_coef(const double* partials, int64_t count, float pre_scale, float max_norm, float* out2, void* stream) {
+    if (!partials || !out2 || count <= 0) return CVAR_EINVAL;
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, as_stream(stream), partials, (long)count, pre_scale, max_norm, out2);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}

@@ -95,13 +95,21 @@ def silu_cast(x: torch.Tensor, out: torch.Tensor):
 
 
 def attention(qkv: torch.Tensor, out: torch.Tensor, R: int, H: int, Lmax: int, q_off: int, l: int, scale: float,
-              lvl_end: Optional[Sequence[int]] = None, qkv_off: int = 0, rowwise: bool = False):
+              lvl_end: Optional[Sequence[int]] = None, qkv_off: int = 0, rowwise: bool = False, lse: Optional[torch.Tensor] = None):
     n = len(lvl_end) if lvl_end else 0
     arr = (C.c_int * max(n, 1))(*(lvl_end or [0]))
     fn = _lib.load().cvar_attention_rowwise if rowwise else _lib.load().cvar_attention
     check(fn(_ptr(qkv) + qkv_off * qkv.element_size(), dt(qkv), R, H, Lmax, q_off, l, scale,
-                                     arr, n, _ptr(out), _stream()), 'cvar_attention')
+                                     arr, n, _ptr(out), _ptr(lse), _stream()), 'cvar_attention')
     return out
+
+
+def attention_bwd(qkv, o, dout, lse, dqkv, ws, R, H, Lmax, l, scale, lvl_end=None, qkv_off: int = 0):
+    n = len(lvl_end) if lvl_end else 0
+    arr = (C.c_int * max(n, 1))(*(lvl_end or [0]))
+    check(_lib.load().cvar_attention_bwd(_ptr(qkv) + qkv_off * qkv.element_size(), dt(qkv), _ptr(o), _ptr(dout), _ptr(lse), R, H, Lmax, 0, l, scale,
+                                         arr, n, _ptr(dqkv), _ptr(ws), _stream()), 'cvar_attention_bwd')
+    return dqkv
 
 
 def cos_qk_norm(qkv: torch.Tensor, R: int, H: int, Lmax: int, q_off: int, l: int, scale_mul: torch.Tensor,
@@ -161,8 +169,8 @@ def softmax_rows(s, p, rows, cols):
     return p
 
 
-def transpose(inp, out, B, n, c, ld_in, in_off: int = 0):
-    check(_lib.load().cvar_transpose(_ptr(inp) + in_off * inp.element_size(), _ptr(out), dt(inp), B, n, c, ld_in, _stream()), 'cvar_transpose')
+def transpose(inp, out, B, n, c, ld_in, in_off: int = 0, ld_out: int = 0):
+    check(_lib.load().cvar_transpose(_ptr(inp) + in_off * inp.element_size(), _ptr(out), dt(inp), B, n, c, ld_in, ld_out or n, _stream()), 'cvar_transpose')
     return out
 
 
@@ -174,3 +182,57 @@ def nchw_to_nhwc(inp, out, B, Cdim, HW, Cpad):
 def nhwc_to_nchw(inp, ld_in, out, B, Cdim, HW, lo=-3.0e38, hi=3.0e38, mul=1.0, add=0.0):
     check(_lib.load().cvar_nhwc_to_nchw(_ptr(inp), dt(inp), ld_in, _ptr(out), B, Cdim, HW, lo, hi, mul, add, _stream()), 'cvar_nhwc_to_nchw')
     return out
+
+
+# ------------------------------------------------------------------------------------------ training step
+def gate_residual(x, f, gate, gate_off, ldg, gate_rows, rowscale, M, Cdim):
+    check(_lib.load().cvar_gate_residual(_ptr(x), _ptr(f), dt(f), _ptr(gate) + 4 * gate_off, ldg, gate_rows, _ptr(rowscale), M, Cdim, _stream()), 'cvar_gate_residual')
+
+
+def gated_grad(dx, f, gate, gate_off, ldg, rowscale, df, dgate, dgate_off, ldo, R, l, Cdim, ws):
+    check(_lib.load().cvar_gated_grad(_ptr(dx), _ptr(f), dt(f), _ptr(gate) + 4 * gate_off, ldg, _ptr(rowscale), _ptr(df), _ptr(dgate) + 4 * dgate_off, ldo,
+                                      R, l, Cdim, _ptr(ws), _stream()), 'cvar_gated_grad')
+
+
+def gelu(a, h):
+    check(_lib.load().cvar_gelu(_ptr(a), _ptr(h), dt(a), a.numel(), _stream()), 'cvar_gelu')
+    return h
+
+
+def gelu_bwd(a, dh):
+    check(_lib.load().cvar_gelu_bwd(_ptr(a), _ptr(dh), dt(a), a.numel(), _stream()), 'cvar_gelu_bwd')
+    return dh
+
+
+def ln_modulate_bwd(x, dy, ada, scale_off, ld_ada, rows_per, dx_in, dx_out, dada, dscale_off, dshift_off, ldo, M, Cdim, eps, ws):
+    check(_lib.load().cvar_ln_modulate_bwd(_ptr(x), _ptr(dy), dt(dy), _ptr(ada) + 4 * scale_off, ld_ada, rows_per, _ptr(dx_in), _ptr(dx_out),
+                                           _ptr(dada) + 4 * dscale_off, _ptr(dada) + 4 * dshift_off, ldo, M, Cdim, eps, _ptr(ws), _stream()), 'cvar_ln_modulate_bwd')
+
+
+def colsum(A, lda, out, M, N, ws, accumulate=False, a_off: int = 0, out_off: int = 0):
+    check(_lib.load().cvar_colsum(_ptr(A) + a_off * A.element_size(), dt(A), lda, _ptr(out) + 4 * out_off, M, N, int(accumulate), _ptr(ws), _stream()), 'cvar_colsum')
+
+
+def ce_fwd_bwd(logits, target, weight, gscale, loss_tok, dlogits, M, V):
+    check(_lib.load().cvar_ce_fwd_bwd(_ptr(logits), _ptr(target), _ptr(weight), float(gscale), _ptr(loss_tok), _ptr(dlogits),
+                                      dt(dlogits) if dlogits is not None else CVAR_F32, M, V, _stream()), 'cvar_ce_fwd_bwd')
+
+
+def scatter_add_rows(src, ld_src, idx, dst, n, Cdim, src_off: int = 0):
+    check(_lib.load().cvar_scatter_add_rows(_ptr(src) + 4 * src_off, ld_src, _ptr(idx), _ptr(dst), n, Cdim, _stream()), 'cvar_scatter_add_rows')
+
+
+def silu_bwd(cond, dsilu, dcond):
+    check(_lib.load().cvar_silu_bwd(_ptr(cond), _ptr(dsilu), _ptr(dcond), cond.numel(), _stream()), 'cvar_silu_bwd')
+
+
+def adamw(p, g, m, v, lr, b1, b2, eps, wd, step, gscale_dev=None, gscale=1.0):
+    check(_lib.load().cvar_adamw(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), lr, b1, b2, eps, wd, step, _ptr(gscale_dev), gscale, _stream()), 'cvar_adamw')
+
+
+def sumsq(x, partial, slot):
+    check(_lib.load().cvar_sumsq(_ptr(x), x.numel(), _ptr(partial) + 8 * 256 * slot, _stream()), 'cvar_sumsq')
+
+
+def clip_coef(partial, count, pre_scale, max_norm, out2):
+    check(_lib.load().cvar_clip_coef(_ptr(partial), count, pre_scale, max_norm, _ptr(out2), _stream()), 'cvar_clip_coef')

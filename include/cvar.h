@@ -80,11 +80,16 @@ int cvar_silu_cast(const float* x, void* out, int out_dtype, int64_t n, void* st
  * n_lvl cumulative scale ends and a query at position p sees keys < lvl_end[level(p)] - the block-causal
  * attn_bias_for_masking of training (control_var.py:158-168).  out: [R*l][H*64] of `dtype`. */
 int cvar_attention(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
-                   const int* lvl_end_host, int n_lvl, void* out, void* stream);
+                   const int* lvl_end_host, int n_lvl, void* out, float* lse /* optional [R][H][l], saved for backward */,
+                   void* stream);
 /* same contract, always the exact row-per-lane fp32-math kernel (the parity-mode implementation; also the in-library
  * reference the bf16 MFMA flash kernel is A/B-tested against). */
 int cvar_attention_rowwise(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
-                           const int* lvl_end_host, int n_lvl, void* out, void* stream);
+                           const int* lvl_end_host, int n_lvl, void* out, float* lse, void* stream);
+/* backward of the level-masked attention (training forward, control_var.py:626-639 under autograd): given dO and the saved
+ * lse, writes dQ | dK | dV into dqkv with the arena layout [R][Lmax][3*H*64].  ws: R*H*l floats.  q_off must be 0. */
+int cvar_attention_bwd(const void* qkv, int dtype, const void* o, const void* dout, const float* lse, int R, int H, int Lmax,
+                       int q_off, int l, float scale, const int* lvl_end_host, int n_lvl, void* dqkv, float* ws, void* stream);
 
 /* cos-attention pre-pass (basic_var.py:99-104), in place on rows [q_off, q_off+l) of the arena:
  * q = normalize(q) * exp(min(scale_mul[h], log 100)),  k = normalize(k). */
@@ -145,12 +150,46 @@ int cvar_groupnorm_silu(const void* x, int dtype, const float* weight, const flo
 /* row softmax of fp32 scores -> dtype probabilities (AttnBlock, vae_modules.py:84). */
 int cvar_softmax_rows(const float* s, void* p, int out_dtype, int rows, int cols, void* stream);
 /* [B][n][c] -> [B][c][n] transpose of `dtype` (V operand of AttnBlock's second bmm, vae_modules.py:87-89). */
-int cvar_transpose(const void* in, void* out, int dtype, int B, int n, int c, int64_t ld_in, void* stream);
+int cvar_transpose(const void* in, void* out, int dtype, int B, int n, int c, int64_t ld_in, int64_t ld_out /* >= n */, void* stream);
 /* NCHW fp32 -> NHWC dtype with channel padding to Cpad (zero filled). */
 int cvar_nchw_to_nhwc(const float* in, void* out, int dtype, int B, int C, int HW, int Cpad, void* stream);
 /* NHWC (ld = ldc) -> NCHW fp32 with y = clamp(x, lo, hi) * mul + add  (vqvae.py:89; control_var.py:563-564). */
 int cvar_nhwc_to_nchw(const void* in, int dtype, int64_t ld_in, float* out, int B, int C, int HW,
                       float lo, float hi, float mul, float add, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Training step (train_control_var_hpu.py:207-250 under autograd; SURVEY.md 8a A5 backward / A20).  The backward
+ * GEMMs reuse cvar_gemm on transposed operands; these are the remaining pieces.  All reductions have a fixed order.
+ * x[m,:] += gate[m / gate_rows,:] * rowscale[m / gate_rows] * f[m,:]   (x + drop_path(gamma * f), basic_var.py:208-209) */
+int cvar_gate_residual(float* x, const void* f, int dtype, const float* gate, int64_t ldg, int gate_rows,
+                       const float* rowscale, int64_t M, int C, void* stream);
+/* df = dx * gate * rowscale;  dgate[r,:] = rowscale[r] * sum_{m in r} dx[m,:] * f[m,:].  ws: 8*R*C floats. */
+int cvar_gated_grad(const float* dx, const void* f, int dtype, const float* gate, int64_t ldg, const float* rowscale,
+                    void* df, float* dgate, int64_t ldo, int R, int l, int C, float* ws, void* stream);
+int cvar_gelu(const void* a, void* h, int dtype, int64_t n, void* stream);            /* h = gelu_tanh(a) */
+int cvar_gelu_bwd(const void* a, void* dh, int dtype, int64_t n, void* stream);       /* dh *= gelu_tanh'(a) */
+/* backward of cvar_ln_modulate: dx_out = dx_in + dLN(dy * (1+scale)); dscale[r,:] = sum dy*xhat; dshift[r,:] = sum dy.
+ * ws: (2*M + 16*R*C) floats. */
+int cvar_ln_modulate_bwd(const float* x, const void* dy, int dtype, const float* scale, int64_t ld_ada, int rows_per,
+                         const float* dx_in, float* dx_out, float* dscale, float* dshift, int64_t ldo,
+                         int M, int C, float eps, float* ws, void* stream);
+/* out[n] (+)= sum_m A[m,n]  (bias gradients).  ws: 64*N floats. */
+int cvar_colsum(const void* A, int dtype, int64_t lda, float* out, int64_t M, int N, int accumulate, float* ws, void* stream);
+/* token cross-entropy (CrossEntropyLoss(reduction='none'), train_control_var_hpu.py:135,231) fused with its gradient:
+ * loss_tok[m] = logsumexp(logits[m,:]) - logits[m,target[m]];  dlogits = (softmax - onehot) * weight[m] * gscale (optional). */
+int cvar_ce_fwd_bwd(const float* logits, const int32_t* target, const float* weight, float gscale, float* loss_tok,
+                    void* dlogits, int out_dtype, int64_t M, int V, void* stream);
+/* dst[idx[i],:] += src[i,:] in row order (nn.Embedding gradients of class_emb / cond_embed). */
+int cvar_scatter_add_rows(const float* src, int64_t ld_src, const int32_t* idx, float* dst, int n, int C, void* stream);
+int cvar_silu_bwd(const float* cond, const float* dsilu, float* dcond, int64_t n, void* stream);
+/* torch.optim.AdamW step of one tensor (train_control_var_hpu.py:631-633); gradient scaled by gscale * gscale_dev[0]
+ * (all-reduce mean and clip_grad_norm_ coefficient folded in). */
+int cvar_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+               float weight_decay, int step, const float* gscale_dev, float gscale, void* stream);
+/* gradient norm (clip_grad_norm_, train_control_var_hpu.py:244-245): 256 double partial sums per tensor, then
+ * out2 = {pre_scale * sqrt(sum), min(1, max_norm / (norm + 1e-6))}. */
+int cvar_sumsq(const float* x, int64_t n, double* partial256, void* stream);
+int cvar_clip_coef(const double* partials, int64_t count, float pre_scale, float max_norm, float* out2, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,183 @@
+"""Training-side kernels on MI355X against torch autograd (CPU fp32) of the same ops."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from controlvar_amd import ops  # noqa: E402
+from controlvar_amd.spec import Pyramid  # noqa: E402
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def dev(t, dtype, d):
+    return t.to(dtype).to(d).contiguous()
+
+
+def close(got, ref, dtype, f32_tol=1e-4, bf16_rel=2e-2):
+    got, ref = got.float().cpu(), ref.float()
+    tol = f32_tol if dtype == F32 else bf16_rel
+    return bool(((got - ref).abs() <= tol * (ref.abs() + 1)).all())
+
+
+@pytest.mark.parametrize('dtype', [F32, BF16])
+def test_gate_residual_and_gated_grad(gpu_device, dtype):
+    R, l, C = 3, 50, 192
+    x, f = rnd(R * l, C, seed=1), rnd(R * l, C, seed=2)
+    ada = rnd(R, 4 * C, seed=3)
+    rs = torch.tensor([1.0, 0.0, 1.25])
+    fd = dev(f, dtype, gpu_device)
+    xd = x.to(gpu_device).clone()
+    ops.gate_residual(xd, fd, ada.to(gpu_device), C, 4 * C, l, rs.to(gpu_device), R * l, C)
+    g = (ada[:, C:2 * C] * rs[:, None]).repeat_interleave(l, 0)
+    ff = fd.float().cpu()
+    assert close(xd, x + g * ff, F32, 1e-5)
+    dx = rnd(R * l, C, seed=4)
+    df = torch.empty(R * l, C, device=gpu_device, dtype=dtype)
+    dgate = torch.zeros(R, 3 * C, device=gpu_device)
+    ws = torch.empty(8 * R * C, device=gpu_device)
+    ops.gated_grad(dx.to(gpu_device), fd, ada.to(gpu_device), C, 4 * C, rs.to(gpu_device), df, dgate, 2 * C, 3 * C, R, l, C, ws)
+    assert close(df, dx * g, dtype)
+    ref = (dx * ff).view(R, l, C).sum(1) * rs[:, None]
+    assert close(dgate[:, 2 * C:], ref, F32, 1e-4) and dgate[:, :2 * C].abs().max() == 0
+
+
+@pytest.mark.parametrize('dtype', [F32, BF16])
+def test_gelu_fwd_bwd(gpu_device, dtype):
+    a = rnd(1000, 33, seed=1, scale=2.0)
+    ad = dev(a, dtype, gpu_device)
+    h = torch.empty_like(ad)
+    ops.gelu(ad, h)
+    ar = ad.float().cpu().requires_grad_(True)
+    ref = F.gelu(ar, approximate='tanh')
+    assert close(h, ref.detach(), dtype, 1e-5)
+    dh = rnd(1000, 33, seed=2)
+    dhd = dev(dh, dtype, gpu_device)
+    ref.backward(dhd.float().cpu())
+    ops.gelu_bwd(ad, dhd)
+    assert close(dhd, ar.grad, dtype, 1e-5)
+
+
+@pytest.mark.parametrize('dtype', [F32, BF16])
+@pytest.mark.parametrize('C', [128, 1536])
+def test_ln_modulate_bwd(gpu_device, dtype, C):
+    R, l = 2, 37
+    M = R * l
+    x = (rnd(M, C, seed=1, scale=1.7) + 0.3).requires_grad_(True)
+    ada = rnd(R, 6 * C, seed=2, scale=0.4)
+    sc = ada[:, 2 * C:3 * C].clone().requires_grad_(True)
+    sh = ada[:, 4 * C:5 * C].clone().requires_grad_(True)
+    y = F.layer_norm(x, (C,), eps=1e-6) * (1 + sc.repeat_interleave(l, 0)) + sh.repeat_interleave(l, 0)
+    dy = rnd(M, C, seed=3)
+    dyd = dev(dy, dtype, gpu_device)
+    y.backward(dyd.float().cpu())
+    dx_in = rnd(M, C, seed=4)
+    dx_out = torch.empty(M, C, device=gpu_device)
+    dada = torch.zeros(R, 6 * C, device=gpu_device)
+    ws = torch.empty(2 * M + 16 * R * C, device=gpu_device)
+    ops.ln_modulate_bwd(x.detach().to(gpu_device), dyd, ada.to(gpu_device), 2 * C, 6 * C, l, dx_in.to(gpu_device), dx_out, dada, 3 * C, 5 * C, 6 * C, M, C, 1e-6, ws)
+    assert close(dx_out, dx_in + x.grad, F32, 2e-4)
+    assert close(dada[:, 3 * C:4 * C], sc.grad, F32, 2e-4) and close(dada[:, 5 * C:], sh.grad, F32, 2e-4)
+
+
+@pytest.mark.parametrize('dtype', [F32, BF16])
+def test_colsum_and_transpose_padded(gpu_device, dtype):
+    M, N = 1000, 200
+    A = rnd(M, 3 * N, seed=1)
+    Ad = dev(A, dtype, gpu_device)
+    out = torch.ones(N, device=gpu_device)
+    ws = torch.empty(64 * N, device=gpu_device)
+    ops.colsum(Ad, 3 * N, out, M, N, ws, accumulate=True, a_off=N)
+    assert close(out, 1 + Ad.float().cpu()[:, N:2 * N].sum(0), F32, 1e-4)
+    Mp = 1008
+    T_ = torch.zeros(N, Mp, device=gpu_device, dtype=dtype)
+    ops.transpose(Ad, T_, 1, M, N, 3 * N, in_off=N, ld_out=Mp)
+    assert torch.equal(T_[:, :M].float().cpu(), Ad.float().cpu()[:, N:2 * N].t()) and T_[:, M:].abs().max() == 0
+
+
+@pytest.mark.parametrize('out_dtype', [F32, BF16])
+def test_ce_fwd_bwd(gpu_device, out_dtype):
+    M, V = 300, 4096
+    logits = rnd(M, V, seed=1, scale=3.0).requires_grad_(True)
+    tgt = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(2))
+    w = torch.rand(M, generator=torch.Generator().manual_seed(3))
+    lt = F.cross_entropy(logits, tgt, reduction='none')
+    scale = 1.0 / (M * (w.mean().item() + 1e-6))
+    (lt * w).sum().mul(scale).backward()
+    loss_tok = torch.empty(M, device=gpu_device)
+    dl = torch.empty(M, V, device=gpu_device, dtype=out_dtype)
+    ops.ce_fwd_bwd(logits.detach().to(gpu_device), tgt.int().to(gpu_device), w.to(gpu_device), scale, loss_tok, dl, M, V)
+    assert close(loss_tok, lt.detach(), F32, 1e-5)
+    assert (dl.float().cpu() - logits.grad).abs().max() < (1e-8 if out_dtype == F32 else 2e-2 * logits.grad.abs().max().item())
+
+
+@pytest.mark.parametrize('dtype', [F32, BF16])
+def test_attention_lse_and_backward(gpu_device, dtype):
+    """level-masked attention over the full ControlVAR pyramid: forward lse + dQ/dK/dV vs autograd of the masked softmax"""
+    py = Pyramid()
+    R, H, c, L = 1, 2, 64, py.L
+    C3 = 3 * H * c
+    qkv = rnd(R, L, C3, seed=5, scale=1.2)
+    qd = dev(qkv, dtype, gpu_device)
+    scale = 0.125
+    lvl_end = list(py.end)
+    out = torch.empty(R * L, H * c, device=gpu_device, dtype=dtype)
+    lse = torch.empty(R, H, L, device=gpu_device)
+    ops.attention(qd, out, R, H, L, 0, L, scale, lvl_end, lse=lse)
+    x = qd.float().cpu().view(R, L, 3, H, c).requires_grad_(True)
+    q, k, v = x[:, :, 0].permute(0, 2, 1, 3), x[:, :, 1].permute(0, 2, 1, 3), x[:, :, 2].permute(0, 2, 1, 3)
+    lvl = torch.from_numpy(py.level_of_token())
+    bias = torch.where(lvl.view(-1, 1) >= lvl.view(1, -1), 0., -torch.inf)
+    s = q @ k.transpose(-1, -2) * scale + bias
+    o_ref = (s.softmax(-1) @ v).permute(0, 2, 1, 3).reshape(R * L, H * c)
+    assert close(out, o_ref.detach(), dtype, 2e-5)
+    assert close(lse, torch.logsumexp(s, dim=-1).detach(), F32, 1e-4 if dtype == F32 else 2e-2)
+    do = rnd(R * L, H * c, seed=6)
+    dod = dev(do, dtype, gpu_device)
+    o_ref.backward(dod.float().cpu())
+    dqkv = torch.zeros(R, L, C3, device=gpu_device, dtype=dtype)
+    ws = torch.empty(R * H * L, device=gpu_device)
+    # the backward consumes the forward's own (possibly bf16-rounded) output
+    ops.attention_bwd(qd, out, dod, lse, dqkv, ws, R, H, L, L, scale, lvl_end)
+    ref = x.grad.view(R, L, C3)
+    err = (dqkv.float().cpu() - ref).abs().max().item()
+    assert err < (2e-4 if dtype == F32 else 3e-2) * max(1.0, ref.abs().max().item()), err
+
+
+def test_adamw_sumsq_clip_scatter_silu(gpu_device):
+    from oracle.train_ref import adamw_update
+    n = 10007
+    p, g = rnd(n, seed=1), rnd(n, seed=2)
+    m0, v0 = rnd(n, seed=3) * 0.1, rnd(n, seed=4).abs() * 0.01
+    pd, md, vd = p.to(gpu_device).clone(), m0.to(gpu_device).clone(), v0.to(gpu_device).clone()
+    gs = torch.tensor([0.5], device=gpu_device)
+    ops.adamw(pd, g.to(gpu_device), md, vd, 3e-3, 0.9, 0.95, 1e-8, 0.05, 7, gs, 0.25)
+    pr, mr, vr = adamw_update(p, g * 0.125, m0, v0, 7, 3e-3, 0.05)
+    assert close(pd, pr, F32, 1e-6) and close(md, mr, F32, 1e-6) and close(vd, vr, F32, 1e-6)
+    part = torch.zeros(2 * 256, device=gpu_device, dtype=torch.float64)
+    ops.sumsq(g.to(gpu_device), part, 0)
+    ops.sumsq(p.to(gpu_device), part, 1)
+    out2 = torch.empty(2, device=gpu_device)
+    ops.clip_coef(part, 512, 0.5, 2.0, out2)
+    nrm = 0.5 * math.sqrt((g.double() ** 2).sum() + (p.double() ** 2).sum())
+    assert abs(out2[0].item() - nrm) < 1e-4 * nrm and abs(out2[1].item() - min(1.0, 2.0 / (nrm + 1e-6))) < 1e-6
+    src = rnd(5, 64, seed=5)
+    idx = torch.tensor([3, 1, 3, 0, 3], dtype=torch.int32)
+    dst = torch.zeros(6, 64, device=gpu_device)
+    ops.scatter_add_rows(src.to(gpu_device), 64, idx.to(gpu_device), dst, 5, 64)
+    assert close(dst, torch.zeros(6, 64).index_add_(0, idx.long(), src), F32, 1e-6)
+    cond = rnd(4, 64, seed=6).requires_grad_(True)
+    ds = rnd(4, 64, seed=7)
+    F.silu(cond).backward(ds)
+    dc = torch.empty(4, 64, device=gpu_device)
+    ops.silu_bwd(cond.detach().to(gpu_device), ds.to(gpu_device), dc)
+    assert close(dc, cond.grad, F32, 1e-5)
