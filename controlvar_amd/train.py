@@ -86,3 +86,312 @@ def filter_params(model, nowd_keys: Iterable[str] = NOWD_KEYS):
         gname = 'D' if decays(name, p.ndim, nowd_keys) else 'ND'
         groups.setdefault(gname, {'params': [], 'wd_sc': 1.0 if gname == 'D' else 0.0, 'lr_sc': 1.0})['params'].append(p)
     return names, paras, list(groups.values())
+
+
+# =====================================================================================
+# Training engine (GPU): forward with saved activations, hand-written backward, fused optimizer
+# =====================================================================================
+import torch  # noqa: E402
+
+from . import ops  # noqa: E402
+from ._lib import ACT_NONE  # noqa: E402
+
+
+def _pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+class TrainEngine:
+    """Teacher-forced forward + backward of ControlVAR / VAR over the HIP kernels (control_var.py:568-651 under autograd).
+
+    Activations of every block are kept in HBM (288 GB: no recomputation).  Weight gradients are produced by the same
+    MFMA GEMM as the forward on transposed operands (activations are transposed into zero-padded [N][Mpad] buffers),
+    accumulated in fp32 into per-layer contiguous slabs so that each layer's slab can be all-reduced as soon as its
+    backward is done (bucket = layer, overlapped with the rest of the backward on a side stream).
+    """
+
+    def __init__(self, var, drop_path: bool = True, reducer=None):
+        self.var = var
+        self.cfg = var.cfg
+        if self.cfg.uses_cos_attn:
+            raise NotImplementedError('cos-attention (depth 30) backward is not built yet')
+        self.drop_path = drop_path
+        self.reducer = reducer
+        self._B = None
+
+    # ---------------------------------------------------------------- buffers
+    def _setup(self, B: int):
+        if self._B == B:
+            return
+        cfg, var = self.cfg, self.var
+        dev, T = var.device, var.compute_dtype
+        C, depth, V = cfg.C, cfg.depth, cfg.vocab
+        L = cfg.pyramid.L
+        M = B * L
+        hid = round(C * cfg.mlp_ratio)
+        n_ada = depth * 6 * C + 2 * C
+        self.M, self.Mp, self.Bp = M, _pad8(M), _pad8(B)
+        f32 = dict(device=dev, dtype=torch.float32)
+        tT = dict(device=dev, dtype=T)
+        # saved activations
+        self.Xs = torch.empty(depth + 1, M, C, **f32)
+        self.X1s = torch.empty(depth, M, C, **f32)
+        self.U = torch.empty(depth, M, C, **tT); self.O = torch.empty(depth, M, C, **tT)
+        self.F1 = torch.empty(depth, M, C, **tT); self.U2 = torch.empty(depth, M, C, **tT); self.F2 = torch.empty(depth, M, C, **tT)
+        self.A = torch.empty(depth, M, hid, **tT); self.Hh = torch.empty(depth, M, hid, **tT)
+        self.arena = torch.empty(depth, B, L, 3 * C, **tT)
+        self.LSE = torch.empty(depth, B, cfg.H, L, **f32)
+        self.UH = torch.empty(M, C, **tT)
+        self.logits = torch.empty(M, V, **f32)
+        self.loss_tok = torch.empty(M, **f32)
+        # backward work buffers
+        self.dlogits = torch.empty(M, V, **tT)
+        self.dX = torch.empty(M, C, **f32)
+        self.DF = torch.empty(M, C, **tT); self.DU = torch.empty(M, C, **tT)
+        self.DH = torch.empty(M, hid, **tT)
+        self.DQKV = torch.empty(B, L, 3 * C, **tT)
+        nmax = max(hid, 3 * C, V)
+        self.TA = torch.zeros(nmax * self.Mp, **tT)           # zero padding columns stay zero
+        self.TB = torch.zeros(nmax * self.Mp, **tT)
+        self.TA32 = torch.zeros(C * _pad8(B * (L - cfg.pyramid.first_l)), **f32)
+        self.TB32 = torch.zeros(cfg.cvae * _pad8(B * (L - cfg.pyramid.first_l)), **f32)
+        self.dada = torch.zeros(B, n_ada, **f32)
+        self.ws = torch.empty(max(2 * M + 16 * B * C, 64 * max(hid, 3 * C, V, n_ada), L * C, B * cfg.H * L) + 16, **f32)
+        # gradient slabs: [layer][w_qkv | w_proj | w_fc1 | w_fc2 | b_qkv | b_proj | b_fc1 | b_fc2]
+        self.slab_off = {}
+        o = 0
+        for name, n in (('w_qkv', 3 * C * C), ('w_proj', C * C), ('w_fc1', hid * C), ('w_fc2', C * hid), ('b_qkv', 3 * C), ('b_proj', C),
+                        ('b_fc1', hid), ('b_fc2', C)):
+            self.slab_off[name] = o
+            o += n
+        self.slab = o
+        self.G_layers = torch.zeros(depth, self.slab, **f32)
+        self.G_ada = torch.zeros(n_ada * C + n_ada, **f32)                       # [w_ada | b_ada]
+        misc = [('w_head', V * C), ('b_head', V), ('w_we', C * cfg.cvae), ('b_we', C), ('pos', L * C), ('lvl', len(cfg.patch_nums) * C),
+                ('pos_start', cfg.pyramid.first_l * C), ('class_emb', (cfg.num_classes + 1) * C), ('cond_embed', 5 * C)]
+        self.misc_off = {}
+        o = 0
+        for name, n in misc:
+            self.misc_off[name] = (o, n)
+            o += n
+        self.G_misc = torch.zeros(o, **f32)
+        self.buckets = [self.G_layers[i] for i in range(depth)] + [self.G_ada, self.G_misc]
+        self._B = B
+        self._transposed_weights()
+
+    def _transposed_weights(self):
+        """W^T copies for the data-gradient GEMMs (refreshed after every optimizer step)."""
+        P, cfg = self.var._pack(), self.cfg
+        C, depth, V = cfg.C, cfg.depth, cfg.vocab
+        hid = P['w_fc1'].shape[1]
+        T = self.var.compute_dtype
+        dev = self.var.device
+        mk = lambda *s: torch.empty(*s, device=dev, dtype=T)
+        self.WT = dict(qkv=mk(depth, C, 3 * C), proj=mk(depth, C, C), fc1=mk(depth, C, hid), fc2=mk(depth, hid, C), head=mk(C, V), ada=mk(C, P['n_ada']))
+        ops.transpose(P['w_qkv'], self.WT['qkv'], depth, 3 * C, C, C)
+        ops.transpose(P['w_proj'], self.WT['proj'], depth, C, C, C)
+        ops.transpose(P['w_fc1'], self.WT['fc1'], depth, hid, C, C)
+        ops.transpose(P['w_fc2'], self.WT['fc2'], depth, C, hid, hid)
+        ops.transpose(P['w_head'], self.WT['head'], 1, V, C, C)
+        ops.transpose(P['w_ada'], self.WT['ada'], 1, P['n_ada'], C, C)
+
+    def grads(self) -> Dict[str, torch.Tensor]:
+        """state_dict key -> gradient view (fp32)"""
+        cfg = self.cfg
+        C, depth, V = cfg.C, cfg.depth, cfg.vocab
+        hid = round(C * cfg.mlp_ratio)
+        so = self.slab_off
+        g: Dict[str, torch.Tensor] = {}
+        for i in range(depth):
+            s = self.G_layers[i]
+            p = f'blocks.{i}.'
+            g[p + 'attn.mat_qkv.weight'] = s[so['w_qkv']:so['w_qkv'] + 3 * C * C].view(3 * C, C)
+            g[p + 'attn.proj.weight'] = s[so['w_proj']:so['w_proj'] + C * C].view(C, C)
+            g[p + 'ffn.fc1.weight'] = s[so['w_fc1']:so['w_fc1'] + hid * C].view(hid, C)
+            g[p + 'ffn.fc2.weight'] = s[so['w_fc2']:so['w_fc2'] + C * hid].view(C, hid)
+            g[p + 'attn.q_bias'] = s[so['b_qkv']:so['b_qkv'] + C]
+            g[p + 'attn.v_bias'] = s[so['b_qkv'] + 2 * C:so['b_qkv'] + 3 * C]
+            g[p + 'attn.proj.bias'] = s[so['b_proj']:so['b_proj'] + C]
+            g[p + 'ffn.fc1.bias'] = s[so['b_fc1']:so['b_fc1'] + hid]
+            g[p + 'ffn.fc2.bias'] = s[so['b_fc2']:so['b_fc2'] + C]
+            n_ada = depth * 6 * C + 2 * C
+            g[p + 'ada_lin.1.weight'] = self.G_ada[:n_ada * C].view(n_ada, C)[i * 6 * C:(i + 1) * 6 * C]
+            g[p + 'ada_lin.1.bias'] = self.G_ada[n_ada * C:][i * 6 * C:(i + 1) * 6 * C]
+        n_ada = depth * 6 * C + 2 * C
+        g['head_nm.ada_lin.1.weight'] = self.G_ada[:n_ada * C].view(n_ada, C)[depth * 6 * C:]
+        g['head_nm.ada_lin.1.bias'] = self.G_ada[n_ada * C:][depth * 6 * C:]
+        mo = lambda k: self.G_misc[self.misc_off[k][0]:self.misc_off[k][0] + self.misc_off[k][1]]
+        py = cfg.pyramid
+        g['head.weight'] = mo('w_head').view(V, C); g['head.bias'] = mo('b_head')
+        g['word_embed.weight'] = mo('w_we').view(C, cfg.cvae); g['word_embed.bias'] = mo('b_we')
+        g['pos_1LC'] = mo('pos').view(1, py.L, C); g['lvl_embed.weight'] = mo('lvl').view(len(cfg.patch_nums), C)
+        g['pos_start'] = mo('pos_start').view(1, py.first_l, C)
+        g['class_emb.weight'] = mo('class_emb').view(cfg.num_classes + 1, C)
+        if cfg.mask_factor == 2:
+            g['cond_embed.weight'] = mo('cond_embed').view(5, C)
+        return g
+
+    # ---------------------------------------------------------------- forward + backward
+    @torch.no_grad()
+    def forward_backward(self, label_B: torch.Tensor, x_wo_first: torch.Tensor, cond_type: Optional[torch.Tensor], targets: torch.Tensor,
+                         ignore_mask: Optional[torch.Tensor] = None, drop_seed: Optional[int] = None):
+        """-> (loss scalar tensor, per-token loss (B*L,)); gradients land in self.grads() (overwritten, not accumulated)."""
+        cfg, var = self.cfg, self.var
+        P = var._pack()
+        py, C, depth, V, H = cfg.pyramid, cfg.C, cfg.depth, cfg.vocab, cfg.H
+        L, fl = py.L, py.first_l
+        dev, T = var.device, var.compute_dtype
+        B = x_wo_first.shape[0]
+        self._setup(B)
+        M, Mp = self.M, self.Mp
+        hid = P['w_fc1'].shape[1]
+        n_ada = P['n_ada']
+        eps = cfg.norm_eps
+        lvl_end = list(py.end)
+        scale = float(cfg.attn_scale)
+        labels = label_B.to(dev)
+        types = cond_type.to(dev) if (cond_type is not None and cfg.mask_factor == 2) else None
+        if var.training and cfg.cond_drop_rate > 0:                 # control_var.py:578,584
+            labels = torch.where(torch.rand(B, device=dev) < cfg.cond_drop_rate, cfg.num_classes, labels)
+            if types is not None:
+                types = torch.where(torch.rand(B, device=dev) < cfg.cond_drop_rate, 4, types)
+        labels = labels.to(torch.int32).contiguous()
+        types = types.to(torch.int32).contiguous() if types is not None else None
+        # DropPath row scales (helpers.py:39-46): per sample, per block, per branch
+        dp1 = dp2 = None
+        rate = 0.1 * depth / 24                                       # models/__init__.py:15,40
+        if self.drop_path and var.training and rate > 0:
+            g = torch.Generator(device=dev)
+            g.manual_seed(drop_seed if drop_seed is not None else int(torch.empty((), dtype=torch.int64).random_().item()))
+            dpr = torch.linspace(0, rate, depth, device=dev).view(depth, 1)
+            keep = 1 - dpr
+            dp1 = (torch.rand(depth, B, device=dev, generator=g) < keep).float() / keep
+            dp2 = (torch.rand(depth, B, device=dev, generator=g) < keep).float() / keep
+        # ---- forward
+        x0 = self.Xs[0]
+        cond = torch.empty(B, C, device=dev, dtype=torch.float32)
+        ops.first_tokens(P['class_emb'], P['cond_embed'], labels, types, P['pos_start'], P['lvl_pos'], x0, cond, B, fl, C, L)
+        tok = x_wo_first.to(device=dev, dtype=torch.float32).contiguous()
+        ops.word_embed(tok, P['w_we'], P['b_we'], P['lvl_pos'], x0, B, 1, L - fl, cfg.cvae, C, L, fl, lvl_off=fl)
+        cs = torch.empty(B, C, device=dev, dtype=T)
+        ops.silu_cast(cond, cs)
+        ada = torch.empty(B, n_ada, device=dev, dtype=torch.float32)
+        ops.gemm(cs, P['w_ada'], ada, M=B, N=n_ada, K=C, bias=P['b_ada'])
+        for i in range(depth):
+            a0 = i * 6 * C
+            x = self.Xs[i]
+            ops.ln_modulate(x, ada, a0 + 2 * C, a0 + 4 * C, n_ada, L, self.U[i], M, C, eps)
+            ops.gemm(self.U[i], P['w_qkv'], self.arena[i], M=M, N=3 * C, K=C, w_off=i * 3 * C * C, bias=P['b_qkv'][i])
+            ops.attention(self.arena[i], self.O[i], B, H, L, 0, L, scale, lvl_end, lse=self.LSE[i])
+            ops.gemm(self.O[i], P['w_proj'], self.F1[i], M=M, N=C, K=C, w_off=i * C * C, bias=P['b_proj'][i])
+            self.X1s[i].copy_(x)
+            ops.gate_residual(self.X1s[i], self.F1[i], ada, a0, n_ada, L, dp1[i].contiguous() if dp1 is not None else None, M, C)
+            ops.ln_modulate(self.X1s[i], ada, a0 + 3 * C, a0 + 5 * C, n_ada, L, self.U2[i], M, C, eps)
+            ops.gemm(self.U2[i], P['w_fc1'], self.A[i], M=M, N=hid, K=C, w_off=i * hid * C, bias=P['b_fc1'][i])
+            ops.gelu(self.A[i], self.Hh[i])
+            ops.gemm(self.Hh[i], P['w_fc2'], self.F2[i], M=M, N=C, K=hid, w_off=i * C * hid, bias=P['b_fc2'][i])
+            self.Xs[i + 1].copy_(self.X1s[i])
+            ops.gate_residual(self.Xs[i + 1], self.F2[i], ada, a0 + C, n_ada, L, dp2[i].contiguous() if dp2 is not None else None, M, C)
+        ah = depth * 6 * C
+        ops.ln_modulate(self.Xs[depth], ada, ah, ah + C, n_ada, L, self.UH, M, C, eps)
+        ops.gemm(self.UH, P['w_head'], self.logits, M=M, N=V, K=C, bias=P['b_head'])
+        tg = targets.to(device=dev, dtype=torch.int32).contiguous().view(-1)
+        if ignore_mask is not None:                                  # train_control_var_hpu.py:233-237
+            w = ignore_mask.to(device=dev, dtype=torch.float32).contiguous().view(-1)
+            gscale = 1.0 / (M * (float(w.mean()) + 1e-6))
+        else:
+            w, gscale = None, 1.0 / M
+        ops.ce_fwd_bwd(self.logits, tg, w, gscale, self.loss_tok, self.dlogits, M, V)
+        loss = (self.loss_tok * w).mean() / (w.mean() + 1e-6) if w is not None else self.loss_tok.mean()
+        # ---- backward: head
+        TA, TB, ws = self.TA, self.TB, self.ws
+        so = self.slab_off
+        mo = self.misc_off
+        self.dada.zero_()
+        ops.gemm(self.dlogits, self.WT['head'], self.DU, M=M, N=C, K=V)
+        ops.transpose(self.dlogits, TA, 1, M, V, V, ld_out=Mp)
+        ops.transpose(self.UH, TB, 1, M, C, C, ld_out=Mp)
+        ops.gemm(TA, TB, self.G_misc, M=V, N=C, K=Mp, c_off=mo['w_head'][0])
+        ops.colsum(self.dlogits, V, self.G_misc, M, V, ws, out_off=mo['b_head'][0])
+        ops.ln_modulate_bwd(self.Xs[depth], self.DU, ada, ah, n_ada, L, None, self.dX, self.dada, ah, ah + C, n_ada, M, C, eps, ws)
+        # ---- backward: blocks
+        for i in reversed(range(depth)):
+            a0 = i * 6 * C
+            G = self.G_layers
+            go = i * self.slab
+            # FFN branch
+            ops.gated_grad(self.dX, self.F2[i], ada, a0 + C, n_ada, dp2[i].contiguous() if dp2 is not None else None, self.DF, self.dada, a0 + C, n_ada, B, L, C, ws)
+            ops.gemm(self.DF, self.WT['fc2'], self.DH, M=M, N=hid, K=C, w_off=i * hid * C)
+            ops.transpose(self.DF, TA, 1, M, C, C, ld_out=Mp)
+            ops.transpose(self.Hh[i], TB, 1, M, hid, hid, ld_out=Mp)
+            ops.gemm(TA, TB, G, M=C, N=hid, K=Mp, c_off=go + so['w_fc2'])
+            ops.colsum(self.DF, C, G, M, C, ws, out_off=go + so['b_fc2'])
+            ops.gelu_bwd(self.A[i], self.DH)
+            ops.gemm(self.DH, self.WT['fc1'], self.DU, M=M, N=C, K=hid, w_off=i * C * hid)
+            ops.transpose(self.DH, TA, 1, M, hid, hid, ld_out=Mp)
+            ops.transpose(self.U2[i], TB, 1, M, C, C, ld_out=Mp)
+            ops.gemm(TA, TB, G, M=hid, N=C, K=Mp, c_off=go + so['w_fc1'])
+            ops.colsum(self.DH, hid, G, M, hid, ws, out_off=go + so['b_fc1'])
+            ops.ln_modulate_bwd(self.X1s[i], self.DU, ada, a0 + 3 * C, n_ada, L, self.dX, self.dX, self.dada, a0 + 3 * C, a0 + 5 * C, n_ada, M, C, eps, ws)
+            # attention branch
+            ops.gated_grad(self.dX, self.F1[i], ada, a0, n_ada, dp1[i].contiguous() if dp1 is not None else None, self.DF, self.dada, a0, n_ada, B, L, C, ws)
+            ops.gemm(self.DF, self.WT['proj'], self.DU, M=M, N=C, K=C, w_off=i * C * C)
+            ops.transpose(self.DF, TA, 1, M, C, C, ld_out=Mp)
+            ops.transpose(self.O[i], TB, 1, M, C, C, ld_out=Mp)
+            ops.gemm(TA, TB, G, M=C, N=C, K=Mp, c_off=go + so['w_proj'])
+            ops.colsum(self.DF, C, G, M, C, ws, out_off=go + so['b_proj'])
+            ops.attention_bwd(self.arena[i], self.O[i], self.DU, self.LSE[i], self.DQKV, ws, B, H, L, L, scale, lvl_end)
+            ops.gemm(self.DQKV, self.WT['qkv'], self.DU, M=M, N=C, K=3 * C, w_off=i * C * 3 * C)
+            ops.transpose(self.DQKV, TA, 1, M, 3 * C, 3 * C, ld_out=Mp)
+            ops.transpose(self.U[i], TB, 1, M, C, C, ld_out=Mp)
+            ops.gemm(TA, TB, G, M=3 * C, N=C, K=Mp, c_off=go + so['w_qkv'])
+            ops.colsum(self.DQKV, 3 * C, G, M, 3 * C, ws, out_off=go + so['b_qkv'])      # the k-bias third is unused (zero_k_bias is a buffer)
+            ops.ln_modulate_bwd(self.Xs[i], self.DU, ada, a0 + 2 * C, n_ada, L, self.dX, self.dX, self.dada, a0 + 2 * C, a0 + 4 * C, n_ada, M, C, eps, ws)
+            if self.reducer is not None:
+                self.reducer.ready(i)
+        # ---- backward: adaLN parameter generator (one GEMM for all blocks + head)
+        Bp = self.Bp
+        dada_T = self.dada.to(T)
+        dsilu = torch.empty(B, C, device=dev, dtype=torch.float32)
+        ops.gemm(dada_T, self.WT['ada'], dsilu, M=B, N=C, K=n_ada)
+        tA = torch.zeros(n_ada, Bp, device=dev, dtype=T)
+        tB = torch.zeros(C, Bp, device=dev, dtype=T)
+        ops.transpose(dada_T, tA, 1, B, n_ada, n_ada, ld_out=Bp)
+        ops.transpose(cs, tB, 1, B, C, C, ld_out=Bp)
+        ops.gemm(tA, tB, self.G_ada, M=n_ada, N=C, K=Bp)
+        ops.colsum(self.dada, n_ada, self.G_ada, B, n_ada, ws, out_off=n_ada * C)
+        dcond = torch.empty(B, C, device=dev, dtype=torch.float32)
+        ops.silu_bwd(cond, dsilu, dcond)
+        if self.reducer is not None:
+            self.reducer.ready(depth)
+        # ---- backward: embeddings (dX now holds d loss / d x0)
+        Gm = self.G_misc
+        ops.colsum(self.dX, L * C, Gm, B, L * C, ws, out_off=mo['pos'][0])
+        for k, (b0, e0) in enumerate(zip(py.begin, py.end)):
+            ops.colsum(Gm, C, Gm, e0 - b0, C, ws, a_off=mo['pos'][0] + b0 * C, out_off=mo['lvl'][0] + k * C)
+        Gm[mo['pos_start'][0]:mo['pos_start'][0] + fl * C].copy_(Gm[mo['pos'][0]:mo['pos'][0] + fl * C])
+        Mt = B * (L - fl)
+        Mtp = _pad8(Mt)
+        self._word_embed_grads(tok, B, L, fl, C, Mt, Mtp)
+        cls_o, cnd_o = mo['class_emb'][0], mo['cond_embed'][0]
+        Gm[cls_o:cls_o + mo['class_emb'][1]].zero_()
+        Gm[cnd_o:cnd_o + mo['cond_embed'][1]].zero_()
+        g_class = Gm[cls_o:cls_o + mo['class_emb'][1]]
+        ops.scatter_add_rows(self.dX, L * C, labels, g_class, B, C, src_off=(fl - 1) * C)     # sos row (position first_l-1 holds the class token)
+        ops.scatter_add_rows(dcond, C, labels, g_class, B, C)
+        if cfg.mask_factor == 2:
+            ops.scatter_add_rows(self.dX, L * C, types, Gm[cnd_o:cnd_o + mo['cond_embed'][1]], B, C, src_off=0)
+        if self.reducer is not None:
+            self.reducer.ready(depth + 1)
+        return loss, self.loss_tok
+
+    def _word_embed_grads(self, tok, B, L, fl, C, Mt, Mtp):
+        cfg = self.cfg
+        mo = self.misc_off
+        Gm = self.G_misc
+        for b in range(B):      # dX rows of sample b -> columns [b*(L-fl), (b+1)*(L-fl)) of TA32 ([C][Mtp])
+            ops.transpose(self.dX, self.TA32[b * (L - fl):], 1, L - fl, C, C, in_off=(b * L + fl) * C, ld_out=Mtp)
+        ops.transpose(tok, self.TB32, 1, Mt, cfg.cvae, cfg.cvae, ld_out=Mtp)
+        ops.gemm(self.TA32, self.TB32, Gm, M=C, N=cfg.cvae, K=Mtp, c_off=mo['w_we'][0])
+        for b in range(B):
+            ops.colsum(self.dX, C, Gm, L - fl, C, self.ws, accumulate=(b > 0), a_off=(b * L + fl) * C, out_off=mo['b_we'][0])
