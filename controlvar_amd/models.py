@@ -612,10 +612,20 @@ class ControlVAR(nn.Module):
         f_hat = self._generate(B, label_B, g_seed, tuple(cfg), top_k, top_p, more_smooth, cond_type, True, c_mask, c_img, _force_idx, _trace)
         return self._decode_pair(f_hat)
 
-    @torch.no_grad()
     def forward(self, label_B: torch.LongTensor, x_BLCv_wo_first_l: torch.Tensor, cond_type=None, mask_first=True) -> torch.Tensor:
-        """control_var.py:568-651 teacher-forced logits (B, L, V) fp32.  Inference-only this round: label /
-        cond-type dropout follows ``self.training`` (torch.rand, as the reference), DropPath and autograd are not built."""
+        """control_var.py:568-651 teacher-forced logits (B, L, V) fp32.  Under autograd (grad mode on and trainable
+        parameters) the call is differentiable - `loss.backward()` runs the hand-written backward kernels
+        (controlvar_amd/train.py); otherwise it is the inference-only fast path.  Label / cond-type dropout follows
+        ``self.training`` (torch.rand, as the reference)."""
+        if torch.is_grad_enabled() and not self.cfg.uses_cos_attn and any(p.requires_grad for p in self.parameters()):
+            from .train import teacher_forced_with_grad
+            if not mask_first:
+                raise NotImplementedError('mask_first=False only occurs with bidirectional=True')
+            return teacher_forced_with_grad(self, label_B, x_BLCv_wo_first_l, cond_type)
+        with torch.no_grad():
+            return self._forward_nograd(label_B, x_BLCv_wo_first_l, cond_type, mask_first)
+
+    def _forward_nograd(self, label_B, x_BLCv_wo_first_l, cond_type=None, mask_first=True):
         cfg, P = self.cfg, self._pack()
         py, C = cfg.pyramid, cfg.C
         dev = self.device
@@ -668,7 +678,6 @@ class VAR(ControlVAR):
     def conditional_infer_cfg(self, *a, **k):
         raise NotImplementedError('plain VAR has no conditional_infer_cfg (var.py)')
 
-    @torch.no_grad()
     def forward(self, label_B, x_BLCv_wo_first_l, cond_type=None, mask_first=True):
         return super().forward(label_B, x_BLCv_wo_first_l, None, True)
 

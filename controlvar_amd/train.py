@@ -236,6 +236,23 @@ class TrainEngine:
     def forward_backward(self, label_B: torch.Tensor, x_wo_first: torch.Tensor, cond_type: Optional[torch.Tensor], targets: torch.Tensor,
                          ignore_mask: Optional[torch.Tensor] = None, drop_seed: Optional[int] = None):
         """-> (loss scalar tensor, per-token loss (B*L,)); gradients land in self.grads() (overwritten, not accumulated)."""
+        self.forward_train(label_B, x_wo_first, cond_type, drop_seed)
+        dev = self.var.device
+        M, V = self.M, self.cfg.vocab
+        tg = targets.to(device=dev, dtype=torch.int32).contiguous().view(-1)
+        if ignore_mask is not None:                                  # train_control_var_hpu.py:233-237
+            w = ignore_mask.to(device=dev, dtype=torch.float32).contiguous().view(-1)
+            gscale = 1.0 / (M * (float(w.mean()) + 1e-6))
+        else:
+            w, gscale = None, 1.0 / M
+        ops.ce_fwd_bwd(self.logits, tg, w, gscale, self.loss_tok, self.dlogits, M, V)
+        loss = (self.loss_tok * w).mean() / (w.mean() + 1e-6) if w is not None else self.loss_tok.mean()
+        self.backward()
+        return loss, self.loss_tok
+
+    @torch.no_grad()
+    def forward_train(self, label_B: torch.Tensor, x_wo_first: torch.Tensor, cond_type: Optional[torch.Tensor], drop_seed: Optional[int] = None):
+        """teacher-forced forward that keeps every block's activations; returns logits (B*L, V) fp32"""
         cfg, var = self.cfg, self.var
         P = var._pack()
         py, C, depth, V, H = cfg.pyramid, cfg.C, cfg.depth, cfg.vocab, cfg.H
@@ -295,14 +312,26 @@ class TrainEngine:
         ah = depth * 6 * C
         ops.ln_modulate(self.Xs[depth], ada, ah, ah + C, n_ada, L, self.UH, M, C, eps)
         ops.gemm(self.UH, P['w_head'], self.logits, M=M, N=V, K=C, bias=P['b_head'])
-        tg = targets.to(device=dev, dtype=torch.int32).contiguous().view(-1)
-        if ignore_mask is not None:                                  # train_control_var_hpu.py:233-237
-            w = ignore_mask.to(device=dev, dtype=torch.float32).contiguous().view(-1)
-            gscale = 1.0 / (M * (float(w.mean()) + 1e-6))
-        else:
-            w, gscale = None, 1.0 / M
-        ops.ce_fwd_bwd(self.logits, tg, w, gscale, self.loss_tok, self.dlogits, M, V)
-        loss = (self.loss_tok * w).mean() / (w.mean() + 1e-6) if w is not None else self.loss_tok.mean()
+        self._saved = dict(ada=ada, cs=cs, cond=cond, labels=labels, types=types, tok=tok, dp1=dp1, dp2=dp2, B=B)
+        return self.logits
+
+    @torch.no_grad()
+    def backward(self):
+        """backward from self.dlogits (compute dtype, (B*L, V)) through head, blocks, adaLN generator and embeddings"""
+        cfg, var = self.cfg, self.var
+        P = var._pack()
+        py, C, depth, V, H = cfg.pyramid, cfg.C, cfg.depth, cfg.vocab, cfg.H
+        L, fl = py.L, py.first_l
+        dev, T = var.device, var.compute_dtype
+        sv = self._saved
+        ada, cs, cond, labels, types, tok, dp1, dp2, B = (sv[k] for k in ('ada', 'cs', 'cond', 'labels', 'types', 'tok', 'dp1', 'dp2', 'B'))
+        M, Mp = self.M, self.Mp
+        hid = P['w_fc1'].shape[1]
+        n_ada = P['n_ada']
+        eps = cfg.norm_eps
+        lvl_end = list(py.end)
+        scale = float(cfg.attn_scale)
+        ah = depth * 6 * C
         # ---- backward: head
         TA, TB, ws = self.TA, self.TB, self.ws
         so = self.slab_off
@@ -383,7 +412,6 @@ class TrainEngine:
             ops.scatter_add_rows(self.dX, L * C, types, Gm[cnd_o:cnd_o + mo['cond_embed'][1]], B, C, src_off=0)
         if self.reducer is not None:
             self.reducer.ready(depth + 1)
-        return loss, self.loss_tok
 
     def _word_embed_grads(self, tok, B, L, fl, C, Mt, Mtp):
         cfg = self.cfg
@@ -395,3 +423,156 @@ class TrainEngine:
         ops.gemm(self.TA32, self.TB32, Gm, M=C, N=cfg.cvae, K=Mtp, c_off=mo['w_we'][0])
         for b in range(B):
             ops.colsum(self.dX, C, Gm, L - fl, C, self.ws, accumulate=(b > 0), a_off=(b * L + fl) * C, out_off=mo['b_we'][0])
+
+
+class BucketReducer:
+    """Gradient all-reduce of the data-parallel step (replaces DDP's bucketed all-reduce, train_control_var_hpu.py:604, and
+    dist.py:100-116): one SUM all-reduce per bucket (bucket = one transformer layer's gradient slab, then the adaLN
+    generator, then head + embeddings), launched on a side stream the moment the backward has finished that bucket, so that
+    RCCL traffic over xGMI overlaps the remaining backward.  The 1/world mean is folded into the optimizer's gradient scale."""
+
+    def __init__(self, buckets: Sequence[torch.Tensor], group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.buckets = list(buckets)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.cuda = len(self.buckets) > 0 and self.buckets[0].is_cuda
+        self.stream = torch.cuda.Stream() if (self.cuda and self.world > 1) else None
+        self.handles: List = []
+        self.launched: List[int] = []
+
+    def ready(self, idx: int):
+        self.launched.append(idx)
+        if self.world == 1:
+            return
+        b = self.buckets[idx]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.stream):
+                self.stream.wait_event(ev)
+                self.handles.append(self.dist.all_reduce(b, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.handles.append(self.dist.all_reduce(b, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.handles.clear()
+        done, self.launched = self.launched, []
+        return done
+
+
+class FusedAdamW:
+    """torch.optim.AdamW(betas=(0.9, 0.95)) over the model's parameters (train_control_var_hpu.py:631-633) with the
+    decay / no-decay groups of filter_params, gradient-norm clipping (:244-245) and the all-reduce mean folded into one
+    fused kernel per tensor.  `param_groups` is torch-shaped so that lr_wd_annealing() drives it unchanged."""
+
+    def __init__(self, var, lr: float, betas=(0.9, 0.95), eps: float = 1e-8, weight_decay: float = 0.0, nowd_keys=NOWD_KEYS):
+        self.var = var
+        self.betas, self.eps = betas, eps
+        self.named = [(n, p) for n, p in var.named_parameters()]
+        self.state = {n: (torch.zeros_like(p.data), torch.zeros_like(p.data)) for n, p in self.named}
+        d_names = [n for n, p in self.named if decays(n, p.ndim, nowd_keys)]
+        nd_names = [n for n, p in self.named if not decays(n, p.ndim, nowd_keys)]
+        self.param_groups = [dict(names=d_names, lr=lr, weight_decay=weight_decay, wd_sc=1.0, lr_sc=1.0),
+                             dict(names=nd_names, lr=lr, weight_decay=0.0, wd_sc=0.0, lr_sc=1.0)]
+        self.steps = 0
+        self._partial = None
+        self._out2 = None
+
+    @torch.no_grad()
+    def step(self, grads: Dict[str, torch.Tensor], max_norm: float = 0.0, world: int = 1) -> torch.Tensor:
+        """returns a device tensor [grad_norm (of the world-averaged gradient), clip coefficient]"""
+        dev = self.named[0][1].device
+        n = len(self.named)
+        if self._partial is None:
+            self._partial = torch.zeros(n * 256, device=dev, dtype=torch.float64)
+            self._out2 = torch.ones(2, device=dev, dtype=torch.float32)
+        for slot, (name, _) in enumerate(self.named):
+            ops.sumsq(grads[name], self._partial, slot)
+        ops.clip_coef(self._partial, n * 256, 1.0 / world, float(max_norm), self._out2)
+        self.steps += 1
+        coef = self._out2[1:]
+        params = dict(self.named)
+        for g in self.param_groups:
+            for name in g['names']:
+                m, v = self.state[name]
+                ops.adamw(params[name].data, grads[name], m, v, float(g['lr']), self.betas[0], self.betas[1], self.eps, float(g['weight_decay']),
+                          self.steps, coef, 1.0 / world)
+        self.var._packed = None                                  # GEMM-ready copies are refreshed lazily
+        return self._out2
+
+
+class Trainer:
+    """One process per GPU; the step of train_control_var_hpu.py:130-255 (minus its logging / gradient-accumulation quirks)."""
+
+    def __init__(self, var, vae, peak_lr: float, weight_decay: float, weight_decay_end: Optional[float] = None, sche: str = 'lin0',
+                 warmup_it: float = 0, max_it: int = 1000, clip: float = 2.0, wp0: float = 0.005, wpe: float = 0.01, drop_path: bool = True):
+        import torch.distributed as dist
+        self.var, self.vae = var, vae
+        self.engine = TrainEngine(var, drop_path=drop_path)
+        self.opt = FusedAdamW(var, lr=peak_lr, weight_decay=weight_decay)
+        self.sched = dict(sche=sche, peak_lr=peak_lr, wd=weight_decay, wd_end=weight_decay if weight_decay_end is None else weight_decay_end,
+                          wp_it=warmup_it, max_it=max_it, wp0=wp0, wpe=wpe)
+        self.clip = clip
+        self.it = 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self._reducer_for = None
+
+    @torch.no_grad()
+    def tokenize(self, images: torch.Tensor, masks: torch.Tensor):
+        """frozen tokenizer + 'interleave_append' (mask first): train_control_var_hpu.py:157-204"""
+        mi = self.vae.img_to_idxBl(masks); mh = self.vae.idxBl_to_h(mi)
+        ii = self.vae.img_to_idxBl(images); ih = self.vae.idxBl_to_h(ii)
+        labels = torch.cat([torch.cat((a, b), 1) for a, b in zip(mi, ii)], dim=1)
+        x = torch.cat([torch.cat((a, b), 1) for a, b in zip(mh, ih)], dim=1)
+        return x, labels
+
+    @torch.no_grad()
+    def step(self, images, masks, cls, types, ignore_mask=None, drop_seed=None) -> Dict[str, object]:
+        s = self.sched
+        lr_wd_annealing(s['sche'], self.opt, s['peak_lr'], s['wd'], s['wd_end'], self.it, s['wp_it'], s['max_it'], wp0=s['wp0'], wpe=s['wpe'])
+        x, labels = self.tokenize(images, masks)
+        self.engine._setup(x.shape[0])
+        if self.world > 1 and self._reducer_for is not self.engine.buckets:
+            self.engine.reducer = BucketReducer(self.engine.buckets)
+            self._reducer_for = self.engine.buckets
+        loss, _ = self.engine.forward_backward(cls, x, types, labels, ignore_mask, drop_seed)
+        if self.engine.reducer is not None:
+            self.engine.reducer.wait()
+        norm_coef = self.opt.step(self.engine.grads(), self.clip, self.world)
+        self.engine._transposed_weights()
+        self.it += 1
+        return dict(loss=loss, grad_norm=norm_coef[0], clip_coef=norm_coef[1], lr=self.opt.param_groups[0]['lr'], wd=self.opt.param_groups[0]['weight_decay'])
+
+
+class _TeacherForcedFn(torch.autograd.Function):
+    """Autograd bridge so that the reference's own training code (`logits = var(...)`; `loss.backward()`,
+    train_control_var_hpu.py:207-241) works unchanged: forward keeps the activations inside the engine, backward runs the
+    hand-written kernels and hands one gradient per parameter back to autograd."""
+
+    @staticmethod
+    def forward(ctx, engine, label_B, x, cond_type, *params):
+        logits = engine.forward_train(label_B, x, cond_type)
+        ctx.engine = engine
+        B = x.shape[0]
+        return logits.view(B, -1, logits.shape[-1]).clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        eng = ctx.engine
+        eng.dlogits.copy_(dlogits.reshape(eng.M, -1))
+        eng.backward()
+        g = eng.grads()
+        return (None, None, None, None) + tuple(g[n].clone() for n, _ in eng.var.named_parameters())
+
+
+def teacher_forced_with_grad(var, label_B, x, cond_type):
+    eng = getattr(var, '_train_engine', None)
+    if eng is None:
+        eng = var._train_engine = TrainEngine(var, drop_path=True)
+    return _TeacherForcedFn.apply(eng, label_B, x, cond_type, *[p for _, p in var.named_parameters()])
