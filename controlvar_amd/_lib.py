@@ -48,6 +48,7 @@ SIGNATURES = {
     'cvar_attention': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, c_p, c_p, c_p]),
     'cvar_attention_rowwise': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, c_p, c_p, c_p]),
     'cvar_attention_bwd': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, c_p, c_p, c_p]),
+    'cvar_attention_bwd_rowwise': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, c_p, c_p, c_p]),
     'cvar_cos_qk_norm': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     'cvar_cfg_sample': (c_i, [c_p, c_i, c_i, c_i, c_i, C.POINTER(c_f), c_i, c_f, C.c_uint64, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
     'cvar_ms_next_input': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -493,9 +493,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
     }
 }
 
-// ws: R*H*l floats (D = rowsum(dO * O))
-extern "C" int cvar_attention_bwd(const void* qkv, int dtype, const void* o, const void* dout, const float* lse, int R, int H, int Lmax,
-                                  int q_off, int l, float scale, const int* lvl_end_host, int n_lvl, void* dqkv, float* ws, void* stream) {
+__global__ void attn_bwd_dq_mfma_kernel(const AttnBwdParams p);
+__global__ void attn_bwd_dkv_mfma_kernel(const AttnBwdParams p);
+
+// ws: R*H*l floats (D = rowsum(dO * O)).  impl: 0 = auto (MFMA kernels for bf16, row-wise exact kernels for fp32), 1 = row-wise
+static int cvar_attention_bwd_impl(const void* qkv, int dtype, const void* o, const void* dout, const float* lse, int R, int H, int Lmax,
+                                   int q_off, int l, float scale, const int* lvl_end_host, int n_lvl, void* dqkv, float* ws, void* stream, int impl) {
     if (!qkv || !o || !dout || !lse || !dqkv || !ws || R <= 0 || H <= 0 || l <= 0 || q_off != 0 || l > Lmax) return CVAR_EINVAL;
     if (n_lvl < 0 || n_lvl > 16 || (n_lvl > 0 && !lvl_end_host)) return CVAR_EINVAL;
     AttnBwdParams p;
@@ -506,8 +509,13 @@ extern "C" int cvar_attention_bwd(const void* qkv, int dtype, const void* o, con
     hipStream_t st = as_stream(stream);
     if (dtype == CVAR_BF16) {
         hipLaunchKernelGGL(attn_bwd_prep_kernel<bf16_t>, dim3(cdiv(tot, 256)), dim3(256), 0, st, p);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, dim3(cdiv(l, 256), H, R), dim3(256), 0, st, p);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, dim3(cdiv(l, 256), H, R), dim3(256), 0, st, p);
+        if (impl == 0) {
+            hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3(cdiv(l, 128), H, R), dim3(256), 0, st, p);
+            hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3(cdiv(l, 128), H, R), dim3(256), 0, st, p);
+        } else {
+            hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, dim3(cdiv(l, 256), H, R), dim3(256), 0, st, p);
+            hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, dim3(cdiv(l, 256), H, R), dim3(256), 0, st, p);
+        }
     } else if (dtype == CVAR_F32) {
         hipLaunchKernelGGL(attn_bwd_prep_kernel<float>, dim3(cdiv(tot, 256)), dim3(256), 0, st, p);
         hipLaunchKernelGGL(attn_bwd_dq_kernel<float>, dim3(cdiv(l, 256), H, R), dim3(256), 0, st, p);
@@ -515,4 +523,264 @@ extern "C" int cvar_attention_bwd(const void* qkv, int dtype, const void* o, con
     } else return CVAR_EUNSUPPORTED;
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;
+}
+
+// ================================================================================================
+// bf16 MFMA backward of the level-masked attention (training).  Two kernels, no atomics:
+//   attn_bwd_dq_mfma  : 4 waves x 32 queries, loops over 64-key tiles:  S^T = K Q^T, dP^T = V dO^T (same operand roles as
+//                       the forward), dS = P (dP - D), dQ^T += K^T dS^T   (K^T staged transposed like V^T in the forward)
+//   attn_bwd_dkv_mfma : 4 waves x 32 keys (K, V fragments in registers), loops over 64-query tiles: S = Q K^T, dP = dO V^T
+//                       (lane = key), P / dS packed to bf16 in the B-operand layout, dV^T += dO^T P, dK^T += Q^T dS with
+//                       Q^T / dO^T staged transposed.
+// P is recomputed from the saved log-sum-exp; fp32 accumulation everywhere.
+// ================================================================================================
+constexpr int BW_T_STRIDE = 68;
+
+// row-major 64 x 64 bf16 tile -> LDS rows of 128 B, chunk index XOR-swizzled by (row>>1)&7
+__device__ __forceinline__ void bw_stage_rowmajor(char* dst, const bf16_t* src, long row_stride, int row0, int row_limit, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 3) + 32 * i, chunk = tid & 7;
+        bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bf16x8_t v = (row0 + row) < row_limit ? *(const bf16x8_t*)(src + (long)(row0 + row) * row_stride + chunk * 8) : z;
+        *(bf16x8_t*)(dst + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = v;
+    }
+}
+// 64 rows x 64 cols -> transposed LDS image T[col][row] with rows of BW_T_STRIDE elements (two rows packed per 32-bit write)
+__device__ __forceinline__ void bw_stage_transposed(bf16_t* dst, const bf16_t* src, long row_stride, int row0, int row_limit, int tid) {
+    const int w = tid >> 6, lane = tid & 63;
+    const int kp = 16 * (w >> 1) + (lane & 15), chunk = 4 * (w & 1) + (lane >> 4);
+    bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int r0 = row0 + 2 * kp;
+    const bf16x8_t a = r0 < row_limit ? *(const bf16x8_t*)(src + (long)r0 * row_stride + chunk * 8) : z;
+    const bf16x8_t b = (r0 + 1) < row_limit ? *(const bf16x8_t*)(src + (long)(r0 + 1) * row_stride + chunk * 8) : z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const unsigned packed = (unsigned)(unsigned short)a[e] | ((unsigned)(unsigned short)b[e] << 16);
+        *(unsigned*)(dst + (chunk * 8 + e) * BW_T_STRIDE + 2 * kp) = packed;
+    }
+}
+__device__ __forceinline__ bf16x8_t bw_read_tfrag(const bf16_t* T, int row, int col0) {     // 4 + 4 elements at col0 and col0 + 8
+    const bf16_t* p = T + row * BW_T_STRIDE + col0;
+    const bf16x4_t v0 = *(const bf16x4_t*)p;
+    const bf16x4_t v1 = *(const bf16x4_t*)(p + 8);
+    const bf16x8_t f = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    return f;
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdParams p) {
+    constexpr int D = 64, KT = 64;
+    __shared__ __attribute__((aligned(16))) char Ks[KT * 128];
+    __shared__ __attribute__((aligned(16))) char Vs[KT * 128];
+    __shared__ __attribute__((aligned(16))) bf16_t Kt[D * BW_T_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lrow = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
+    const int h = blockIdx.y;
+    const long r = blockIdx.z;
+    const int C3 = 3 * p.H * D;
+    const bf16_t* base = (const bf16_t*)p.qkv + r * (long)p.Lmax * C3;
+    const bf16_t* kbase = base + p.H * D + h * D;
+    const bf16_t* vbase = kbase + p.H * D;
+    const int q0 = blockIdx.x * 128 + w * 32;
+    const int qi = q0 + lrow;
+    const int qrow = min(qi, p.l - 1);
+    const int kvlen = kv_len_of_b(p, p.q_off + qrow);
+    const int wave_min_kv = kv_len_of_b(p, p.q_off + min(q0, p.l - 1));
+    const int kv_end = kv_len_of_b(p, p.q_off + min(p.l, (int)(blockIdx.x + 1) * 128) - 1);
+    bf16x8_t qf[4], of[4];
+    {
+        const bf16_t* qp = base + (long)(p.q_off + qrow) * C3 + h * D;
+        const bf16_t* dp = (const bf16_t*)p.dout + (r * p.l + qrow) * (long)(p.H * D) + h * D;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { qf[ks] = *(const bf16x8_t*)(qp + (2 * ks + hi) * 8); of[ks] = *(const bf16x8_t*)(dp + (2 * ks + hi) * 8); }
+    }
+    const float c2 = p.scale * 1.4426950408889634f;
+    const float lse2 = p.lse[(r * p.H + h) * (long)p.l + qrow] * 1.4426950408889634f;
+    const float Dq = p.dsum[(r * p.H + h) * (long)p.l + qrow];
+    f32x16_t dq[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
+
+    for (int kt0 = 0; kt0 < kv_end; kt0 += KT) {
+        bw_stage_rowmajor(Ks, kbase, C3, kt0, kv_end, tid);
+        bw_stage_rowmajor(Vs, vbase, C3, kt0, kv_end, tid);
+        bw_stage_transposed(Kt, kbase, C3, kt0, kv_end, tid);
+        __syncthreads();
+        f32x16_t s[2], dp[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[kb][i] = 0.f; dp[kb][i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = (32 * kb + lrow) * 128 + (((2 * ks + hi) ^ sw) << 4);
+                const bf16x8_t kf = *(const bf16x8_t*)(Ks + off);
+                const bf16x8_t vf = *(const bf16x8_t*)(Vs + off);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+                dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, of[ks], dp[kb], 0, 0, 0);
+            }
+        }
+        const bool need_mask = kt0 + KT > wave_min_kv;
+        bf16x8_t dsf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float ds[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = 8 * t + j;
+                    float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], c2, -lse2));
+                    if (need_mask) {
+                        const int key = kt0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hi;
+                        if (key >= kvlen) pr = 0.f;
+                    }
+                    ds[j] = pr * (dp[kb][i] - Dq);
+                }
+                dsf[kb][t] = pack_bf16x8(ds);
+            }
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw_read_tfrag(Kt, 32 * db + lrow, 32 * kb + 16 * t + 4 * hi), dsf[kb][t], dq[db], 0, 0, 0);
+        __syncthreads();
+    }
+    if (qi < p.l) {
+        bf16_t* op = (bf16_t*)p.dqkv + (r * p.Lmax + p.q_off + qi) * (long)C3 + h * D;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float ov[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = dq[db][4 * g + e] * p.scale;
+                *(bf16x4_t*)(op + 32 * db + 8 * g + 4 * hi) = pack_bf16x4(ov);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdParams p) {
+    constexpr int D = 64, QT = 64;
+    __shared__ __attribute__((aligned(16))) char Qs[QT * 128];
+    __shared__ __attribute__((aligned(16))) char Os[QT * 128];
+    __shared__ __attribute__((aligned(16))) bf16_t Qt[D * BW_T_STRIDE];
+    __shared__ __attribute__((aligned(16))) bf16_t Ot[D * BW_T_STRIDE];
+    __shared__ __attribute__((aligned(16))) float Ls[QT];
+    __shared__ __attribute__((aligned(16))) float Dsum[QT];
+    __shared__ __attribute__((aligned(16))) int Kv[QT];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lrow = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
+    const int h = blockIdx.y;
+    const long r = blockIdx.z;
+    const int C3 = 3 * p.H * D;
+    const bf16_t* base = (const bf16_t*)p.qkv + r * (long)p.Lmax * C3;
+    const bf16_t* qbase = base + (long)p.q_off * C3 + h * D;
+    const bf16_t* obase = (const bf16_t*)p.dout + r * (long)p.l * (p.H * D) + h * D;
+    const int nkeys = p.q_off + p.l;
+    const int kj = blockIdx.x * 128 + w * 32 + lrow;                 // key position owned by this lane
+    const int krow = min(kj, nkeys - 1);
+    bf16x8_t kf[4], vf[4];
+    {
+        const bf16_t* kp = base + (long)krow * C3 + p.H * D + h * D;
+        const bf16_t* vp = kp + p.H * D;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { kf[ks] = *(const bf16x8_t*)(kp + (2 * ks + hi) * 8); vf[ks] = *(const bf16x8_t*)(vp + (2 * ks + hi) * 8); }
+    }
+    const float c2 = p.scale * 1.4426950408889634f;
+    f32x16_t dk[2], dv[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
+
+    const int q_begin = first_query_of(p, blockIdx.x * 128);            // first query that sees the block's first key
+    for (int qt0 = (q_begin / QT) * QT; qt0 < p.l; qt0 += QT) {
+        bw_stage_rowmajor(Qs, qbase, C3, qt0, p.l, tid);
+        bw_stage_rowmajor(Os, obase, (long)(p.H * D), qt0, p.l, tid);
+        bw_stage_transposed(Qt, qbase, C3, qt0, p.l, tid);
+        bw_stage_transposed(Ot, obase, (long)(p.H * D), qt0, p.l, tid);
+        if (tid < QT) {
+            const int qi = qt0 + tid;
+            const bool ok = qi < p.l;
+            Ls[tid] = ok ? p.lse[(r * p.H + h) * (long)p.l + qi] * 1.4426950408889634f : 0.f;
+            Dsum[tid] = ok ? p.dsum[(r * p.H + h) * (long)p.l + qi] : 0.f;
+            Kv[tid] = ok ? kv_len_of_b(p, p.q_off + qi) : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int off = (32 * qb + lrow) * 128 + (((2 * ks + hi) ^ sw) << 4);
+                const bf16x8_t qa = *(const bf16x8_t*)(Qs + off);
+                const bf16x8_t oa = *(const bf16x8_t*)(Os + off);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);       // S[q][key]: lane = key, regs = queries
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[ks], dp, 0, 0, 0);
+            }
+            bf16x8_t pf[2], df[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float pv[8], dsv[8];
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int g = 2 * t + g2;                                   // regs 4g..4g+3 <-> queries 32qb + 8g + 4hi + 0..3
+                    const int qloc = 32 * qb + 8 * g + 4 * hi;
+                    const f32x4_t l4 = *(const f32x4_t*)&Ls[qloc];
+                    const f32x4_t d4 = *(const f32x4_t*)&Dsum[qloc];
+                    const int4 k4 = *(const int4*)&Kv[qloc];
+                    const int kvl[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * g + e;
+                        float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c2, -l4[e]));
+                        if (krow >= kvl[e]) pr = 0.f;
+                        pv[4 * g2 + e] = pr;
+                        dsv[4 * g2 + e] = pr * (dp[i] - d4[e]);
+                    }
+                }
+                pf[t] = pack_bf16x8(pv);
+                df[t] = pack_bf16x8(dsv);
+            }
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int col0 = 32 * qb + 16 * t + 4 * hi;
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw_read_tfrag(Ot, 32 * db + lrow, col0), pf[t], dv[db], 0, 0, 0);
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw_read_tfrag(Qt, 32 * db + lrow, col0), df[t], dk[db], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    if (kj < nkeys) {
+        bf16_t* kp = (bf16_t*)p.dqkv + (r * p.Lmax + kj) * (long)C3 + p.H * D + h * D;
+        bf16_t* vp = kp + p.H * D;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float a[4], b[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] = dk[db][4 * g + e] * p.scale; b[e] = dv[db][4 * g + e]; }
+                *(bf16x4_t*)(kp + 32 * db + 8 * g + 4 * hi) = pack_bf16x4(a);
+                *(bf16x4_t*)(vp + 32 * db + 8 * g + 4 * hi) = pack_bf16x4(b);
+            }
+    }
+}
+
+extern "C" int cvar_attention_bwd_rowwise(const void* qkv, int dtype, const void* o, const void* dout, const float* lse, int R, int H, int Lmax,
+                                          int q_off, int l, float scale, const int* lvl_end_host, int n_lvl, void* dqkv, float* ws, void* stream) {
+    return cvar_attention_bwd_impl(qkv, dtype, o, dout, lse, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, dqkv, ws, stream, 1);
+}
+extern "C" int cvar_attention_bwd(const void* qkv, int dtype, const void* o, const void* dout, const float* lse, int R, int H, int Lmax,
+                                  int q_off, int l, float scale, const int* lvl_end_host, int n_lvl, void* dqkv, float* ws, void* stream) {
+    return cvar_attention_bwd_impl(qkv, dtype, o, dout, lse, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, dqkv, ws, stream, 0);
 }

@@ -104,10 +104,11 @@ def attention(qkv: torch.Tensor, out: torch.Tensor, R: int, H: int, Lmax: int, q
     return out
 
 
-def attention_bwd(qkv, o, dout, lse, dqkv, ws, R, H, Lmax, l, scale, lvl_end=None, qkv_off: int = 0):
+def attention_bwd(qkv, o, dout, lse, dqkv, ws, R, H, Lmax, l, scale, lvl_end=None, qkv_off: int = 0, rowwise: bool = False):
     n = len(lvl_end) if lvl_end else 0
     arr = (C.c_int * max(n, 1))(*(lvl_end or [0]))
-    check(_lib.load().cvar_attention_bwd(_ptr(qkv) + qkv_off * qkv.element_size(), dt(qkv), _ptr(o), _ptr(dout), _ptr(lse), R, H, Lmax, 0, l, scale,
+    fn = _lib.load().cvar_attention_bwd_rowwise if rowwise else _lib.load().cvar_attention_bwd
+    check(fn(_ptr(qkv) + qkv_off * qkv.element_size(), dt(qkv), _ptr(o), _ptr(dout), _ptr(lse), R, H, Lmax, 0, l, scale,
                                          arr, n, _ptr(dqkv), _ptr(ws), _stream()), 'cvar_attention_bwd')
     return dqkv
 

@@ -90,6 +90,9 @@ int cvar_attention_rowwise(const void* qkv, int dtype, int R, int H, int Lmax, i
  * lse, writes dQ | dK | dV into dqkv with the arena layout [R][Lmax][3*H*64].  ws: R*H*l floats.  q_off must be 0. */
 int cvar_attention_bwd(const void* qkv, int dtype, const void* o, const void* dout, const float* lse, int R, int H, int Lmax,
                        int q_off, int l, float scale, const int* lvl_end_host, int n_lvl, void* dqkv, float* ws, void* stream);
+/* same contract, always the exact row-per-lane kernels (fp32-mode implementation / A-B reference of the bf16 MFMA backward) */
+int cvar_attention_bwd_rowwise(const void* qkv, int dtype, const void* o, const void* dout, const float* lse, int R, int H, int Lmax,
+                               int q_off, int l, float scale, const int* lvl_end_host, int n_lvl, void* dqkv, float* ws, void* stream);
 
 /* cos-attention pre-pass (basic_var.py:99-104), in place on rows [q_off, q_off+l) of the arena:
  * q = normalize(q) * exp(min(scale_mul[h], log 100)),  k = normalize(k). */

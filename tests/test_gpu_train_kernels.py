@@ -151,6 +151,12 @@ def test_attention_lse_and_backward(gpu_device, dtype):
     ref = x.grad.view(R, L, C3)
     err = (dqkv.float().cpu() - ref).abs().max().item()
     assert err < (2e-4 if dtype == F32 else 3e-2) * max(1.0, ref.abs().max().item()), err
+    if dtype == BF16:       # MFMA kernels (default) against the exact row-wise kernels of the same library
+        dq_rw = torch.zeros_like(dqkv)
+        ops.attention_bwd(qd, out, dod, lse, dq_rw, ws, R, H, L, L, scale, lvl_end, rowwise=True)
+        d = (dqkv.float() - dq_rw.float()).abs().max().item()
+        assert d < 3e-2 * max(1.0, ref.abs().max().item()), d
+        assert (dq_rw.float().cpu() - ref).abs().max().item() < 3e-2 * max(1.0, ref.abs().max().item())
 
 
 def test_adamw_sumsq_clip_scatter_silu(gpu_device):
