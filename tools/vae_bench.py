@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""BASELINE config 5: VQVAE-only encode -> multi-scale quant -> decode throughput, 256^2, B images per GPU."""
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from controlvar_amd import models
+from controlvar_amd.synth import synth_images
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+dev = torch.device('cuda:0')
+vae = models.build_vae(ch=160, decode_chunk=64).to(dev)
+img = synth_images(B, 256, seed=3).to(dev)
+def step():
+    outs = []
+    for s in range(0, B, 64):
+        ids = vae.img_to_idxBl(img[s:s + 64])
+        outs.append(vae.idxBl_to_img(ids, same_shape=True, last_one=True))
+    return outs
+step(); torch.cuda.synchronize()
+t0 = time.perf_counter(); n = 3
+for _ in range(n): out = step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+print(json.dumps({'metric': 'VQVAE encode+quant+decode images/s (256^2)', 'value': round(B / dt, 1), 'batch': B, 'ms_per_pass': round(dt * 1e3, 1),
+                  'algorithmic_tflops': round(609e9 * B / dt / 1e12, 1), 'mem_GB': round(torch.cuda.max_memory_allocated() / 2**30, 1)}))
