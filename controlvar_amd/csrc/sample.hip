@@ -13,6 +13,7 @@ struct SampleParams {
     int top_k;
     float top_p;
     unsigned long long seed;
+    const unsigned long long* seed_dev;     // optional device-resident seed added to `seed` (lets a captured hipGraph draw fresh samples)
     int stage, n_draw;
     int* idx_out;
     float* combined;
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void cfg_sample_kernel(const SampleParams p) {
         if (tid == 0) p.kept[bt] = tot;
     }
     for (int d = 0; d < p.n_draw; ++d) {
-        unsigned long long h = splitmix64(p.seed ^ 0xC0FFEE1234ull);
+        unsigned long long h = splitmix64((p.seed + (p.seed_dev ? p.seed_dev[0] : 0ull)) ^ 0xC0FFEE1234ull);
         h = splitmix64(h ^ ((unsigned long long)p.stage << 48) ^ ((unsigned long long)((long)d * p.B + b) << 16) ^ (unsigned long long)t);
         const double u = (double)(h >> 11) * (1.0 / 9007199254740992.0);       // 53 bits -> [0,1)
         u64 target = (u64)(u * (double)Zk);
@@ -254,14 +255,14 @@ __global__ __launch_bounds__(256) void cfg_sample_kernel(const SampleParams p) {
 }
 
 extern "C" int cvar_cfg_sample(const float* logits, int B, int nrep, int l, int V, const float* coef_host,
-                               int top_k, float top_p, uint64_t seed, int stage, int n_draw,
+                               int top_k, float top_p, uint64_t seed, const uint64_t* seed_dev, int stage, int n_draw,
                                int32_t* idx_out, float* combined, float* margin, int32_t* kept, void* stream) {
     if (!logits || !coef_host || !idx_out || B <= 0 || l <= 0 || V <= 1) return CVAR_EINVAL;
     if (nrep < 1 || nrep > 4 || n_draw < 1 || n_draw > 4 || V > 4096) return CVAR_EUNSUPPORTED;
     SampleParams p;
     p.logits = logits; p.B = B; p.nrep = nrep; p.l = l; p.V = V;
     for (int i = 0; i < 4; ++i) p.coef[i] = i < nrep ? coef_host[i] : 0.f;
-    p.top_k = top_k; p.top_p = top_p; p.seed = seed; p.stage = stage; p.n_draw = n_draw;
+    p.top_k = top_k; p.top_p = top_p; p.seed = seed; p.seed_dev = (const unsigned long long*)seed_dev; p.stage = stage; p.n_draw = n_draw;
     p.idx_out = idx_out; p.combined = combined; p.margin = margin; p.kept = kept;
     dim3 grid((unsigned)((long)B * l)), block(256);
     if (top_k == 1) hipLaunchKernelGGL(cfg_greedy_kernel, grid, block, 0, as_stream(stream), p);

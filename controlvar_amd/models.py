@@ -528,25 +528,39 @@ class ControlVAR(nn.Module):
         return cond_type.to(device=dev, dtype=torch.int32)
 
     @torch.no_grad()
+    def _prepare_rows(self, B, label_B, cond_type, four_way, seed):
+        """labels / condition types of all CFG rows: [cond ; uncond] or the 4-branch layout (control_var.py:252-263,381-400)"""
+        cfg = self.cfg
+        labels = self._as_labels(B, label_B, seed)
+        empty = torch.full_like(labels, self.num_classes)
+        nrep = 4 if four_way else 2
+        labels_all = torch.cat([labels] + [empty] * (nrep - 1)).contiguous()
+        types_all = None
+        if cfg.mask_factor == 2:
+            types = self._as_types(B, cond_type, seed)
+            e4 = torch.full_like(types, 4)
+            types_all = (torch.cat([types, types, e4, e4]) if four_way else torch.cat([types, e4])).contiguous()
+        return labels_all, types_all
+
+    @torch.no_grad()
     def _generate(self, B, label_B, g_seed, cfg_scale, top_k, top_p, more_smooth, cond_type, four_way, c_mask, c_img,
                   force_idx=None, trace: bool = False):
         if more_smooth:
             raise NotImplementedError('more_smooth (Gumbel visualisation path) is not built (SURVEY.md 8f N4)')
+        seed = int(g_seed) if g_seed is not None else int(torch.empty((), dtype=torch.int64).random_().item())
+        labels_all, types_all = self._prepare_rows(B, label_B, cond_type, four_way, seed)
+        return self._generate_core(B, labels_all, types_all, seed, None, cfg_scale, top_k, top_p, four_way, c_mask, c_img, force_idx, trace)
+
+    @torch.no_grad()
+    def _generate_core(self, B, labels_all, types_all, seed, seed_dev, cfg_scale, top_k, top_p, four_way, c_mask=None, c_img=None,
+                       force_idx=None, trace: bool = False):
+        """the 10-scale loop on device-resident inputs only (capturable in a HIP graph: no host sync, static shapes)"""
         cfg, P = self.cfg, self._pack()
         vae: VQVAE = self.vae_proxy[0]
         py, mf, C = cfg.pyramid, cfg.mask_factor, cfg.C
         dev = self.device
-        seed = int(g_seed) if g_seed is not None else int(torch.empty((), dtype=torch.int64).random_().item())
-        labels = self._as_labels(B, label_B, seed)
-        empty = torch.full_like(labels, self.num_classes)
         nrep = 4 if four_way else 2
         R = nrep * B
-        labels_all = torch.cat([labels] + [empty] * (nrep - 1)).contiguous()
-        types_all = None
-        if mf == 2:
-            types = self._as_types(B, cond_type, seed)
-            e4 = torch.full_like(types, 4)
-            types_all = (torch.cat([types, types, e4, e4]) if four_way else torch.cat([types, e4])).contiguous()
         nb = R if four_way else B
         x = torch.empty(R * py.l[-1], C, device=dev, dtype=torch.float32)
         cond = torch.empty(R, C, device=dev, dtype=torch.float32)
@@ -571,7 +585,7 @@ class ControlVAR(nn.Module):
             idx = torch.empty(n_draw * B, l, device=dev, dtype=torch.int32)
             comb = torch.empty(B, l, cfg.vocab, device=dev, dtype=torch.float32) if trace else None
             mg = torch.empty(B, l, device=dev, dtype=torch.float32) if trace else None
-            ops.cfg_sample(logits, B, nrep, l, cfg.vocab, coef, top_k, top_p, seed, si, n_draw, idx, comb, mg)
+            ops.cfg_sample(logits, B, nrep, l, cfg.vocab, coef, top_k, top_p, seed, si, n_draw, idx, comb, mg, seed_dev=seed_dev)
             if trace:
                 tr['idx'].append(idx.clone()); tr['margin'].append(mg); tr['logits'].append(comb)
             if force_idx is not None:
@@ -589,6 +603,42 @@ class ControlVAR(nn.Module):
             tr['f_hat'] = f_hat[:B].clone()
             self.last_trace = tr
         return f_hat[:B]
+
+    @torch.no_grad()
+    def graphed_generator(self, B: int, cfg=1.5, top_k: int = 0, top_p: float = 0.0):
+        """Capture one full `autoregressive_infer_cfg` (10 scales x depth blocks + both VQVAE decodes, ~2.5k launches) in a
+        HIP graph and return ``run(label_B, cond_type=None, g_seed=None) -> images``.  Labels, condition types and the
+        sampling seed live in static device buffers that are refreshed before each replay, so every call draws new samples.
+        Removes the host launch cost that dominates small batches (the reference's loop is host-launched op by op)."""
+        dev = self.device
+        four_way = False
+        lab0 = torch.zeros(B, dtype=torch.int64)
+        ty0 = torch.zeros(B, dtype=torch.int64) if self.cfg.mask_factor == 2 else None
+        labels_all, types_all = self._prepare_rows(B, lab0, ty0, four_way, 0)
+        seed_dev = torch.zeros(1, device=dev, dtype=torch.int64)
+        self._pack(); self.vae_proxy[0]._pack()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                       # warm-up off the capture (module loads, attribute setup, arena)
+            self._decode_pair(self._generate_core(B, labels_all, types_all, 0, seed_dev, cfg, top_k, top_p, four_way))
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self._decode_pair(self._generate_core(B, labels_all, types_all, 0, seed_dev, cfg, top_k, top_p, four_way))
+
+        def run(label_B, cond_type=None, g_seed=None):
+            seed = int(g_seed) if g_seed is not None else int(torch.empty((), dtype=torch.int64).random_().item())
+            la, ta = self._prepare_rows(B, label_B, cond_type, four_way, seed)
+            labels_all.copy_(la)
+            if types_all is not None:
+                types_all.copy_(ta)
+            seed_dev.fill_(seed & (2 ** 62 - 1))
+            graph.replay()
+            return out.clone()
+
+        run.graph = graph
+        return run
 
     def _decode_pair(self, f_hat: torch.Tensor) -> torch.Tensor:
         vae: VQVAE = self.vae_proxy[0]

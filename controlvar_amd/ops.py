@@ -121,9 +121,9 @@ def cos_qk_norm(qkv: torch.Tensor, R: int, H: int, Lmax: int, q_off: int, l: int
 
 def cfg_sample(logits: torch.Tensor, B: int, nrep: int, l: int, V: int, coef: Sequence[float], top_k: int, top_p: float,
                seed: int, stage: int, n_draw: int, idx_out: torch.Tensor, combined: Optional[torch.Tensor] = None,
-               margin: Optional[torch.Tensor] = None, kept: Optional[torch.Tensor] = None):
+               margin: Optional[torch.Tensor] = None, kept: Optional[torch.Tensor] = None, seed_dev: Optional[torch.Tensor] = None):
     arr = (C.c_float * 4)(*(list(coef) + [0.0] * (4 - len(coef))))
-    check(_lib.load().cvar_cfg_sample(_ptr(logits), B, nrep, l, V, arr, top_k, float(top_p), int(seed) & (2 ** 64 - 1), stage, n_draw,
+    check(_lib.load().cvar_cfg_sample(_ptr(logits), B, nrep, l, V, arr, top_k, float(top_p), int(seed) & (2 ** 64 - 1), _ptr(seed_dev), stage, n_draw,
                                       _ptr(idx_out), _ptr(combined), _ptr(margin), _ptr(kept), _stream()), 'cvar_cfg_sample')
     return idx_out
 

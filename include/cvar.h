@@ -107,7 +107,7 @@ int cvar_cos_qk_norm(void* qkv, int dtype, int R, int H, int Lmax, int q_off, in
  * generator keyed by (seed, stage, row).  idx_out: [n_draw*B][l] int32.  Optional outputs (may be NULL):
  * combined [B][l][V] fp32, margin [B][l] fp32 (top1 - top2 of the combined logits), kept [B][l] int32. */
 int cvar_cfg_sample(const float* logits, int B, int nrep, int l, int V, const float* coef_host,
-                    int top_k, float top_p, uint64_t seed, int stage, int n_draw,
+                    int top_k, float top_p, uint64_t seed, const uint64_t* seed_dev /* optional, added to seed */, int stage, int n_draw,
                     int32_t* idx_out, float* combined, float* margin, int32_t* kept, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
