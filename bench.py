@@ -35,7 +35,7 @@ def parse():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--depth', type=int, default=24)
-    ap.add_argument('--batch', type=int, default=64, help='samples per GPU per step')
+    ap.add_argument('--batch', type=int, default=128, help='samples per GPU per step (KV arena: 0.6 GB per sample at d24 bf16)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--cfg', type=float, default=4.0)
     ap.add_argument('--top_k', type=int, default=900)      # the reference's sampling defaults (train_control_var_hpu.py:338)

@@ -43,6 +43,7 @@ SIGNATURES = {
     'cvar_abi_version': (c_i, []),
     'cvar_status_str': (C.c_char_p, [c_i]),
     'cvar_gemm': (c_i, [C.POINTER(GemmDesc), c_p]),
+    'cvar_gemm_set_workspace': (c_i, [c_p, c_l]),
     'cvar_ln_modulate': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p, c_i, c_i, c_i, c_f, c_p]),
     'cvar_silu_cast': (c_i, [c_p, c_p, c_i, c_l, c_p]),
     'cvar_attention': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, c_p, c_p, c_p]),

@@ -33,6 +33,8 @@ struct GemmParams {
     void* C; int out_dtype; long ldc;
     int remap_l, remap_L, remap_off;
     int tiles_m, tiles_n;
+    int split_tiles;          // split-K: K tiles per blockIdx.y slice (0 = no split); partials go to C + blockIdx.y * split_stride
+    long split_stride;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
         a_tap[jj] = 0; a_ci[jj] = 0;
         if (CONV) {
             a_ptr[jj] = nullptr;
-            a_tap[jj] = a_k0[jj] / p.Cin; a_ci[jj] = a_k0[jj] - a_tap[jj] * p.Cin;
+            { const int kfirst = (int)blockIdx.y * p.split_tiles * KT + a_k0[jj]; a_tap[jj] = kfirst / p.Cin; a_ci[jj] = kfirst - a_tap[jj] * p.Cin; }
             if (m < p.M) {
                 const int hw = p.Hout * p.Wout;
                 const int b = m / hw, rem = m - b * hw;
@@ -169,14 +171,16 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int lrow = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
-    const int nk = (p.K + KT - 1) / KT;
+    const int nk_all = (p.K + KT - 1) / KT;
+    const int kt_lo = p.split_tiles > 0 ? (int)blockIdx.y * p.split_tiles : 0;
+    const int nk = p.split_tiles > 0 ? min(nk_all, kt_lo + p.split_tiles) : nk_all;
 
     // Pipeline: the DMA pieces of tile kt+1 are spread over the four k-steps of tile kt and issued right behind that
     // k-step's fragment reads, so their issue cost overlaps the MFMAs already queued on the matrix pipe.
 #pragma unroll
-    for (int idx = 0; idx < NL; ++idx) issue_one(0, 0, idx);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+    for (int idx = 0; idx < NL; ++idx) issue_one(kt_lo, 0, idx);
+    for (int kt = kt_lo; kt < nk; ++kt) {
+        const int cur = (kt - kt_lo) & 1;
         const bool more = kt + 1 < nk;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -233,7 +237,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     static_assert(NW * 16 * EROW * 4 <= 2 * STAGE, "epilogue staging must fit the pipeline LDS");
     float* stg = (float*)smem + wave * (16 * EROW);
     char* Cb = (char*)p.C;
-    const long cz = zb * p.strideC, rz = zb * p.strideR;
+    const long cz = zb * p.strideC + (long)blockIdx.y * p.split_stride, rz = zb * p.strideR;
     const int erow = lane / LPR, ecol = (lane % LPR) * 8;
     const bool vec_ok = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && ((p.strideC & 7) == 0) && (((uintptr_t)p.C & 15) == 0) &&
                         (!p.residual || (((p.ldr & 7) == 0) && ((p.strideR & 7) == 0) && (((uintptr_t)p.residual & 15) == 0))) &&
@@ -324,7 +328,9 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     const size_t lds = 2 * (BM + BN) * 128;
-    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), 1, (unsigned)batch), block(WM * WN * 64);
+    const int nk_all = (p.K + (128 / (int)sizeof(T)) - 1) / (128 / (int)sizeof(T));
+    const int splits = p.split_tiles > 0 ? (nk_all + p.split_tiles - 1) / p.split_tiles : 1;
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits, (unsigned)batch), block(WM * WN * 64);
     if (p.conv) {
         auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, true>;
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -355,6 +361,46 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     const int ov = gemm_cfg_override();
     if (ov != 0 && p.M >= 2048 && p.N % 256 == 0) return launch_cfg<T, 256, 256, 2, 4>(p, batch, st);
     return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
+}
+
+// ---- split-K: the small-M GEMMs of the early scales (and of small batches) have too few tiles to fill 256 CUs and are
+// bound by the serial load->MFMA latency chain of one block's K loop.  They are split along K into slices that write fp32
+// partial tiles to a caller workspace; this kernel sums the slices in a fixed order and applies the full epilogue.
+__global__ __launch_bounds__(256) void cvar_splitk_epilogue_kernel(const float* __restrict__ part, int nsplit, const GemmParams p) {
+    const long nvec = (long)p.M * (p.N / 4);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / (p.N / 4));
+        const int n = (int)(i % (p.N / 4)) * 4;
+        f32x4_t v = *(const f32x4_t*)(part + (long)m * p.N + n);
+        for (int s = 1; s < nsplit; ++s) {
+            const f32x4_t w = *(const f32x4_t*)(part + (long)s * p.M * p.N + (long)m * p.N + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += w[e];
+        }
+        long orow = m;
+        if (p.remap_l > 0) {
+            const int sq = m / p.remap_l;
+            orow = (long)sq * p.remap_L + p.remap_off + (m - sq * p.remap_l);
+        }
+        const float* grow = p.gate ? p.gate + (long)(m / p.gate_rows) * p.ldg : nullptr;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[e] * p.alpha;
+            if (p.bias) x += p.bias[n + e];
+            if (p.act == CVAR_ACT_GELU_TANH) x = gelu_tanh_f(x);
+            if (grow) x *= grow[n + e];
+            if (p.residual) x += ld_any(p.residual, p.res_dtype, (long)m * p.ldr + n + e);
+            st_any(p.C, p.out_dtype, orow * p.ldc + n + e, x);
+        }
+    }
+}
+
+static float* g_splitk_ws = nullptr;       // set by cvar_gemm_set_workspace (caller-owned device memory)
+static size_t g_splitk_ws_bytes = 0;
+extern "C" int cvar_gemm_set_workspace(void* ws, int64_t bytes) {
+    g_splitk_ws = (float*)ws;
+    g_splitk_ws_bytes = ws ? (size_t)bytes : 0;
+    return CVAR_OK;
 }
 
 extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
@@ -388,6 +434,30 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     p.C = d->C; p.out_dtype = d->out_dtype; p.ldc = d->ldc;
     p.remap_l = d->remap_l; p.remap_L = d->remap_L; p.remap_off = d->remap_off;
     p.tiles_m = p.tiles_n = 0;
+    p.split_tiles = 0; p.split_stride = 0;
     hipStream_t st = as_stream(stream);
+    // split-K decision: plain (non-conv, unbatched) GEMMs whose tile count leaves most CUs idle
+    const int kt_elems = 128 / es;
+    const int nk_all = (d->K + kt_elems - 1) / kt_elems;
+    const int tm = d->M <= 64 ? (d->M + 63) / 64 : (d->M + 127) / 128, tn = (d->N + 127) / 128;
+    if (!d->conv && d->batch == 1 && d->M <= 1024 && (d->N % 4) == 0 && tm * tn < 128 && nk_all >= 8 && g_splitk_ws) {
+        int splits = min(16, max(2, 320 / (tm * tn)));
+        int per = (nk_all + splits - 1) / splits;
+        if (per < 2) per = 2;
+        splits = (nk_all + per - 1) / per;
+        const size_t need = (size_t)splits * d->M * d->N * sizeof(float);
+        if (splits > 1 && need <= g_splitk_ws_bytes) {
+            GemmParams ps = p;
+            ps.alpha = 1.0f; ps.bias = nullptr; ps.act = CVAR_ACT_NONE; ps.gate = nullptr; ps.residual = nullptr;
+            ps.C = g_splitk_ws; ps.out_dtype = CVAR_F32; ps.ldc = d->N; ps.remap_l = 0; ps.strideC = 0;
+            ps.split_tiles = per; ps.split_stride = (long)d->M * d->N;
+            const int rc = d->dtype == CVAR_BF16 ? launch_typed<bf16_t>(ps, 1, st) : launch_typed<float>(ps, 1, st);
+            if (rc != CVAR_OK) return rc;
+            const long nvec = (long)d->M * (d->N / 4);
+            hipLaunchKernelGGL(cvar_splitk_epilogue_kernel, dim3((unsigned)min((long)2048, (nvec + 255) / 256)), dim3(256), 0, st, g_splitk_ws, splits, p);
+            CVAR_CHECK_LAUNCH();
+            return CVAR_OK;
+        }
+    }
     return d->dtype == CVAR_BF16 ? launch_typed<bf16_t>(p, d->batch, st) : launch_typed<float>(p, d->batch, st);
 }

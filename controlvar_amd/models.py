@@ -428,6 +428,7 @@ class ControlVAR(nn.Module):
         dev, T, cfg = self.device, self.compute_dtype, self.cfg
         if dev.type != 'cuda':
             raise RuntimeError('controlvar_amd models compute on the GPU only; call .to("cuda") first')
+        ops.ensure_splitk_workspace(dev)
         sd = {k: v.detach() for k, v in self.state_dict().items()}
         C, depth = cfg.C, cfg.depth
         P: Dict[str, Any] = {}

@@ -39,6 +39,17 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+_SPLITK_WS = {}
+
+
+def ensure_splitk_workspace(device, nbytes: int = 256 << 20):
+    """give the library a split-K workspace on `device` (kept alive here; one per process)"""
+    key = str(device)
+    if key not in _SPLITK_WS or _SPLITK_WS[key].numel() < nbytes:
+        _SPLITK_WS[key] = torch.empty(nbytes, device=device, dtype=torch.uint8)
+        check(_lib.load().cvar_gemm_set_workspace(_SPLITK_WS[key].data_ptr(), nbytes), 'cvar_gemm_set_workspace')
+
+
 def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, lda: int = 0, ldw: int = 0, ldc: int = 0,
          bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, alpha: float = 1.0,
          gate: Optional[torch.Tensor] = None, ldg: int = 0, gate_rows: int = 1, gate_off: int = 0,

@@ -61,6 +61,10 @@ typedef struct {
     int remap_l, remap_L, remap_off;
 } cvar_gemm_desc;
 int cvar_gemm(const cvar_gemm_desc* d, void* stream);
+/* Optional caller-owned device workspace for split-K (fp32 partial tiles of small-M GEMMs, summed in a fixed order by a
+ * second kernel that applies the epilogue).  Without it cvar_gemm never splits.  Process-wide; pass NULL to clear.
+ * GEMMs that use it must be issued on ONE stream at a time. */
+int cvar_gemm_set_workspace(void* ws, int64_t bytes);
 
 /* ---------------------------------------------------------------------------------------------
  * adaLN: out[m,:] = cast( LN(x[m,:]) * (1 + scale[m / rows_per, :]) + shift[m / rows_per, :] ), LN over C with

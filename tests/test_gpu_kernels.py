@@ -324,3 +324,26 @@ def test_attention_mfma_flash_bf16(gpu_device, q_off, l, masked):
     assert close(out_rw, ref, torch.bfloat16, bf16_rel=2e-2)
     assert close(out, ref, torch.bfloat16, bf16_rel=2e-2)
     assert (out.float() - out_rw.float()).abs().max() < 2e-2
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('M,N,K', [(4, 1536, 1536), (256, 1536, 6144), (1000, 768, 1024), (36, 4608, 1536)])
+def test_gemm_split_k(gpu_device, dtype, M, N, K):
+    """small-M GEMMs take the split-K route once a workspace is registered: partial tiles + fixed-order reduce + epilogue"""
+    ops.ensure_splitk_workspace(gpu_device)
+    l = 4 if M % 4 == 0 else 1
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1.0 / math.sqrt(K)), rnd(N, seed=3)
+    gate = rnd(max(1, M // l), N, seed=4)
+    x = rnd(M, N, seed=5)
+    Ad, Wd = to_dev(A, dtype, gpu_device), to_dev(W, dtype, gpu_device)
+    acc = Ad.float().cpu() @ Wd.float().cpu().t() + b
+    out = torch.empty(M, N, device=gpu_device, dtype=dtype)
+    ops.gemm(Ad, Wd, out, M=M, N=N, K=K, bias=b.to(gpu_device), act=ACT_GELU_TANH)
+    assert close(out, F.gelu(acc, approximate='tanh'), dtype, 2e-4)
+    xd = x.to(gpu_device).clone()
+    ops.gemm(Ad, Wd, xd, M=M, N=N, K=K, bias=b.to(gpu_device), gate=gate.to(gpu_device), ldg=N, gate_rows=l, residual=xd)
+    assert close(xd, x + acc * gate.repeat_interleave(l, 0)[:M], dtype, 3e-4)
+    R, Lmax, off = M // l, 3 * l + 5, 2
+    arena = torch.zeros(R, Lmax, N, device=gpu_device, dtype=dtype)
+    ops.gemm(Ad, Wd, arena, M=M, N=N, K=K, bias=b.to(gpu_device), remap=(l, Lmax, off))
+    assert close(arena[:, off:off + l].reshape(M, N), acc, dtype, 2e-4) and arena[:, :off].abs().max() == 0
