@@ -10,7 +10,7 @@ import os
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libcvar_hip.so')
+LIB_PATH = os.environ.get('CVAR_LIB') or os.path.join(HERE, 'libcvar_hip.so')      # CVAR_LIB: A/B runs against another build
 ABI_VERSION = 3
 
 CVAR_F32, CVAR_BF16 = 0, 1
