@@ -40,7 +40,7 @@ struct GemmParams {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2>
 __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParams p) {
     constexpr int NW = WM * WN;
     constexpr int ES = sizeof(T);
@@ -175,15 +175,26 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     const int kt_lo = p.split_tiles > 0 ? (int)blockIdx.y * p.split_tiles : 0;
     const int nk = p.split_tiles > 0 ? min(nk_all, kt_lo + p.split_tiles) : nk_all;
 
-    // Pipeline: the DMA pieces of tile kt+1 are spread over the four k-steps of tile kt and issued right behind that
-    // k-step's fragment reads, so their issue cost overlaps the MFMAs already queued on the matrix pipe.
+    // Pipeline: NSTAGE LDS stages, PF = NSTAGE-1 tiles in flight.  The DMA pieces of tile kt+PF are spread over the four
+    // k-steps of tile kt and issued right behind that k-step's fragment reads, so their issue cost overlaps the MFMAs already
+    // queued on the matrix pipe.  One barrier per K tile: passing it means (a) every wave's pieces of tile kt have landed
+    // (counted vmcnt before the barrier) and (b) every wave has finished reading tile kt-1, whose stage is the one the
+    // pieces issued in this iteration overwrite.
+    constexpr int PF = NSTAGE - 1;
 #pragma unroll
-    for (int idx = 0; idx < NL; ++idx) issue_one(kt_lo, 0, idx);
+    for (int t = 0; t < PF; ++t) {
+        if (kt_lo + t < nk) {
+#pragma unroll
+            for (int idx = 0; idx < NL; ++idx) issue_one(kt_lo + t, t, idx);
+        }
+    }
+    int cur = 0;
     for (int kt = kt_lo; kt < nk; ++kt) {
-        const int cur = (kt - kt_lo) & 1;
-        const bool more = kt + 1 < nk;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const bool more = kt + PF < nk;
+        if (PF > 1 && kt + PF - 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        const int nxt = (cur + PF) % NSTAGE;
         const char* As = smem + cur * STAGE + (wm * SUB_M + lrow) * 128;
         const char* Bs = smem + cur * STAGE + BM * 128 + (wn * SUB_N + lrow) * 128;
 #pragma unroll
@@ -197,7 +208,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                 for (int j = 0; j < NJ; ++j) b[j] = *(const bf16x8_t*)(Bs + j * 32 * 128 + c);
                 if (more) {
 #pragma unroll
-                    for (int idx = ks * NL / 4; idx < (ks + 1) * NL / 4; ++idx) issue_one(kt + 1, cur ^ 1, idx);
+                    for (int idx = ks * NL / 4; idx < (ks + 1) * NL / 4; ++idx) issue_one(kt + PF, nxt, idx);
                 }
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                 for (int j = 0; j < NJ; ++j) b[j] = *(const f32x4_t*)(Bs + j * 32 * 128 + c);
                 if (more) {
 #pragma unroll
-                    for (int idx = ks * NL / 4; idx < (ks + 1) * NL / 4; ++idx) issue_one(kt + 1, cur ^ 1, idx);
+                    for (int idx = ks * NL / 4; idx < (ks + 1) * NL / 4; ++idx) issue_one(kt + PF, nxt, idx);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -224,8 +235,9 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        cur = (cur + 1) % NSTAGE;
     }
+    __syncthreads();
 
     // ---- epilogue: accumulators -> LDS (per-wave region, 32 rows at a time) -> row-major 8-wide vectors, so that
     // bias / gate / residual loads and the C stores are 16-byte and coalesced (128-B rows per 8 lanes).
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     constexpr int LPR = SUB_N / 8;                        // lanes per output row
     constexpr int RPP = 64 / LPR;                         // rows per pass (lanes >= RPP*LPR idle when LPR does not divide 64)
     constexpr int NPASS = (16 + RPP - 1) / RPP;
-    static_assert(NW * 16 * EROW * 4 <= 2 * STAGE, "epilogue staging must fit the pipeline LDS");
+    static_assert(NW * 16 * EROW * 4 <= NSTAGE * STAGE, "epilogue staging must fit the pipeline LDS");
     float* stg = (float*)smem + wave * (16 * EROW);
     char* Cb = (char*)p.C;
     const long cz = zb * p.strideC + (long)blockIdx.y * p.split_stride, rz = zb * p.strideR;
@@ -322,21 +334,21 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE = 2>
 static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     GemmParams p = gp;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    const size_t lds = 2 * (BM + BN) * 128;
+    const size_t lds = NSTAGE * (BM + BN) * 128;
     const int nk_all = (p.K + (128 / (int)sizeof(T)) - 1) / (128 / (int)sizeof(T));
     const int splits = p.split_tiles > 0 ? (nk_all + p.split_tiles - 1) / p.split_tiles : 1;
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits, (unsigned)batch), block(WM * WN * 64);
     if (p.conv) {
-        auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, true>;
+        auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, true, NSTAGE>;
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
     } else {
-        auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, false>;
+        auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, false, NSTAGE>;
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
     }
@@ -359,6 +371,7 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     // large streaming GEMMs: 256x256 tile, 8 waves (2x4) - halves the operand bytes per flop and doubles the MFMA work
     // per barrier; measured +10..15 % over 128x128 on the d24 shapes.  CVAR_GEMM_CFG=0 forces the 128x128 tile (A/B runs).
     const int ov = gemm_cfg_override();
+    if (ov == 2 && p.M >= 2048 && p.N % 128 == 0) return launch_cfg<T, 256, 128, 4, 2, 3>(p, batch, st);
     if (ov != 0 && p.M >= 2048 && p.N % 256 == 0) return launch_cfg<T, 256, 256, 2, 4>(p, batch, st);
     return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
 }
