@@ -397,25 +397,89 @@ extern "C" int cvar_softmax_rows(const float* s, void* p, int out_dtype, int row
     return CVAR_OK;
 }
 
-// [B][n][c] (row stride ld_in) -> [B][c][n]
+// [B][n][c] (row stride ld_in) -> [B][c][ld_out >= n]   64 x 64 tiles, 16-byte global accesses on both sides
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int n, int c, long ld_in, long ld_out) {
-    __shared__ T tile[32][33];
+    constexpr int VEC = 16 / sizeof(T);          // elements per 16-byte access
+    constexpr int TS = 64;                       // tile side
+    constexpr int TPR = TS / VEC;                // threads per tile row
+    constexpr int RPP = 256 / TPR;               // tile rows per pass
+    __shared__ T tile[TS][TS + 2 * VEC / VEC + (sizeof(T) == 2 ? 2 : 1)];   // padded rows (odd dword stride)
     const long b = blockIdx.z;
-    const int n0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
-    for (int r = ty; r < 32; r += 8)
-        if (n0 + r < n && c0 + tx < c) tile[r][tx] = in[(b * n + n0 + r) * ld_in + c0 + tx];
+    const int n0 = blockIdx.x * TS, c0 = blockIdx.y * TS;
+    const int tr = threadIdx.x / TPR, tv = (threadIdx.x % TPR) * VEC;
+    const bool vec_in = ((ld_in % VEC) == 0) && ((((uintptr_t)in) & 15) == 0);
+    const bool vec_out = ((ld_out % VEC) == 0) && ((((uintptr_t)out) & 15) == 0);
+    // load: tile[r][cc] = in[n0 + r][c0 + cc]
+    for (int r = tr; r < TS; r += RPP) {
+        const int nn = n0 + r, cc = c0 + tv;
+        if (nn < n) {
+            const T* src = in + (b * n + nn) * ld_in + cc;
+            if (vec_in && cc + VEC <= c) {
+                T tmp[VEC];
+                *(u32x4_t*)tmp = *(const u32x4_t*)src;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) tile[r][tv + e] = tmp[e];
+            } else {
+                for (int e = 0; e < VEC; ++e) if (cc + e < c) tile[r][tv + e] = src[e];
+            }
+        }
+    }
     __syncthreads();
-    for (int r = ty; r < 32; r += 8)
-        if (c0 + r < c && n0 + tx < n) out[(b * c + c0 + r) * ld_out + n0 + tx] = tile[tx][r];
+    // store: out[c0 + r][n0 + cc] = tile[cc][r]
+    for (int r = tr; r < TS; r += RPP) {
+        const int cidx = c0 + r, nn = n0 + tv;
+        if (cidx < c) {
+            T* dst = out + (b * c + cidx) * ld_out + nn;
+            if (vec_out && nn + VEC <= n) {
+                T tmp[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) tmp[e] = tile[tv + e][r];
+                *(u32x4_t*)dst = *(const u32x4_t*)tmp;
+            } else {
+                for (int e = 0; e < VEC; ++e) if (nn + e < n) dst[e] = tile[tv + e][r];
+            }
+        }
+    }
 }
 
 extern "C" int cvar_transpose(const void* in, void* out, int dtype, int B, int n, int c, int64_t ld_in, int64_t ld_out, void* stream) {
     if (!in || !out || B <= 0 || n <= 0 || c <= 0 || ld_out < n) return CVAR_EINVAL;
-    dim3 grid(cdiv(n, 32), cdiv(c, 32), B), block(256);
+    dim3 grid(cdiv(n, 64), cdiv(c, 64), B), block(256);
     if (dtype == CVAR_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, block, 0, as_stream(stream), (const bf16_t*)in, (bf16_t*)out, n, c, (long)ld_in, (long)ld_out);
     else if (dtype == CVAR_F32) hipLaunchKernelGGL(transpose_kernel<float>, grid, block, 0, as_stream(stream), (const float*)in, (float*)out, n, c, (long)ld_in, (long)ld_out);
+    else return CVAR_EUNSUPPORTED;
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// out[r] (+)= sum_j A[r][j], j < ncols  (rows contiguous: bias gradients read from the already transposed dY)
+template <typename T>
+__global__ __launch_bounds__(256) void rowsum_kernel(const T* __restrict__ A, long lda, float* __restrict__ out, int nrows, int ncols, int accumulate) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const T* ar = A + (long)row * lda;
+    float acc = 0.f;
+    const int nv = ncols / VEC;
+    for (int i = lane; i < nv; i += 64) {
+        T tmp[VEC];
+        *(u32x4_t*)tmp = *(const u32x4_t*)(ar + (long)i * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc += Elem<T>::ld(tmp + e);
+    }
+    for (int j = nv * VEC + lane; j < ncols; j += 64) acc += Elem<T>::ld(ar + j);
+    acc = wave_sum(acc);
+    if (lane == 0) out[row] = accumulate ? out[row] + acc : acc;
+}
+extern "C" int cvar_rowsum(const void* A, int dtype, int64_t lda, float* out, int nrows, int ncols, int accumulate, void* stream) {
+    if (!A || !out || nrows <= 0 || ncols <= 0) return CVAR_EINVAL;
+    const int es = dtype == CVAR_BF16 ? 2 : 4;
+    if ((lda * es) % 16 || ((uintptr_t)A & 15)) return CVAR_EUNSUPPORTED;
+    dim3 grid(cdiv(nrows, 4)), block(256);
+    if (dtype == CVAR_BF16) hipLaunchKernelGGL(rowsum_kernel<bf16_t>, grid, block, 0, as_stream(stream), (const bf16_t*)A, (long)lda, out, nrows, ncols, accumulate);
+    else if (dtype == CVAR_F32) hipLaunchKernelGGL(rowsum_kernel<float>, grid, block, 0, as_stream(stream), (const float*)A, (long)lda, out, nrows, ncols, accumulate);
     else return CVAR_EUNSUPPORTED;
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;

@@ -225,6 +225,10 @@ def colsum(A, lda, out, M, N, ws, accumulate=False, a_off: int = 0, out_off: int
     check(_lib.load().cvar_colsum(_ptr(A) + a_off * A.element_size(), dt(A), lda, _ptr(out) + 4 * out_off, M, N, int(accumulate), _ptr(ws), _stream()), 'cvar_colsum')
 
 
+def rowsum(A, lda, out, nrows, ncols, accumulate=False, out_off: int = 0):
+    check(_lib.load().cvar_rowsum(_ptr(A), dt(A), lda, _ptr(out) + 4 * out_off, nrows, ncols, int(accumulate), _stream()), 'cvar_rowsum')
+
+
 def ce_fwd_bwd(logits, target, weight, gscale, loss_tok, dlogits, M, V):
     check(_lib.load().cvar_ce_fwd_bwd(_ptr(logits), _ptr(target), _ptr(weight), float(gscale), _ptr(loss_tok), _ptr(dlogits),
                                       dt(dlogits) if dlogits is not None else CVAR_F32, M, V, _stream()), 'cvar_ce_fwd_bwd')

@@ -341,7 +341,7 @@ class TrainEngine:
         ops.transpose(self.dlogits, TA, 1, M, V, V, ld_out=Mp)
         ops.transpose(self.UH, TB, 1, M, C, C, ld_out=Mp)
         ops.gemm(TA, TB, self.G_misc, M=V, N=C, K=Mp, c_off=mo['w_head'][0])
-        ops.colsum(self.dlogits, V, self.G_misc, M, V, ws, out_off=mo['b_head'][0])
+        ops.rowsum(TA, Mp, self.G_misc, V, M, out_off=mo['b_head'][0])
         ops.ln_modulate_bwd(self.Xs[depth], self.DU, ada, ah, n_ada, L, None, self.dX, self.dada, ah, ah + C, n_ada, M, C, eps, ws)
         # ---- backward: blocks
         for i in reversed(range(depth)):
@@ -354,13 +354,13 @@ class TrainEngine:
             ops.transpose(self.DF, TA, 1, M, C, C, ld_out=Mp)
             ops.transpose(self.Hh[i], TB, 1, M, hid, hid, ld_out=Mp)
             ops.gemm(TA, TB, G, M=C, N=hid, K=Mp, c_off=go + so['w_fc2'])
-            ops.colsum(self.DF, C, G, M, C, ws, out_off=go + so['b_fc2'])
+            ops.rowsum(TA, Mp, G, C, M, out_off=go + so['b_fc2'])
             ops.gelu_bwd(self.A[i], self.DH)
             ops.gemm(self.DH, self.WT['fc1'], self.DU, M=M, N=C, K=hid, w_off=i * C * hid)
             ops.transpose(self.DH, TA, 1, M, hid, hid, ld_out=Mp)
             ops.transpose(self.U2[i], TB, 1, M, C, C, ld_out=Mp)
             ops.gemm(TA, TB, G, M=hid, N=C, K=Mp, c_off=go + so['w_fc1'])
-            ops.colsum(self.DH, hid, G, M, hid, ws, out_off=go + so['b_fc1'])
+            ops.rowsum(TA, Mp, G, hid, M, out_off=go + so['b_fc1'])
             ops.ln_modulate_bwd(self.X1s[i], self.DU, ada, a0 + 3 * C, n_ada, L, self.dX, self.dX, self.dada, a0 + 3 * C, a0 + 5 * C, n_ada, M, C, eps, ws)
             # attention branch
             ops.gated_grad(self.dX, self.F1[i], ada, a0, n_ada, dp1[i].contiguous() if dp1 is not None else None, self.DF, self.dada, a0, n_ada, B, L, C, ws)
@@ -368,13 +368,13 @@ class TrainEngine:
             ops.transpose(self.DF, TA, 1, M, C, C, ld_out=Mp)
             ops.transpose(self.O[i], TB, 1, M, C, C, ld_out=Mp)
             ops.gemm(TA, TB, G, M=C, N=C, K=Mp, c_off=go + so['w_proj'])
-            ops.colsum(self.DF, C, G, M, C, ws, out_off=go + so['b_proj'])
+            ops.rowsum(TA, Mp, G, C, M, out_off=go + so['b_proj'])
             ops.attention_bwd(self.arena[i], self.O[i], self.DU, self.LSE[i], self.DQKV, ws, B, H, L, L, scale, lvl_end)
             ops.gemm(self.DQKV, self.WT['qkv'], self.DU, M=M, N=C, K=3 * C, w_off=i * C * 3 * C)
             ops.transpose(self.DQKV, TA, 1, M, 3 * C, 3 * C, ld_out=Mp)
             ops.transpose(self.U[i], TB, 1, M, C, C, ld_out=Mp)
             ops.gemm(TA, TB, G, M=3 * C, N=C, K=Mp, c_off=go + so['w_qkv'])
-            ops.colsum(self.DQKV, 3 * C, G, M, 3 * C, ws, out_off=go + so['b_qkv'])      # the k-bias third is unused (zero_k_bias is a buffer)
+            ops.rowsum(TA, Mp, G, 3 * C, M, out_off=go + so['b_qkv'])      # the k-bias third is unused (zero_k_bias is a buffer)
             ops.ln_modulate_bwd(self.Xs[i], self.DU, ada, a0 + 2 * C, n_ada, L, self.dX, self.dX, self.dada, a0 + 2 * C, a0 + 4 * C, n_ada, M, C, eps, ws)
             if self.reducer is not None:
                 self.reducer.ready(i)

@@ -182,6 +182,9 @@ int cvar_ln_modulate_bwd(const float* x, const void* dy, int dtype, const float*
                          int M, int C, float eps, float* ws, void* stream);
 /* out[n] (+)= sum_m A[m,n]  (bias gradients).  ws: 64*N floats. */
 int cvar_colsum(const void* A, int dtype, int64_t lda, float* out, int64_t M, int N, int accumulate, float* ws, void* stream);
+/* out[r] (+)= sum_j A[r][j], j < ncols (16-byte aligned rows): the same bias gradient read from the transposed dY that the
+ * weight-gradient GEMM needs anyway - contiguous rows instead of a strided column walk. */
+int cvar_rowsum(const void* A, int dtype, int64_t lda, float* out, int nrows, int ncols, int accumulate, void* stream);
 /* token cross-entropy (CrossEntropyLoss(reduction='none'), train_control_var_hpu.py:135,231) fused with its gradient:
  * loss_tok[m] = logsumexp(logits[m,:]) - logits[m,target[m]];  dlogits = (softmax - onehot) * weight[m] * gscale (optional). */
 int cvar_ce_fwd_bwd(const float* logits, const int32_t* target, const float* weight, float gscale, float* loss_tok,

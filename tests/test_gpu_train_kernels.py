@@ -187,3 +187,19 @@ def test_adamw_sumsq_clip_scatter_silu(gpu_device):
     dc = torch.empty(4, 64, device=gpu_device)
     ops.silu_bwd(cond.detach().to(gpu_device), ds.to(gpu_device), dc)
     assert close(dc, cond.grad, F32, 1e-5)
+
+
+@pytest.mark.parametrize('dtype', [F32, BF16])
+@pytest.mark.parametrize('n,c', [(1000, 200), (64, 64), (37, 130), (4097, 96)])
+def test_transpose_tiles_and_rowsum(gpu_device, dtype, n, c):
+    B = 2
+    x = rnd(B, n, c + 8, seed=1)
+    xd = dev(x, dtype, gpu_device)
+    npad = (n + 7) // 8 * 8
+    out = torch.zeros(B, c, npad, device=gpu_device, dtype=dtype)
+    ops.transpose(xd, out, B, n, c, c + 8, in_off=8, ld_out=npad)
+    assert torch.equal(out[:, :, :n].float().cpu(), xd.float().cpu()[:, :, 8:].transpose(1, 2))
+    assert npad == n or out[:, :, n:].abs().max() == 0
+    rs = torch.ones(c, device=gpu_device)
+    ops.rowsum(out[0], npad, rs, c, n, accumulate=True)
+    assert close(rs, 1 + xd.float().cpu()[0, :, 8:].sum(0), F32, 2e-4)
