@@ -121,7 +121,7 @@ extern "C" int cvar_silu_cast(const float* x, void* out, int out_dtype, int64_t 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void cos_qk_norm_kernel(T* __restrict__ qkv, int R, int H, int Lmax, int q_off, int l,
-                                                         const float* __restrict__ scale_mul) {
+                                                         const float* __restrict__ scale_mul, float* __restrict__ norms) {
     const int lane = threadIdx.x & 63;
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);     // over R*l*H*2
     const long total = (long)R * l * H * 2;
@@ -133,19 +133,63 @@ __global__ __launch_bounds__(256) void cos_qk_norm_kernel(T* __restrict__ qkv, i
     const long r = rt / l;
     T* p = qkv + ((r * Lmax + q_off + t) * 3 + which) * (long)(H * 64) + h * 64 + lane;
     const float v = Elem<T>::ld(p);
-    const float nrm = sqrtf(wave_sum(v * v));
-    float o = v / fmaxf(nrm, 1e-12f);                              // F.normalize eps
+    const float nrm = fmaxf(sqrtf(wave_sum(v * v)), 1e-12f);      // F.normalize eps
+    float o = v / nrm;
     if (which == 0) o *= __expf(fminf(scale_mul[h], 4.605170185988092f));
     Elem<T>::st(p, o);
+    if (norms && lane == 0) norms[item] = nrm;                     // [R][l][H][q|k], saved for the backward pass
 }
 
 extern "C" int cvar_cos_qk_norm(void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, const float* scale_mul,
-                                void* stream) {
+                                float* norms, void* stream) {
     if (!qkv || !scale_mul || R <= 0 || H <= 0 || l <= 0) return CVAR_EINVAL;
     const long total = (long)R * l * H * 2;
     dim3 grid(cdiv(total, 4)), block(256);
-    if (dtype == CVAR_BF16) hipLaunchKernelGGL(cos_qk_norm_kernel<bf16_t>, grid, block, 0, as_stream(stream), (bf16_t*)qkv, R, H, Lmax, q_off, l, scale_mul);
-    else if (dtype == CVAR_F32) hipLaunchKernelGGL(cos_qk_norm_kernel<float>, grid, block, 0, as_stream(stream), (float*)qkv, R, H, Lmax, q_off, l, scale_mul);
+    if (dtype == CVAR_BF16) hipLaunchKernelGGL(cos_qk_norm_kernel<bf16_t>, grid, block, 0, as_stream(stream), (bf16_t*)qkv, R, H, Lmax, q_off, l, scale_mul, norms);
+    else if (dtype == CVAR_F32) hipLaunchKernelGGL(cos_qk_norm_kernel<float>, grid, block, 0, as_stream(stream), (float*)qkv, R, H, Lmax, q_off, l, scale_mul, norms);
+    else return CVAR_EUNSUPPORTED;
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// backward of the cos-attention pre-pass, in place on dqkv (gradients w.r.t. q_hat*sm, k_hat -> w.r.t. raw q, k):
+//   x_t = x / |x| ;  dx = (g' - x_t (x_t . g')) / |x|  with g' = g * sm for q, g for k;  dsm[token, head] = g . x_t  (q only)
+template <typename T>
+__global__ __launch_bounds__(256) void cos_qk_norm_bwd_kernel(const T* __restrict__ qkv, T* __restrict__ dqkv, int R, int H, int Lmax, int l,
+                                                             const float* __restrict__ scale_mul, const float* __restrict__ norms,
+                                                             float* __restrict__ dsm_tok /*[R*l][H]*/) {
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long total = (long)R * l * H * 2;
+    if (item >= total) return;
+    const int which = (int)(item & 1);
+    const int h = (int)((item >> 1) % H);
+    const long rt = (item >> 1) / H;
+    const int t = (int)(rt % l);
+    const long r = rt / l;
+    const long off = ((r * Lmax + t) * 3 + which) * (long)(H * 64) + h * 64 + lane;
+    const float sm = __expf(fminf(scale_mul[h], 4.605170185988092f));
+    const float xh = Elem<T>::ld(qkv + off);                        // normalized (and, for q, scaled) value kept by the forward
+    const float g = Elem<T>::ld(dqkv + off);
+    const float nrm = norms[item];
+    const float xt = which == 0 ? xh / sm : xh;
+    const float gp = which == 0 ? g * sm : g;
+    const float dot = wave_sum(xt * gp);
+    Elem<T>::st(dqkv + off, (gp - xt * dot) / nrm);
+    if (which == 0) {
+        const float ds = wave_sum(g * xt);
+        // chain rule through sm = exp(min(s, ln 100)): d sm / d s = sm below the clamp, 0 above it
+        if (lane == 0) dsm_tok[rt * H + h] = scale_mul[h] < 4.605170185988092f ? ds * sm : 0.f;
+    }
+}
+
+extern "C" int cvar_cos_qk_norm_bwd(const void* qkv, void* dqkv, int dtype, int R, int H, int Lmax, int l, const float* scale_mul,
+                                    const float* norms, float* dsm_tok, void* stream) {
+    if (!qkv || !dqkv || !scale_mul || !norms || !dsm_tok || R <= 0 || H <= 0 || l <= 0) return CVAR_EINVAL;
+    const long total = (long)R * l * H * 2;
+    dim3 grid(cdiv(total, 4)), block(256);
+    if (dtype == CVAR_BF16) hipLaunchKernelGGL(cos_qk_norm_bwd_kernel<bf16_t>, grid, block, 0, as_stream(stream), (const bf16_t*)qkv, (bf16_t*)dqkv, R, H, Lmax, l, scale_mul, norms, dsm_tok);
+    else if (dtype == CVAR_F32) hipLaunchKernelGGL(cos_qk_norm_bwd_kernel<float>, grid, block, 0, as_stream(stream), (const float*)qkv, (float*)dqkv, R, H, Lmax, l, scale_mul, norms, dsm_tok);
     else return CVAR_EUNSUPPORTED;
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;
@@ -536,7 +580,7 @@ extern "C" int cvar_nhwc_to_nchw(const void* in, int dtype, int64_t ld_in, float
     return CVAR_OK;
 }
 
-extern "C" int cvar_abi_version(void) { return 3; }
+extern "C" int cvar_abi_version(void) { return 4; }
 extern "C" const char* cvar_status_str(int status) {
     switch (status) {
         case CVAR_OK: return "ok";

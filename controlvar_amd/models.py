@@ -668,7 +668,7 @@ class ControlVAR(nn.Module):
         parameters) the call is differentiable - `loss.backward()` runs the hand-written backward kernels
         (controlvar_amd/train.py); otherwise it is the inference-only fast path.  Label / cond-type dropout follows
         ``self.training`` (torch.rand, as the reference)."""
-        if torch.is_grad_enabled() and not self.cfg.uses_cos_attn and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from .train import teacher_forced_with_grad
             if not mask_first:
                 raise NotImplementedError('mask_first=False only occurs with bidirectional=True')

@@ -125,9 +125,14 @@ def attention_bwd(qkv, o, dout, lse, dqkv, ws, R, H, Lmax, l, scale, lvl_end=Non
 
 
 def cos_qk_norm(qkv: torch.Tensor, R: int, H: int, Lmax: int, q_off: int, l: int, scale_mul: torch.Tensor,
-                qkv_off: int = 0, sm_off: int = 0):
+                qkv_off: int = 0, sm_off: int = 0, norms: Optional[torch.Tensor] = None):
     check(_lib.load().cvar_cos_qk_norm(_ptr(qkv) + qkv_off * qkv.element_size(), dt(qkv), R, H, Lmax, q_off, l,
-                                       _ptr(scale_mul) + 4 * sm_off, _stream()), 'cvar_cos_qk_norm')
+                                       _ptr(scale_mul) + 4 * sm_off, _ptr(norms), _stream()), 'cvar_cos_qk_norm')
+
+
+def cos_qk_norm_bwd(qkv, dqkv, R, H, Lmax, l, scale_mul, norms, dsm_tok, sm_off: int = 0):
+    check(_lib.load().cvar_cos_qk_norm_bwd(_ptr(qkv), _ptr(dqkv), dt(qkv), R, H, Lmax, l, _ptr(scale_mul) + 4 * sm_off, _ptr(norms), _ptr(dsm_tok),
+                                           _stream()), 'cvar_cos_qk_norm_bwd')
 
 
 def cfg_sample(logits: torch.Tensor, B: int, nrep: int, l: int, V: int, coef: Sequence[float], top_k: int, top_p: float,

@@ -113,8 +113,6 @@ class TrainEngine:
     def __init__(self, var, drop_path: bool = True, reducer=None):
         self.var = var
         self.cfg = var.cfg
-        if self.cfg.uses_cos_attn:
-            raise NotImplementedError('cos-attention (depth 30) backward is not built yet')
         self.drop_path = drop_path
         self.reducer = reducer
         self._B = None
@@ -141,6 +139,8 @@ class TrainEngine:
         self.A = torch.empty(depth, M, hid, **tT); self.Hh = torch.empty(depth, M, hid, **tT)
         self.arena = torch.empty(depth, B, L, 3 * C, **tT)
         self.LSE = torch.empty(depth, B, cfg.H, L, **f32)
+        self.NORMS = torch.empty(depth, B, L, cfg.H, 2, **f32) if cfg.uses_cos_attn else None
+        self.DSM = torch.empty(M, cfg.H, **f32) if cfg.uses_cos_attn else None
         self.UH = torch.empty(M, C, **tT)
         self.logits = torch.empty(M, V, **f32)
         self.loss_tok = torch.empty(M, **f32)
@@ -161,7 +161,7 @@ class TrainEngine:
         self.slab_off = {}
         o = 0
         for name, n in (('w_qkv', 3 * C * C), ('w_proj', C * C), ('w_fc1', hid * C), ('w_fc2', C * hid), ('b_qkv', 3 * C), ('b_proj', C),
-                        ('b_fc1', hid), ('b_fc2', C)):
+                        ('b_fc1', hid), ('b_fc2', C), ('scale_mul', _pad8(cfg.H))):
             self.slab_off[name] = o
             o += n
         self.slab = o
@@ -214,6 +214,8 @@ class TrainEngine:
             g[p + 'attn.proj.bias'] = s[so['b_proj']:so['b_proj'] + C]
             g[p + 'ffn.fc1.bias'] = s[so['b_fc1']:so['b_fc1'] + hid]
             g[p + 'ffn.fc2.bias'] = s[so['b_fc2']:so['b_fc2'] + C]
+            if cfg.uses_cos_attn:
+                g[p + 'attn.scale_mul_1H11'] = s[so['scale_mul']:so['scale_mul'] + cfg.H].view(1, cfg.H, 1, 1)
             n_ada = depth * 6 * C + 2 * C
             g[p + 'ada_lin.1.weight'] = self.G_ada[:n_ada * C].view(n_ada, C)[i * 6 * C:(i + 1) * 6 * C]
             g[p + 'ada_lin.1.bias'] = self.G_ada[n_ada * C:][i * 6 * C:(i + 1) * 6 * C]
@@ -299,6 +301,8 @@ class TrainEngine:
             x = self.Xs[i]
             ops.ln_modulate(x, ada, a0 + 2 * C, a0 + 4 * C, n_ada, L, self.U[i], M, C, eps)
             ops.gemm(self.U[i], P['w_qkv'], self.arena[i], M=M, N=3 * C, K=C, w_off=i * 3 * C * C, bias=P['b_qkv'][i])
+            if cfg.uses_cos_attn:
+                ops.cos_qk_norm(self.arena[i], B, H, L, 0, L, P['scale_mul'], sm_off=i * H, norms=self.NORMS[i])
             ops.attention(self.arena[i], self.O[i], B, H, L, 0, L, scale, lvl_end, lse=self.LSE[i])
             ops.gemm(self.O[i], P['w_proj'], self.F1[i], M=M, N=C, K=C, w_off=i * C * C, bias=P['b_proj'][i])
             self.X1s[i].copy_(x)
@@ -370,6 +374,9 @@ class TrainEngine:
             ops.gemm(TA, TB, G, M=C, N=C, K=Mp, c_off=go + so['w_proj'])
             ops.rowsum(TA, Mp, G, C, M, out_off=go + so['b_proj'])
             ops.attention_bwd(self.arena[i], self.O[i], self.DU, self.LSE[i], self.DQKV, ws, B, H, L, L, scale, lvl_end)
+            if cfg.uses_cos_attn:           # normalisation + learned temperature of basic_var.py:99-104
+                ops.cos_qk_norm_bwd(self.arena[i], self.DQKV, B, H, L, L, P['scale_mul'], self.NORMS[i], self.DSM, sm_off=i * H)
+                ops.colsum(self.DSM, H, G, M, H, ws, out_off=go + so['scale_mul'])
             ops.gemm(self.DQKV, self.WT['qkv'], self.DU, M=M, N=C, K=3 * C, w_off=i * C * 3 * C)
             ops.transpose(self.DQKV, TA, 1, M, 3 * C, 3 * C, ld_out=Mp)
             ops.transpose(self.U[i], TB, 1, M, C, C, ld_out=Mp)

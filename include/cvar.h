@@ -101,7 +101,11 @@ int cvar_attention_bwd_rowwise(const void* qkv, int dtype, const void* o, const 
 /* cos-attention pre-pass (basic_var.py:99-104), in place on rows [q_off, q_off+l) of the arena:
  * q = normalize(q) * exp(min(scale_mul[h], log 100)),  k = normalize(k). */
 int cvar_cos_qk_norm(void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, const float* scale_mul,
-                     void* stream);
+                     float* norms /* optional [R][l][H][2] = |q|, |k|, saved for training */, void* stream);
+/* backward of the pre-pass, in place on dqkv (arena layout, q_off 0): gradients w.r.t. the normalised q, k become gradients
+ * w.r.t. the raw projections; dsm_tok[R*l][H] receives d loss / d scale_mul per token (summed over tokens by cvar_colsum). */
+int cvar_cos_qk_norm_bwd(const void* qkv, void* dqkv, int dtype, int R, int H, int Lmax, int l, const float* scale_mul,
+                         const float* norms, float* dsm_tok, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * CFG combine + sampling (control_var.py:295-307,501-505; helpers.py:6-19).

@@ -64,10 +64,12 @@ def test_training_step_fp32_matches_reference_fixture(gpu_device):
     print(f'worst relative gradient-slice error vs the reference: {worst:.2e}')
 
 
-@pytest.mark.parametrize('kind', ['control', 'var'])
+@pytest.mark.parametrize('kind', ['control', 'var', 'cos'])
 def test_all_gradients_against_oracle_fp32(gpu_device, kind):
-    """full tensors of every gradient vs autograd over the oracle (d2; ControlVAR and plain VAR), with an ignore mask"""
-    cfg = VarConfig(depth=2) if kind == 'control' else VarConfig(depth=2, mask_factor=1, control=False, multi_cond=False)
+    """full tensors of every gradient vs autograd over the oracle (d2 ControlVAR, plain VAR, and the depth-30 cos-attention
+    variant at narrow width incl. its learned temperature), with an ignore mask"""
+    cfg = {'control': VarConfig(depth=2), 'var': VarConfig(depth=2, mask_factor=1, control=False, multi_cond=False),
+           'cos': VarConfig(depth=30, embed_dim=128, num_heads=2)}[kind]
     vae, m = make(cfg, torch.float32, gpu_device)
     sd = synth_var_state(cfg)
     B, L, fl = 2, cfg.pyramid.L, cfg.pyramid.first_l
@@ -76,7 +78,7 @@ def test_all_gradients_against_oracle_fp32(gpu_device, kind):
     tg = torch.randint(0, 4096, (B, L), generator=gen)
     im = (torch.rand(B, L, generator=gen) > 0.3).float()
     cls, ty = torch.tensor([5, 999]), torch.tensor([1, 3])
-    loss_r, _, grads_r = train_ref.loss_and_grads(sd, cfg, cls, x, ty if kind == 'control' else None, tg, im)
+    loss_r, _, grads_r = train_ref.loss_and_grads(sd, cfg, cls, x, ty if kind != 'var' else None, tg, im)
     eng = T.TrainEngine(m, drop_path=False)
     loss, _ = eng.forward_backward(cls, x.to(gpu_device), ty, tg.to(gpu_device), im.to(gpu_device))
     assert abs(loss.item() - loss_r.item()) < 2e-5
