@@ -483,10 +483,12 @@ class FusedAdamW:
         self.betas, self.eps = betas, eps
         self.named = [(n, p) for n, p in var.named_parameters()]
         self.state = {n: (torch.zeros_like(p.data), torch.zeros_like(p.data)) for n, p in self.named}
-        d_names = [n for n, p in self.named if decays(n, p.ndim, nowd_keys)]
-        nd_names = [n for n, p in self.named if not decays(n, p.ndim, nowd_keys)]
-        self.param_groups = [dict(names=d_names, lr=lr, weight_decay=weight_decay, wd_sc=1.0, lr_sc=1.0),
-                             dict(names=nd_names, lr=lr, weight_decay=0.0, wd_sc=0.0, lr_sc=1.0)]
+        groups: Dict[str, dict] = {}                             # first-seen order, as filter_params (utils/lr_control.py:67-101)
+        for n, p in self.named:
+            d = decays(n, p.ndim, nowd_keys)
+            groups.setdefault('D' if d else 'ND', dict(names=[], lr=lr, weight_decay=weight_decay if d else 0.0,
+                                                       wd_sc=1.0 if d else 0.0, lr_sc=1.0))['names'].append(n)
+        self.param_groups = list(groups.values())
         self.steps = 0
         self._partial = None
         self._out2 = None
@@ -512,6 +514,47 @@ class FusedAdamW:
                           self.steps, coef, 1.0 / world)
         self.var._packed = None                                  # GEMM-ready copies are refreshed lazily
         return self._out2
+
+    # ---- wire format of torch.optim.AdamW.state_dict() (what train_control_var_hpu.py:420-447 saves and resumes)
+    def state_dict(self) -> Dict[str, object]:
+        state, groups, at = {}, [], 0
+        for g in self.param_groups:
+            idx = list(range(at, at + len(g['names'])))
+            at += len(idx)
+            if self.steps > 0:
+                for i, name in zip(idx, g['names']):
+                    m, v = self.state[name]
+                    state[i] = {'step': torch.tensor(float(self.steps)), 'exp_avg': m, 'exp_avg_sq': v}
+            groups.append({'lr': g['lr'], 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': g['weight_decay'], 'amsgrad': False,
+                           'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False, 'fused': None,
+                           'decoupled_weight_decay': True, 'wd_sc': g['wd_sc'], 'lr_sc': g['lr_sc'], 'params': idx})
+        return {'state': state, 'param_groups': groups}
+
+    def load_state_dict(self, sd: Dict[str, object]) -> None:
+        groups = sd['param_groups']
+        if len(groups) != len(self.param_groups) or any(len(a['params']) != len(b['names']) for a, b in zip(groups, self.param_groups)):
+            raise ValueError('loaded state dict has a different number / size of parameter groups')     # torch's own check
+        steps = set()
+        for saved, g in zip(groups, self.param_groups):
+            for k in ('lr', 'weight_decay', 'wd_sc', 'lr_sc'):
+                if k in saved:
+                    g[k] = saved[k]
+            if 'betas' in saved:
+                self.betas = tuple(saved['betas'])
+            self.eps = saved.get('eps', self.eps)
+            for i, name in zip(saved['params'], g['names']):
+                st = sd['state'].get(i)
+                m, v = self.state[name]
+                if st is None:
+                    m.zero_(); v.zero_()
+                    continue
+                if tuple(st['exp_avg'].shape) != tuple(m.shape):
+                    raise ValueError(f'optimizer state for {name}: shape {tuple(st["exp_avg"].shape)} != {tuple(m.shape)}')
+                m.copy_(st['exp_avg']); v.copy_(st['exp_avg_sq'])
+                steps.add(int(float(st['step'])))
+        if len(steps) > 1:
+            raise ValueError(f'per-parameter step counts differ ({sorted(steps)}); the fused optimizer keeps one')
+        self.steps = steps.pop() if steps else 0
 
 
 class Trainer:
@@ -542,7 +585,7 @@ class Trainer:
     @torch.no_grad()
     def step(self, images, masks, cls, types, ignore_mask=None, drop_seed=None) -> Dict[str, object]:
         s = self.sched
-        lr_wd_annealing(s['sche'], self.opt, s['peak_lr'], s['wd'], s['wd_end'], self.it, s['wp_it'], s['max_it'], wp0=s['wp0'], wpe=s['wpe'])
+        _, max_lr, _, max_wd = lr_wd_annealing(s['sche'], self.opt, s['peak_lr'], s['wd'], s['wd_end'], self.it, s['wp_it'], s['max_it'], wp0=s['wp0'], wpe=s['wpe'])
         x, labels = self.tokenize(images, masks)
         self.engine._setup(x.shape[0])
         if self.world > 1 and self._reducer_for is not self.engine.buckets:
@@ -554,7 +597,7 @@ class Trainer:
         norm_coef = self.opt.step(self.engine.grads(), self.clip, self.world)
         self.engine._transposed_weights()
         self.it += 1
-        return dict(loss=loss, grad_norm=norm_coef[0], clip_coef=norm_coef[1], lr=self.opt.param_groups[0]['lr'], wd=self.opt.param_groups[0]['weight_decay'])
+        return dict(loss=loss, grad_norm=norm_coef[0], clip_coef=norm_coef[1], lr=max_lr, wd=max_wd)
 
 
 class _TeacherForcedFn(torch.autograd.Function):

@@ -339,6 +339,54 @@ def case_train_step():
          names=np.array(names), nd_names=np.array(nd_names), gnorms=gnorms, total_norm=total_norm, lrs=np.array(lrs, dtype=np.float64), **sl, **after)
 
 
+def case_checkpoint():
+    """N1: the reference's own load_var_weight (train_control_var_hpu.py:472-534; the function body is lifted out of the
+    script by ast HERE, at generation time only, because the script itself imports Habana modules) applied to a DDP-style
+    VAR-d2 checkpoint -> per-key SHA-256 of the ControlVAR state that results; plus the layout of the reference
+    optimizer's state_dict (group order / index lists / keys) for the wire-format test."""
+    import argparse, ast, hashlib, importlib.util, math, tempfile
+    from collections import OrderedDict
+    import torch.nn as nn
+    src = open('/root/reference/train_control_var_hpu.py').read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == 'load_var_weight'][0]
+    ns = dict(torch=torch, nn=nn, math=math, OrderedDict=OrderedDict)
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), 'load_var_weight', 'exec'), ns)
+    vae = make_vae(32)
+    var_plain = make_cvar(vae, VarConfig(depth=2, mask_factor=1, control=False), seed=3)
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, 'var_d2.pth')
+        torch.save({'model_state_dict': OrderedDict(('module.' + k, v) for k, v in var_plain.state_dict().items())}, path)
+        for interpos in (False, True):
+            m = make_cvar(vae, VarConfig(depth=2), seed=0)
+            args = argparse.Namespace(var_pretrained_path=path, embed_dim=128, mask_type='interleave_append', interpos=interpos,
+                                      separator=False, mpos=False, v_patch_nums=PN, vocab_size=4096)
+            quiet(ns['load_var_weight'], m, args)
+            tag = 'ip1' if interpos else 'ip0'
+            keys = list(m.state_dict().keys())
+            out[f'{tag}_keys'] = np.array(keys)
+            out[f'{tag}_sha'] = np.array([hashlib.sha256(v.contiguous().numpy().tobytes()).hexdigest() for v in m.state_dict().values()])
+            out[f'{tag}_pos'] = m.state_dict()['pos_1LC'][0, ::37, ::5].clone()
+    spec = importlib.util.spec_from_file_location('ref_lr_control', '/root/reference/utils/lr_control.py')
+    lrc = importlib.util.module_from_spec(spec); spec.loader.exec_module(lrc)
+    m = make_cvar(vae, VarConfig(depth=2), seed=0)
+    for p_ in m.parameters():
+        p_.requires_grad_(True)
+    names, paras, groups = lrc.filter_params(m, nowd_keys={'cls_token', 'start_token', 'task_token', 'cfg_uncond', 'pos_embed', 'pos_1LC',
+                                                            'pos_start', 'start_pos', 'lvl_embed', 'gamma', 'beta', 'ada_gss', 'moe_bias', 'scale_mul'})
+    opt = torch.optim.AdamW(groups, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.05)
+    for p_ in paras:
+        p_.grad = torch.full_like(p_, 1e-3)
+    opt.step(); opt.step()
+    osd = opt.state_dict()
+    by_id = {id(p_): n for n, p_ in m.named_parameters()}
+    order = [by_id[id(p_)] for g in groups for p_ in g['params']]
+    save('checkpoint_d2', opt_order=np.array(order), opt_group_sizes=np.array([len(g['params']) for g in osd['param_groups']]),
+         opt_group_keys=np.array(sorted(osd['param_groups'][0].keys())), opt_wd_sc=np.array([g['wd_sc'] for g in osd['param_groups']]),
+         opt_state_keys=np.array(sorted(osd['state'][0].keys())), opt_step=osd['state'][0]['step'].clone(),
+         opt_step_dtype=np.array(str(osd['state'][0]['step'].dtype)), **out)
+
+
 CASES = {
     'interp': case_interp,
     'tok_tiny': lambda: case_tokenizer(32, 3, 'ch32'),
@@ -353,6 +401,7 @@ CASES = {
     'sampler': case_sampler,
     'lr': case_lr,
     'train': case_train_step,
+    'checkpoint': case_checkpoint,
 }
 
 if __name__ == '__main__':

@@ -166,3 +166,35 @@ def test_autograd_bridge_and_loss_decreases(gpu_device):
         eng._transposed_weights()
         losses.append(l_.item())
     assert losses[-1] < losses[0] - 0.05, losses
+
+
+def test_resume_from_checkpoint_continues_bit_identically(gpu_device, tmp_path):
+    """N1: save_checkpoint after step 2, resume into a freshly built model + optimizer, step 3 there == step 3 of the
+    uninterrupted run (parameters and loss bit-identical: the kernels are deterministic and the snapshot is complete)."""
+    from controlvar_amd import checkpoint as ckpt
+    cfg = VarConfig(depth=2)
+    images, masks = synth_images(2, 256, seed=6).to(gpu_device), synth_images(2, 256, seed=7).to(gpu_device)
+    cls, types = torch.tensor([17, 403]), torch.tensor([2, 0])
+    kw = dict(peak_lr=2e-3, weight_decay=0.05, weight_decay_end=0.01, sche='lin0', warmup_it=2, max_it=50, clip=2.0, drop_path=False)
+    vae, m = make(cfg, torch.bfloat16, gpu_device)
+    m.eval()
+    tr = T.Trainer(m, vae, **kw)
+    for _ in range(2):
+        tr.step(images, masks, cls, types)
+    path = ckpt.save_checkpoint(m, tr.opt, epoch=0, step=tr.it, save_dir=str(tmp_path), latest=True)
+    want = tr.step(images, masks, cls, types)
+    want_sd = {k: v.clone() for k, v in m.state_dict().items()}
+
+    vae2, m2 = make(cfg, torch.bfloat16, gpu_device)
+    m2.eval()
+    with torch.no_grad():
+        for p in m2.parameters():
+            p.add_(0.01)                        # make sure the resumed values come from the file
+    tr2 = T.Trainer(m2, vae2, **kw)
+    steps, epoch = ckpt.resume(m2, tr2.opt, path)
+    assert (steps, epoch) == (2, 0)
+    tr2.it = steps
+    got = tr2.step(images, masks, cls, types)
+    assert got['loss'].item() == want['loss'].item() and got['lr'] == want['lr']
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, want_sd[k]), k
