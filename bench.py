@@ -143,8 +143,8 @@ def main():
             'end_to_end_tflops_per_gpu': round(per_sample_tf * B * a.steps / dt, 1),
         }
         if prof:
-            ms = sum(s.elapsed_time(e) for s, e, _ in prof)
-            flops = sum(f for _, _, f in prof)
+            ms = sum(r[0].elapsed_time(r[1]) for r in prof)
+            flops = sum(r[2] for r in prof)
             ach = flops / (ms * 1e-3) / 1e12
             peak = 2500.0 if a.dtype == 'bf16' else 157.3
             traffic = None

@@ -80,5 +80,14 @@ __device__ __forceinline__ float gelu_tanh_f(float t) {
     return t / (1.0f + __expf(-u2));
 }
 
+__device__ __forceinline__ float gelu_tanh_fast(float t) {
+    // same function for the bf16 mode (the result is rounded to bf16 right away): v_exp_f32 and v_rcp_f32 directly,
+    // t * rcp(1 + 2^(-2u log2 e)) - about 1 ulp of f32 each, far inside the bf16 rounding step
+    const float c1 = -2.0f * 0.7978845608028654f * 1.4426950408889634f, c3 = c1 * 0.044715f;
+    const float t2 = t * t;
+    const float arg = t * (c1 + c3 * t2);
+    return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(arg));
+}
+
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -18,6 +18,10 @@
 #include <stdlib.h>
 
 __device__ __attribute__((aligned(16))) unsigned int cvar_zero_chunk[4] = {0u, 0u, 0u, 0u};
+#ifdef CVAR_GEMM_TIMING
+__device__ unsigned long long cvar_gemm_dbg[64 * 8 * 8];
+extern "C" int cvar_gemm_dbg_read(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cvar_gemm_dbg), sizeof(unsigned long long) * 64 * 8 * 8); }
+#endif
 
 struct GemmParams {
     int M, N, K;
@@ -33,16 +37,39 @@ struct GemmParams {
     void* C; int out_dtype; long ldc;
     int remap_l, remap_L, remap_off;
     int tiles_m, tiles_n;
+    int cv_adv, cv_rem;       // conv: a K tile advances (tap, ci) by (KT / Cin, KT % Cin) plus one carry
+    unsigned remap_magic, gate_magic; int remap_shift, gate_shift;   // exact m / remap_l and m / gate_rows for 0 <= m < 2^31 (fast_div)
     int split_tiles;          // split-K: K tiles per blockIdx.y slice (0 = no split); partials go to C + blockIdx.y * split_stride
     long split_stride;
 };
 
+
+// floor(m / d) for 0 <= m < 2^31 as mulhi + shift: magic = ceil(2^(31+s) / d), 2^(s-1) < d <= 2^s (shift < 0 encodes d == 1)
+__device__ __forceinline__ int fast_div(int m, unsigned magic, int shift) {
+    const unsigned q = __umulhi((unsigned)m, magic) >> (shift < 0 ? 0 : shift);
+    return shift < 0 ? m : (int)q;
+}
+static void make_fast_div(long d, unsigned* magic, int* shift) {
+    if (d <= 1) { *magic = 0; *shift = -1; return; }
+    int sft = 0;
+    while ((1L << sft) < d) ++sft;                        // 2^(s-1) < d <= 2^s, s >= 1
+    const unsigned long long num = 1ULL << (31 + sft);
+    *magic = (unsigned)((num + (unsigned long long)d - 1) / (unsigned long long)d);
+    *shift = sft - 1;                                      // mulhi drops 32 bits; 31 + s - 32 remain
+}
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2, bool FAST = false>
 __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParams p) {
+    static_assert(!(CONV && FAST), "FAST addressing is for plain GEMMs");
     constexpr int NW = WM * WN;
+    constexpr bool FRAG_PIPE = (NW == 4) && (BM == 256) && (BN == 256);
+#ifndef CVAR_DMA_EARLY
+#define CVAR_DMA_EARLY 1
+#endif
+    constexpr int DMA_EARLY = CVAR_DMA_EARLY;
     constexpr int ES = sizeof(T);
     constexpr int KCH = 16 / ES;         // elements per 16-byte chunk
     constexpr int KT = 128 / ES;         // elements of K per tile
@@ -107,6 +134,26 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             a_ptr[jj] = (m < p.M) ? Abase + ((long)m * p.lda + a_k0[jj]) * ES : nullptr;
         }
     }
+    // FAST (host guarantees K % KT == 0 and 32-bit row offsets): a piece's address is a wave-uniform tile base that advances
+    // by 128 B per K tile (scalar arithmetic) plus a per-lane 32-bit offset that never changes -> no vector address math in the
+    // K loop.  Rows past M / N are clamped to the last valid row: they only feed output rows / columns that are never stored.
+    unsigned a_off[A_PER_W], w_off[B_PER_W];
+    const char* const a_tile = Abase + (long)m0 * p.lda * ES;
+    const char* const w_tile = Wbase + (long)n0 * p.ldw * ES;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_tile, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_tile, 0, 0x7fffffff, 0x00020000);
+    if (FAST) {
+#pragma unroll
+        for (int jj = 0; jj < A_PER_W; ++jj) {
+            const int row = (wave + jj * NW) * 8 + lr;
+            a_off[jj] = (unsigned)min(row, p.M - 1 - m0) * (unsigned)(p.lda * ES) + (unsigned)((slot ^ ((row >> 1) & 7)) * 16);
+        }
+#pragma unroll
+        for (int jj = 0; jj < B_PER_W; ++jj) {
+            const int row = (wave + jj * NW) * 8 + lr;
+            w_off[jj] = (unsigned)min(row, p.N - 1 - n0) * (unsigned)(p.ldw * ES) + (unsigned)((slot ^ ((row >> 1) & 7)) * 16);
+        }
+    }
     const char* w_ptr[B_PER_W];
     int w_k0[B_PER_W];
 #pragma unroll
@@ -120,8 +167,19 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     }
 
     // one 1-KiB DMA piece of tile kt: idx < A_PER_W -> A operand, else W operand
+    // the K loop issues pieces unconditionally (past the last tile it re-fetches the last one into a stage nobody reads), so
+    // that its body is one basic block and the scheduler can place DMA issue and address math between MFMAs
     auto issue_one = [&](int kt, int stage, int idx) {
         char* sbase = smem + stage * STAGE;
+        if (FAST) {
+            // buffer_load_dwordx4 v_off, s[rsrc], s_koff offen lds: resource and K offset are scalar, the lane offset is fixed
+            if (idx < A_PER_W)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(sbase + (wave + idx * NW) * 1024), 16, (int)a_off[idx], kt * 128, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(sbase + BM * 128 + (wave + (idx - A_PER_W) * NW) * 1024), 16,
+                                                         (int)w_off[idx - A_PER_W], kt * 128, 0, 0);
+            return;
+        }
         if (idx < A_PER_W) {
             const int jj = idx;
             const int j = wave + jj * NW;
@@ -144,8 +202,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                     }
                     if (ok) src = Abase + ((((long)a_b[jj] * p.Hin + iy) * p.Win + ix) * p.Cin + ci) * ES;
                 }
-                int nci = ci + KT, ntap = tap;
-                while (nci >= p.Cin) { nci -= p.Cin; ++ntap; }
+                int nci = ci + p.cv_rem, ntap = tap + p.cv_adv;
+                if (nci >= p.Cin) { nci -= p.Cin; ++ntap; }
                 a_ci[jj] = nci; a_tap[jj] = ntap;
             } else {
                 if (a_ptr[jj] != nullptr && k < p.K) src = a_ptr[jj] + (long)kt * 128;
@@ -183,20 +241,61 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     constexpr int PF = NSTAGE - 1;
 #pragma unroll
     for (int t = 0; t < PF; ++t) {
-        if (kt_lo + t < nk) {
 #pragma unroll
-            for (int idx = 0; idx < NL; ++idx) issue_one(kt_lo + t, t, idx);
-        }
+        for (int idx = 0; idx < NL; ++idx) issue_one(min(kt_lo + t, nk - 1), t, idx);
     }
     int cur = 0;
+#ifdef CVAR_GEMM_TIMING
+    unsigned long long dbg_comp = 0, dbg_vm = 0, dbg_bar = 0, dbg_last = 0;
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
+#endif
     for (int kt = kt_lo; kt < nk; ++kt) {
-        const bool more = kt + PF < nk;
-        if (PF > 1 && kt + PF - 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * NL) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ktn = min(kt + PF, nk - 1);
+#ifdef CVAR_GEMM_TIMING
+        const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+#endif
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * NL) : "memory");   // uniform: dead pieces keep the count regular
+#ifdef CVAR_GEMM_TIMING
+        const unsigned long long tq1 = __builtin_amdgcn_s_memtime();
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef CVAR_GEMM_TIMING
+        const unsigned long long tq2 = __builtin_amdgcn_s_memtime();
+        if (kt > kt_lo) dbg_comp += tq0 - dbg_last;
+        dbg_vm += tq1 - tq0; dbg_bar += tq2 - tq1; dbg_last = tq2;
+#endif
         const int nxt = (cur + PF) % NSTAGE;
         const char* As = smem + cur * STAGE + (wm * SUB_M + lrow) * 128;
         const char* Bs = smem + cur * STAGE + BM * 128 + (wn * SUB_N + lrow) * 128;
+        if constexpr (ES == 2 && FRAG_PIPE) {
+            // one wave per SIMD (accumulators in AGPRs): nothing else hides the ds_read -> MFMA latency, so the fragments of
+            // k-step ks+1 are fetched into a second register set before the MFMAs of k-step ks are issued
+            bf16x8_t a[2][MI], b[2][NJ];
+            auto read_frag = [&](int buf, int ks1, int r) {      // r < MI: A fragment r, else W fragment r - MI
+                const int c = ((2 * ks1 + hi) ^ sw) * 16;
+                if (r < MI) a[buf][r] = *(const bf16x8_t*)(As + r * 32 * 128 + c);
+                else b[buf][r - MI] = *(const bf16x8_t*)(Bs + (r - MI) * 32 * 128 + c);
+            };
+#pragma unroll
+            for (int r = 0; r < MI + NJ; ++r) read_frag(0, 0, r);
+            // The issue order is written out by hand and pinned with sched_barrier(0): per MFMA at most one fragment read
+            // (every second MFMA) and one DMA piece with its address math (every fourth), so the matrix pipe never waits
+            // behind a bunch of LDS / DMA issues.
+            static_assert(MI * NJ == 16 && MI + NJ == 8 && NL == 16, "schedule below is written for the 128x128 wave tile");
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int q = 0; q < MI * NJ; ++q) {
+                    const int i = q / NJ, j = q % NJ;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
+                    if (ks < 3 && (q & 1) == 0) read_frag((ks + 1) & 1, ks + 1, q >> 1);
+                    if (DMA_EARLY == 2) { if (ks == 0) issue_one(ktn, nxt, q); }
+                    else if (DMA_EARLY == 1) { if (ks < 2 && (q & 1) == 1) issue_one(ktn, nxt, ks * 8 + (q >> 1)); }
+                    else if ((q & 3) == 3) issue_one(ktn, nxt, ks * 4 + (q >> 2));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int c = ((2 * ks + hi) ^ sw) * 16;
@@ -206,10 +305,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                 for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8_t*)(As + i * 32 * 128 + c);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) b[j] = *(const bf16x8_t*)(Bs + j * 32 * 128 + c);
-                if (more) {
 #pragma unroll
-                    for (int idx = ks * NL / 4; idx < (ks + 1) * NL / 4; ++idx) issue_one(kt + PF, nxt, idx);
-                }
+                for (int idx = ks * NL / 4; idx < (ks + 1) * NL / 4; ++idx) issue_one(ktn, nxt, idx);
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -221,10 +318,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                 for (int i = 0; i < MI; ++i) a[i] = *(const f32x4_t*)(As + i * 32 * 128 + c);
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) b[j] = *(const f32x4_t*)(Bs + j * 32 * 128 + c);
-                if (more) {
 #pragma unroll
-                    for (int idx = ks * NL / 4; idx < (ks + 1) * NL / 4; ++idx) issue_one(kt + PF, nxt, idx);
-                }
+                for (int idx = ks * NL / 4; idx < (ks + 1) * NL / 4; ++idx) issue_one(ktn, nxt, idx);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -237,6 +332,9 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         cur = (cur + 1) % NSTAGE;
     }
+#ifdef CVAR_GEMM_TIMING
+    const unsigned long long dbg_t1 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
 
     // ---- epilogue: accumulators -> LDS (per-wave region, 32 rows at a time) -> row-major 8-wide vectors, so that
@@ -255,22 +353,32 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                         (!p.residual || (((p.ldr & 7) == 0) && ((p.strideR & 7) == 0) && (((uintptr_t)p.residual & 15) == 0))) &&
                         (!p.gate || (((p.ldg & 3) == 0) && (((uintptr_t)p.gate & 15) == 0))) &&
                         (!p.bias || (((uintptr_t)p.bias & 15) == 0));
+    // per-lane constants of the row-major phase: the column group never changes, so bias is loaded once
+    const int n = n0 + wn * SUB_N + ecol;
+    const bool lane_on = (erow < RPP) && (n < p.N);
+    float bias8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias8[e] = 0.0f;
+    if (vec_ok && p.bias && lane_on) {
+        const f32x4_t b0 = *(const f32x4_t*)(p.bias + n), b1 = *(const f32x4_t*)(p.bias + n + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
+    }
+    // The staging region is private to the wave and one wave's LDS operations execute in order, so the 2*MI passes need no
+    // workgroup barrier between their write and read halves.
 #pragma clang loop unroll(full)
     for (int ih = 0; ih < 2 * MI; ++ih) {
         const int i = ih >> 1, half = ih & 1;             // rows 16*half .. 16*half+15 of block i <-> regs 8*half .. 8*half+7
-        __syncthreads();
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r8 = 0; r8 < 8; ++r8)
                 stg[((r8 & 3) + 8 * (r8 >> 2) + 4 * hi) * EROW + j * 32 + lrow] = acc[i][j][8 * half + r8];
-        __syncthreads();
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int rr = ps * RPP + erow;
             const int m = m0 + wm * SUB_M + i * 32 + 16 * half + rr;
-            const int n = n0 + wn * SUB_N + ecol;
-            if (erow >= RPP || rr >= 16 || m >= p.M || n >= p.N) continue;
+            if (!lane_on || rr >= 16 || m >= p.M) continue;
             float v[8];
             {
                 const f32x4_t a0 = *(const f32x4_t*)(stg + rr * EROW + ecol);
@@ -280,19 +388,16 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             }
             long orow = m;
             if (p.remap_l > 0) {
-                const int sq = m / p.remap_l;
+                const int sq = fast_div(m, p.remap_magic, p.remap_shift);
                 orow = (long)sq * p.remap_L + p.remap_off + (m - sq * p.remap_l);
             }
-            const float* grow = p.gate ? p.gate + (long)(m / p.gate_rows) * p.ldg : nullptr;
+            const float* grow = p.gate ? p.gate + (long)fast_div(m, p.gate_magic, p.gate_shift) * p.ldg : nullptr;
             if (vec_ok) {
-                if (p.bias) {
-                    const f32x4_t b0 = *(const f32x4_t*)(p.bias + n), b1 = *(const f32x4_t*)(p.bias + n + 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-                }
+                for (int e = 0; e < 8; ++e) v[e] += bias8[e];
                 if (p.act == CVAR_ACT_GELU_TANH) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gelu_tanh_f(v[e]);
+                    for (int e = 0; e < 8; ++e) v[e] = (ES == 2) ? gelu_tanh_fast(v[e]) : gelu_tanh_f(v[e]);
                 }
                 if (grow) {
                     const f32x4_t g0 = *(const f32x4_t*)(grow + n), g1 = *(const f32x4_t*)(grow + n + 4);
@@ -311,6 +416,9 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                         for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
                     }
                 }
+#if defined(CVAR_ABL_NOSTORE)
+                if (v[0] == 1.2345e30f)
+#endif
                 if (p.out_dtype == CVAR_BF16) {
                     *(bf16x8_t*)((bf16_t*)Cb + cz + orow * p.ldc + n) = pack_bf16x8(v);
                 } else {
@@ -332,6 +440,13 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             }
         }
     }
+#ifdef CVAR_GEMM_TIMING
+    if (lane == 0 && blockIdx.x < 64) {
+        const unsigned long long dbg_t2 = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = cvar_gemm_dbg + (blockIdx.x * 8 + wave) * 8;
+        o[0] = dbg_comp; o[1] = dbg_vm; o[2] = dbg_bar; o[3] = dbg_t1 - dbg_t0; o[4] = dbg_t2 - dbg_t1; o[5] = nk - kt_lo; o[6] = dbg_t0; o[7] = dbg_t2;
+    }
+#endif
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE = 2>
@@ -339,12 +454,18 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     GemmParams p = gp;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
+    if (p.conv) { const int kt_e = 128 / (int)sizeof(T); p.cv_adv = kt_e / p.Cin; p.cv_rem = kt_e % p.Cin; }
     const size_t lds = NSTAGE * (BM + BN) * 128;
     const int nk_all = (p.K + (128 / (int)sizeof(T)) - 1) / (128 / (int)sizeof(T));
     const int splits = p.split_tiles > 0 ? (nk_all + p.split_tiles - 1) / p.split_tiles : 1;
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits, (unsigned)batch), block(WM * WN * 64);
     if (p.conv) {
         auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, true, NSTAGE>;
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
+    } else if (p.K % (128 / (int)sizeof(T)) == 0 && (long)(BM - 1) * p.lda * (long)sizeof(T) + (long)p.K * (long)sizeof(T) < (1L << 31) &&
+               (long)(BN - 1) * p.ldw * (long)sizeof(T) + (long)p.K * (long)sizeof(T) < (1L << 31)) {
+        auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, false, NSTAGE, true>;
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
     } else {
@@ -372,6 +493,9 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     // per barrier; measured +10..15 % over 128x128 on the d24 shapes.  CVAR_GEMM_CFG=0 forces the 128x128 tile (A/B runs).
     const int ov = gemm_cfg_override();
     if (ov == 2 && p.M >= 2048 && p.N % 128 == 0) return launch_cfg<T, 256, 128, 4, 2, 3>(p, batch, st);
+    // bf16: 4 waves (2x2), one per SIMD, 128x128 per wave with the accumulators in AGPRs and a hand-placed issue order;
+    // CVAR_GEMM_CFG=1 selects the 8-wave (2x4) variant instead (A/B runs; also the fp32 parity-mode configuration)
+    if (sizeof(T) == 2 && ov != 0 && ov != 1 && p.M >= 2048 && p.N % 256 == 0) return launch_cfg<T, 256, 256, 2, 2>(p, batch, st);
     if (ov != 0 && p.M >= 2048 && p.N % 256 == 0) return launch_cfg<T, 256, 256, 2, 4>(p, batch, st);
     return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
 }
@@ -392,10 +516,10 @@ __global__ __launch_bounds__(256) void cvar_splitk_epilogue_kernel(const float* 
         }
         long orow = m;
         if (p.remap_l > 0) {
-            const int sq = m / p.remap_l;
+            const int sq = fast_div(m, p.remap_magic, p.remap_shift);
             orow = (long)sq * p.remap_L + p.remap_off + (m - sq * p.remap_l);
         }
-        const float* grow = p.gate ? p.gate + (long)(m / p.gate_rows) * p.ldg : nullptr;
+        const float* grow = p.gate ? p.gate + (long)fast_div(m, p.gate_magic, p.gate_shift) * p.ldg : nullptr;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float x = v[e] * p.alpha;
@@ -447,6 +571,9 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     p.C = d->C; p.out_dtype = d->out_dtype; p.ldc = d->ldc;
     p.remap_l = d->remap_l; p.remap_L = d->remap_L; p.remap_off = d->remap_off;
     p.tiles_m = p.tiles_n = 0;
+    p.cv_adv = p.cv_rem = 0;
+    make_fast_div(p.remap_l, &p.remap_magic, &p.remap_shift);
+    make_fast_div(p.gate ? p.gate_rows : 1, &p.gate_magic, &p.gate_shift);
     p.split_tiles = 0; p.split_stride = 0;
     hipStream_t st = as_stream(stream);
     // split-K decision: plain (non-conv, unbatched) GEMMs whose tile count leaves most CUs idle

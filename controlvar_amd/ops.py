@@ -15,7 +15,7 @@ from ._lib import ACT_GELU_TANH, ACT_NONE, CVAR_BF16, CVAR_F32, GemmDesc, check
 
 _DT = {torch.float32: CVAR_F32, torch.bfloat16: CVAR_BF16}
 
-# bench.py sets this to a list to collect (start_event, end_event, algorithmic_flops) per GEMM launch
+# bench.py sets this to a list to collect (start_event, end_event, algorithmic_flops, shape tag) per GEMM launch
 GEMM_PROFILE = None
 
 
@@ -88,7 +88,8 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
         e0.record()
         check(_lib.load().cvar_gemm(C.byref(d), _stream()), 'cvar_gemm')
         e1.record()
-        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K * batch))
+        tag = ('conv' if conv else 'gemm', M, N, K, batch, 'gate' if gate is not None else ('res' if residual is not None else ('act' if act else ('remap' if remap is not None else 'plain'))), str(out.dtype)[6:])
+        GEMM_PROFILE.append((e0, e1, 2.0 * M * N * K * batch, tag))
     return out
 
 
