@@ -16,10 +16,13 @@
 //   * blockIdx -> tile mapping is XCD-aware (contiguous tile ranges per XCD L2) and grouped along M.
 #include "cvar_common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 __device__ __attribute__((aligned(16))) unsigned int cvar_zero_chunk[4] = {0u, 0u, 0u, 0u};
 #ifdef CVAR_GEMM_TIMING
 __device__ unsigned long long cvar_gemm_dbg[64 * 8 * 8];
+__device__ unsigned long long cvar_gemm_dbg_tot[8];
+extern "C" int cvar_gemm_dbg_tot_read(unsigned long long* host, int reset) { int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cvar_gemm_dbg_tot), 64); if (reset) { unsigned long long z[8] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(cvar_gemm_dbg_tot), z, 64); } return rc; }
 extern "C" int cvar_gemm_dbg_read(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cvar_gemm_dbg), sizeof(unsigned long long) * 64 * 8 * 8); }
 #endif
 
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     }
     int cur = 0;
 #ifdef CVAR_GEMM_TIMING
-    unsigned long long dbg_comp = 0, dbg_vm = 0, dbg_bar = 0, dbg_last = 0;
+    unsigned long long dbg_comp = 0, dbg_vm = 0, dbg_bar = 0, dbg_last = 0, dbg_ew = 0;
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
 #endif
     for (int kt = kt_lo; kt < nk; ++kt) {
@@ -364,16 +367,113 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
     }
+    // Specialised epilogues for the combinations the hot path uses on the large tiles: every flag is a compile-time constant,
+    // pointers are hoisted to one per-lane base plus a wave-uniform row offset per pass, so a pass is ~20 vector instructions
+    // instead of the generic code's flag tests and 64-bit address rebuilds.
+    constexpr bool SPEC = (BM * BN >= 128 * 160) && (16 % RPP == 0);
+    bool done = false;
+    if constexpr (SPEC) {
+        auto run = [&](auto OUTBF, auto ACT, auto GATE, auto RES, auto REMAP) {
+            constexpr bool out_bf = decltype(OUTBF)::value, gate = decltype(GATE)::value, remap = decltype(REMAP)::value;
+            constexpr int act = decltype(ACT)::value, res = decltype(RES)::value;          // res: 0 none, 1 fp32, 2 bf16
+            constexpr int OES = out_bf ? 2 : 4, RES_ES = res == 2 ? 2 : 4;
+            const int mrow = m0 + wm * SUB_M + erow;
+            const float* stg_r = stg + erow * EROW + ecol;
+            char* c_lane = Cb + (cz + n) * OES;
+            const char* r_lane = res ? (const char*)p.residual + (rz + n) * RES_ES : nullptr;
+            const float* g_lane = gate ? p.gate + n : nullptr;
+#pragma clang loop unroll(full)
+            for (int ih = 0; ih < 2 * MI; ++ih) {
+                const int i = ih >> 1, half = ih & 1;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8)
+                        stg[((r8 & 3) + 8 * (r8 >> 2) + 4 * hi) * EROW + j * 32 + lrow] = acc[i][j][8 * half + r8];
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int roff = i * 32 + 16 * half + ps * RPP;          // wave-uniform, known at compile time
+                    const int m = mrow + roff;
+                    if (lane_on && m < p.M) {
+                        const f32x4_t a0 = *(const f32x4_t*)(stg_r + ps * RPP * EROW);
+                        const f32x4_t a1 = *(const f32x4_t*)(stg_r + ps * RPP * EROW + 4);
+                        float v[8];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[e] = a0[e] * p.alpha + bias8[e]; v[4 + e] = a1[e] * p.alpha + bias8[4 + e]; }
+                        if constexpr (act == CVAR_ACT_GELU_TANH) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = (ES == 2) ? gelu_tanh_fast(v[e]) : gelu_tanh_f(v[e]);
+                        }
+                        if constexpr (gate) {
+                            const float* gp = g_lane + (long)fast_div(m, p.gate_magic, p.gate_shift) * p.ldg;
+                            const f32x4_t g0 = *(const f32x4_t*)gp, g1 = *(const f32x4_t*)(gp + 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v[e] *= g0[e]; v[4 + e] *= g1[e]; }
+                        }
+                        if constexpr (res == 1) {
+                            const float* rp = (const float*)(r_lane + (long)m * p.ldr * 4);
+                            const f32x4_t r0 = *(const f32x4_t*)rp, r1 = *(const f32x4_t*)(rp + 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                        } else if constexpr (res == 2) {
+                            const bf16x8_t rv = *(const bf16x8_t*)(r_lane + (long)m * p.ldr * 2);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rv[e]);
+                        }
+                        long orow = m;
+                        if constexpr (remap) {
+                            const int sq = fast_div(m, p.remap_magic, p.remap_shift);
+                            orow = (long)sq * p.remap_L + p.remap_off + (m - sq * p.remap_l);
+                        }
+                        char* cp = c_lane + orow * p.ldc * OES;
+                        if constexpr (out_bf) {
+                            *(bf16x8_t*)cp = pack_bf16x8(v);
+                        } else {
+                            const f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                            *(f32x4_t*)cp = o0;
+                            *(f32x4_t*)(cp + 16) = o1;
+                        }
+                    }
+                }
+            }
+        };
+        using std::integral_constant;
+        typedef integral_constant<bool, true> Y; typedef integral_constant<bool, false> NO;
+        typedef integral_constant<int, 0> I0; typedef integral_constant<int, 1> I1; typedef integral_constant<int, 2> I2;
+        const bool obf = p.out_dtype == CVAR_BF16, rm = p.remap_l > 0;
+        if (vec_ok) {
+            if (!p.gate && !p.residual && p.act == CVAR_ACT_NONE) {
+                if (obf && rm) { run(Y{}, I0{}, NO{}, I0{}, Y{}); done = true; }
+                else if (obf && !rm) { run(Y{}, I0{}, NO{}, I0{}, NO{}); done = true; }
+                else if (!obf && !rm) { run(NO{}, I0{}, NO{}, I0{}, NO{}); done = true; }
+            } else if (!p.gate && !p.residual && p.act == CVAR_ACT_GELU_TANH && obf && !rm) {
+                run(Y{}, I1{}, NO{}, I0{}, NO{}); done = true;
+            } else if (p.gate && p.residual && p.res_dtype == CVAR_F32 && p.act == CVAR_ACT_NONE && !obf && !rm) {
+                run(NO{}, I0{}, Y{}, I1{}, NO{}); done = true;
+            } else if (!p.gate && p.residual && p.res_dtype == CVAR_BF16 && p.act == CVAR_ACT_NONE && obf && !rm) {
+                run(Y{}, I0{}, NO{}, I2{}, NO{}); done = true;
+            }
+        }
+    }
+    if (!done) {
     // The staging region is private to the wave and one wave's LDS operations execute in order, so the 2*MI passes need no
     // workgroup barrier between their write and read halves.
 #pragma clang loop unroll(full)
     for (int ih = 0; ih < 2 * MI; ++ih) {
         const int i = ih >> 1, half = ih & 1;             // rows 16*half .. 16*half+15 of block i <-> regs 8*half .. 8*half+7
+#ifdef CVAR_GEMM_TIMING
+        const unsigned long long te0 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r8 = 0; r8 < 8; ++r8)
                 stg[((r8 & 3) + 8 * (r8 >> 2) + 4 * hi) * EROW + j * 32 + lrow] = acc[i][j][8 * half + r8];
+#ifdef CVAR_GEMM_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long te1 = __builtin_amdgcn_s_memtime();
+        dbg_ew += te1 - te0;
+#endif
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             const int rr = ps * RPP + erow;
@@ -440,11 +540,17 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             }
         }
     }
+    }   // generic epilogue
 #ifdef CVAR_GEMM_TIMING
     if (lane == 0 && blockIdx.x < 64) {
         const unsigned long long dbg_t2 = __builtin_amdgcn_s_memtime();
         unsigned long long* o = cvar_gemm_dbg + (blockIdx.x * 8 + wave) * 8;
         o[0] = dbg_comp; o[1] = dbg_vm; o[2] = dbg_bar; o[3] = dbg_t1 - dbg_t0; o[4] = dbg_t2 - dbg_t1; o[5] = nk - kt_lo; o[6] = dbg_t0; o[7] = dbg_t2;
+    }
+    if (lane == 0 && wave == 0) {       // totals over every tile of the launch
+        const unsigned long long dbg_t2 = __builtin_amdgcn_s_memtime();
+        atomicAdd(&cvar_gemm_dbg_tot[0], dbg_t1 - dbg_t0); atomicAdd(&cvar_gemm_dbg_tot[1], dbg_t2 - dbg_t1); atomicAdd(&cvar_gemm_dbg_tot[2], 1ULL);
+        atomicAdd(&cvar_gemm_dbg_tot[6], dbg_ew); atomicAdd(&cvar_gemm_dbg_tot[3], dbg_vm); atomicAdd(&cvar_gemm_dbg_tot[4], dbg_bar); atomicAdd(&cvar_gemm_dbg_tot[5], dbg_comp);
     }
 #endif
 }

@@ -7,9 +7,15 @@ dev = torch.device('cuda:0'); T = torch.bfloat16
 M, N, K = 131072, int(sys.argv[1]) if len(sys.argv) > 1 else 6144, int(sys.argv[2]) if len(sys.argv) > 2 else 1536
 A = torch.randn(M, K, device=dev).to(T); W = (torch.randn(N, K, device=dev) / K ** 0.5).to(T)
 out = torch.empty(M, N, device=dev, dtype=T)
-for _ in range(3): ops.gemm(A, W, out, M=M, N=N, K=K)
-torch.cuda.synchronize()
 lib = _lib.load()
+lib.cvar_gemm_dbg_tot_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+tot = (ctypes.c_ulonglong * 8)()
+for _ in range(2): ops.gemm(A, W, out, M=M, N=N, K=K)
+torch.cuda.synchronize(); lib.cvar_gemm_dbg_tot_read(tot, 1)
+ops.gemm(A, W, out, M=M, N=N, K=K)
+torch.cuda.synchronize(); lib.cvar_gemm_dbg_tot_read(tot, 1)
+t = [float(x) for x in tot]
+print(f'ALL TILES ({t[2]:.0f}): loop {t[0] / t[2]:.0f}  epilogue {t[1] / t[2]:.0f} (staging writes {t[6] / t[2]:.0f})  per K tile: compute {t[5] / t[2] / (K / 64 - 1):.0f} vm {t[3] / t[2] / (K / 64):.0f} barrier {t[4] / t[2] / (K / 64):.0f}')
 buf = (ctypes.c_ulonglong * (64 * 8 * 8))()
 lib.cvar_gemm_dbg_read.argtypes = [ctypes.c_void_p]
 assert lib.cvar_gemm_dbg_read(buf) == 0
