@@ -367,6 +367,10 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #pragma unroll
         for (int e = 0; e < 4; ++e) { bias8[e] = b0[e]; bias8[4 + e] = b1[e]; }
     }
+    // Pin the bias registers as "arrived" here, on a path every lane takes: otherwise the load stays pending across the
+    // predicated passes below and the compiler re-emits s_waitcnt vmcnt(0) in each of them, which also waits for the
+    // previous pass's stores (vmcnt counts stores on gfx9) and serialises the whole epilogue on store latency.
+    asm volatile("" : "+v"(bias8[0]), "+v"(bias8[1]), "+v"(bias8[2]), "+v"(bias8[3]), "+v"(bias8[4]), "+v"(bias8[5]), "+v"(bias8[6]), "+v"(bias8[7]));
     // Specialised epilogues for the combinations the hot path uses on the large tiles: every flag is a compile-time constant,
     // pointers are hoisted to one per-lane base plus a wave-uniform row offset per pass, so a pass is ~20 vector instructions
     // instead of the generic code's flag tests and 64-bit address rebuilds.
@@ -385,6 +389,25 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #pragma clang loop unroll(full)
             for (int ih = 0; ih < 2 * MI; ++ih) {
                 const int i = ih >> 1, half = ih & 1;
+                // gate / residual operands of all NPASS passes are requested first: their latency hides behind the staging
+                // writes, and the passes below then never wait on a load that was queued behind the previous pass's store
+                f32x4_t gq[gate ? NPASS : 1][2], rq[res == 1 ? NPASS : 1][2];
+                bf16x8_t rb[res == 2 ? NPASS : 1];
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const int m = mrow + i * 32 + 16 * half + ps * RPP;
+                    if (lane_on && m < p.M) {
+                        if constexpr (gate) {
+                            const float* gp = g_lane + (long)fast_div(m, p.gate_magic, p.gate_shift) * p.ldg;
+                            gq[ps][0] = *(const f32x4_t*)gp; gq[ps][1] = *(const f32x4_t*)(gp + 4);
+                        }
+                        if constexpr (res == 1) {
+                            const float* rp = (const float*)(r_lane + (long)m * p.ldr * 4);
+                            rq[ps][0] = *(const f32x4_t*)rp; rq[ps][1] = *(const f32x4_t*)(rp + 4);
+                        }
+                        if constexpr (res == 2) rb[ps] = *(const bf16x8_t*)(r_lane + (long)m * p.ldr * 2);
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -405,20 +428,15 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                             for (int e = 0; e < 8; ++e) v[e] = (ES == 2) ? gelu_tanh_fast(v[e]) : gelu_tanh_f(v[e]);
                         }
                         if constexpr (gate) {
-                            const float* gp = g_lane + (long)fast_div(m, p.gate_magic, p.gate_shift) * p.ldg;
-                            const f32x4_t g0 = *(const f32x4_t*)gp, g1 = *(const f32x4_t*)(gp + 4);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { v[e] *= g0[e]; v[4 + e] *= g1[e]; }
+                            for (int e = 0; e < 4; ++e) { v[e] *= gq[ps][0][e]; v[4 + e] *= gq[ps][1][e]; }
                         }
                         if constexpr (res == 1) {
-                            const float* rp = (const float*)(r_lane + (long)m * p.ldr * 4);
-                            const f32x4_t r0 = *(const f32x4_t*)rp, r1 = *(const f32x4_t*)(rp + 4);
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+                            for (int e = 0; e < 4; ++e) { v[e] += rq[ps][0][e]; v[4 + e] += rq[ps][1][e]; }
                         } else if constexpr (res == 2) {
-                            const bf16x8_t rv = *(const bf16x8_t*)(r_lane + (long)m * p.ldr * 2);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rv[e]);
+                            for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rb[ps][e]);
                         }
                         long orow = m;
                         if constexpr (remap) {
