@@ -68,7 +68,7 @@ template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2,
 __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParams p) {
     static_assert(!(CONV && FAST), "FAST addressing is for plain GEMMs");
     constexpr int NW = WM * WN;
-    constexpr bool FRAG_PIPE = (NW == 4) && (BM == 256) && (BN == 256);
+    constexpr bool FRAG_PIPE = (BM == 256) && (BN == 256) && !CONV;
 #ifndef CVAR_DMA_EARLY
 #define CVAR_DMA_EARLY 1
 #endif
@@ -284,17 +284,32 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             // The issue order is written out by hand and pinned with sched_barrier(0): per MFMA at most one fragment read
             // (every second MFMA) and one DMA piece with its address math (every fourth), so the matrix pipe never waits
             // behind a bunch of LDS / DMA issues.
-            static_assert(MI * NJ == 16 && MI + NJ == 8 && NL == 16, "schedule below is written for the 128x128 wave tile");
+            constexpr int NM = MI * NJ, NR = MI + NJ;           // MFMAs / fragment reads per k-step
+            static_assert(NR <= NM && (NL % 2) == 0 && NL / 2 <= NM, "schedule needs a slot per read and per early DMA piece");
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-                for (int q = 0; q < MI * NJ; ++q) {
+                for (int q = 0; q < NM; ++q) {
                     const int i = q / NJ, j = q % NJ;
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
-                    if (ks < 3 && (q & 1) == 0) read_frag((ks + 1) & 1, ks + 1, q >> 1);
-                    if (DMA_EARLY == 2) { if (ks == 0) issue_one(ktn, nxt, q); }
-                    else if (DMA_EARLY == 1) { if (ks < 2 && (q & 1) == 1) issue_one(ktn, nxt, ks * 8 + (q >> 1)); }
-                    else if ((q & 3) == 3) issue_one(ktn, nxt, ks * 4 + (q >> 2));
+                    // reads of k-step ks+1: read r goes behind MFMA floor(r * NM / NR) (evenly spread, all done before the last MFMA)
+                    if (ks < 3) {
+#pragma unroll
+                        for (int r = 0; r < NR; ++r)
+                            if ((r * NM) / NR == q) read_frag((ks + 1) & 1, ks + 1, r);
+                    }
+                    // DMA pieces of the next tile: all inside k-steps 0 and 1 (so they have k-steps 2, 3 to land), evenly spread
+                    if (DMA_EARLY == 1) {
+                        if (ks < 2) {
+#pragma unroll
+                            for (int t = 0; t < NL / 2; ++t)
+                                if ((t * NM) / (NL / 2) + (NM / (NL / 2) - 1) == q) issue_one(ktn, nxt, ks * (NL / 2) + t);
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < NL / 4; ++t)
+                            if ((t * NM) / (NL / 4) + (NM / (NL / 4) - 1) == q) issue_one(ktn, nxt, ks * (NL / 4) + t);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -374,7 +389,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     // Specialised epilogues for the combinations the hot path uses on the large tiles: every flag is a compile-time constant,
     // pointers are hoisted to one per-lane base plus a wave-uniform row offset per pass, so a pass is ~20 vector instructions
     // instead of the generic code's flag tests and 64-bit address rebuilds.
-    constexpr bool SPEC = (BM * BN >= 128 * 160) && (16 % RPP == 0);
+    constexpr bool SPEC = (BM * BN >= 128 * 160);
     bool done = false;
     if constexpr (SPEC) {
         auto run = [&](auto OUTBF, auto ACT, auto GATE, auto RES, auto REMAP) {
@@ -396,7 +411,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) {
                     const int m = mrow + i * 32 + 16 * half + ps * RPP;
-                    if (lane_on && m < p.M) {
+                    if (lane_on && m < p.M && ((16 % RPP == 0) || ps * RPP + erow < 16)) {
                         if constexpr (gate) {
                             const float* gp = g_lane + (long)fast_div(m, p.gate_magic, p.gate_shift) * p.ldg;
                             gq[ps][0] = *(const f32x4_t*)gp; gq[ps][1] = *(const f32x4_t*)(gp + 4);
@@ -417,7 +432,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                 for (int ps = 0; ps < NPASS; ++ps) {
                     const int roff = i * 32 + 16 * half + ps * RPP;          // wave-uniform, known at compile time
                     const int m = mrow + roff;
-                    if (lane_on && m < p.M) {
+                    if (lane_on && m < p.M && ((16 % RPP == 0) || ps * RPP + erow < 16)) {
                         const f32x4_t a0 = *(const f32x4_t*)(stg_r + ps * RPP * EROW);
                         const f32x4_t a1 = *(const f32x4_t*)(stg_r + ps * RPP * EROW + 4);
                         float v[8];
