@@ -5,7 +5,7 @@ Units/corrections as MI355X_MICROARCH.md section HBM prescribes: the counters ar
 import csv, glob, json, sys, collections
 out = {}
 for tag in ('fetch', 'write'):
-    f = glob.glob(f'gpurun_out/pmc_{tag}/*counter_collection.csv')
+    f = glob.glob(f'gpurun_out/pmc_{tag}/**/*counter_collection.csv', recursive=True)
     if not f:
         continue
     acc = collections.defaultdict(list)
