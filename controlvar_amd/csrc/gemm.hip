@@ -41,6 +41,7 @@ struct GemmParams {
     int remap_l, remap_L, remap_off;
     int tiles_m, tiles_n;
     int cv_adv, cv_rem;       // conv: a K tile advances (tap, ci) by (KT / Cin, KT % Cin) plus one carry
+    unsigned conv_bytes;      // conv FAST: bytes of the NHWC input of one batch slice (buffer range: out-of-range offsets read zeros)
     unsigned remap_magic, gate_magic; int remap_shift, gate_shift;   // exact m / remap_l and m / gate_rows for 0 <= m < 2^31 (fast_div)
     int split_tiles;          // split-K: K tiles per blockIdx.y slice (0 = no split); partials go to C + blockIdx.y * split_stride
     long split_stride;
@@ -66,9 +67,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2, bool FAST = false>
 __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParams p) {
-    static_assert(!(CONV && FAST), "FAST addressing is for plain GEMMs");
     constexpr int NW = WM * WN;
-    constexpr bool FRAG_PIPE = (BM == 256) && (BN == 256) && !CONV;
+    constexpr bool FRAG_PIPE = (BM == 256) && (!CONV || FAST);
 #ifndef CVAR_DMA_EARLY
 #define CVAR_DMA_EARLY 1
 #endif
@@ -141,22 +141,67 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     // by 128 B per K tile (scalar arithmetic) plus a per-lane 32-bit offset that never changes -> no vector address math in the
     // K loop.  Rows past M / N are clamped to the last valid row: they only feed output rows / columns that are never stored.
     unsigned a_off[A_PER_W], w_off[B_PER_W];
-    const char* const a_tile = Abase + (long)m0 * p.lda * ES;
+    const char* const a_tile = CONV ? Abase : Abase + (long)m0 * p.lda * ES;
     const char* const w_tile = Wbase + (long)n0 * p.ldw * ES;
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_tile, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_tile, 0, CONV ? (int)p.conv_bytes : 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_tile, 0, 0x7fffffff, 0x00020000);
-    if (FAST) {
+    // conv FAST (stride 1, no upsample, Cin % 32 == 0, input < 2 GiB): each 32-element half of a K tile lies inside ONE tap, so
+    // (tap, channel) of the two halves are wave-uniform scalars advanced per K tile; a lane keeps its pixel's byte offset and a
+    // 9-bit mask of in-range taps per piece, and because the swizzled chunk of a lane is the same for all its pieces
+    // ((row >> 1) & 7 does not depend on jj when NW is even) the half it reads from is a lane constant:
+    //   offset = pixel + (half ? delta1 : delta0),  valid = mask >> (half ? tap1 : tap0) & 1,  invalid -> out-of-range offset -> zeros
+    unsigned c_vm[CONV ? A_PER_W : 1];
+    const int lane_half = (slot ^ ((((wave * 8 + lr)) >> 1) & 7)) >> 2;
+    int cf_tap = 0, cf_ci = 0, lane_D = 0, lane_T = 31;
+    static_assert(!(CONV && FAST) || (NW % 2 == 0), "lane-constant half needs an even wave count");
+    if (FAST && !CONV) {
 #pragma unroll
         for (int jj = 0; jj < A_PER_W; ++jj) {
             const int row = (wave + jj * NW) * 8 + lr;
             a_off[jj] = (unsigned)min(row, p.M - 1 - m0) * (unsigned)(p.lda * ES) + (unsigned)((slot ^ ((row >> 1) & 7)) * 16);
         }
+    }
+    if (FAST && CONV) {
+#pragma unroll
+        for (int jj = 0; jj < A_PER_W; ++jj) {
+            const int row = (wave + jj * NW) * 8 + lr;
+            const int chunk = slot ^ ((row >> 1) & 7);
+            unsigned vm = 0;
+            const int b = a_b[jj], oy = a_oy[jj], ox = a_ox[jj];
+            if (b >= 0) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+                    if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) vm |= 1u << t;
+                }
+            }
+            c_vm[jj] = vm;
+            a_off[jj] = (unsigned)(((max(b, 0) * p.Hin + oy) * p.Win + ox) * p.Cin * ES + (chunk & 3) * 16);
+        }
+    }
+    if (FAST) {
 #pragma unroll
         for (int jj = 0; jj < B_PER_W; ++jj) {
             const int row = (wave + jj * NW) * 8 + lr;
             w_off[jj] = (unsigned)min(row, p.N - 1 - n0) * (unsigned)(p.ldw * ES) + (unsigned)((slot ^ ((row >> 1) & 7)) * 16);
         }
     }
+    // conv FAST: lane offset / tap of the NEXT tile to issue, then advance the scalar (tap, channel) state by one K tile
+    auto conv_next = [&]() {
+        const int t0 = cf_tap, c0 = cf_ci;
+        int c1 = c0 + 32, t1 = t0;
+        if (c1 >= p.Cin) { c1 -= p.Cin; ++t1; }
+        auto delta = [&](int t, int c) {
+            const int tt = min(t, 8), ky = (tt * 11) >> 5, kx = tt - ky * 3;
+            return (((ky - 1) * p.Win + (kx - 1)) * p.Cin + c) * ES;
+        };
+        const int d0 = delta(t0, c0), d1 = delta(t1, c1);
+        lane_D = lane_half ? d1 : d0;
+        lane_T = lane_half ? min(t1, 31) : min(t0, 31);
+        int c2 = c1 + 32, t2 = t1;
+        if (c2 >= p.Cin) { c2 -= p.Cin; ++t2; }
+        cf_tap = t2; cf_ci = c2;
+    };
     const char* w_ptr[B_PER_W];
     int w_k0[B_PER_W];
 #pragma unroll
@@ -176,9 +221,14 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
         char* sbase = smem + stage * STAGE;
         if (FAST) {
             // buffer_load_dwordx4 v_off, s[rsrc], s_koff offen lds: resource and K offset are scalar, the lane offset is fixed
-            if (idx < A_PER_W)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(sbase + (wave + idx * NW) * 1024), 16, (int)a_off[idx], kt * 128, 0, 0);
-            else
+            if (idx < A_PER_W) {
+                if (CONV) {
+                    const int off = ((c_vm[idx] >> lane_T) & 1u) ? (int)(a_off[idx] + (unsigned)lane_D) : (int)0x80000000;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(sbase + (wave + idx * NW) * 1024), 16, off, 0, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(sbase + (wave + idx * NW) * 1024), 16, (int)a_off[idx], kt * 128, 0, 0);
+                }
+            } else
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(sbase + BM * 128 + (wave + (idx - A_PER_W) * NW) * 1024), 16,
                                                          (int)w_off[idx - A_PER_W], kt * 128, 0, 0);
             return;
@@ -244,6 +294,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     constexpr int PF = NSTAGE - 1;
 #pragma unroll
     for (int t = 0; t < PF; ++t) {
+        if (FAST && CONV) conv_next();
 #pragma unroll
         for (int idx = 0; idx < NL; ++idx) issue_one(min(kt_lo + t, nk - 1), t, idx);
     }
@@ -268,6 +319,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
         dbg_vm += tq1 - tq0; dbg_bar += tq2 - tq1; dbg_last = tq2;
 #endif
         const int nxt = (cur + PF) % NSTAGE;
+        if (FAST && CONV) conv_next();
         const char* As = smem + cur * STAGE + (wm * SUB_M + lrow) * 128;
         const char* Bs = smem + cur * STAGE + BM * 128 + (wn * SUB_N + lrow) * 128;
         if constexpr (ES == 2 && FRAG_PIPE) {
@@ -285,7 +337,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             // (every second MFMA) and one DMA piece with its address math (every fourth), so the matrix pipe never waits
             // behind a bunch of LDS / DMA issues.
             constexpr int NM = MI * NJ, NR = MI + NJ;           // MFMAs / fragment reads per k-step
-            static_assert(NR <= NM && (NL % 2) == 0 && NL / 2 <= NM, "schedule needs a slot per read and per early DMA piece");
+            static_assert(NR <= NM && NL <= 2 * NM, "schedule needs a slot per read and per early DMA piece");
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -298,17 +350,16 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                         for (int r = 0; r < NR; ++r)
                             if ((r * NM) / NR == q) read_frag((ks + 1) & 1, ks + 1, r);
                     }
-                    // DMA pieces of the next tile: all inside k-steps 0 and 1 (so they have k-steps 2, 3 to land), evenly spread
+                    // DMA pieces of the next tile: piece t goes behind MFMA number ((t+1) * 2NM) / NL - 1 of the tile, i.e. all
+                    // inside k-steps 0 and 1 (so they have k-steps 2, 3 to land), evenly spread
                     if (DMA_EARLY == 1) {
-                        if (ks < 2) {
 #pragma unroll
-                            for (int t = 0; t < NL / 2; ++t)
-                                if ((t * NM) / (NL / 2) + (NM / (NL / 2) - 1) == q) issue_one(ktn, nxt, ks * (NL / 2) + t);
-                        }
+                        for (int t = 0; t < NL; ++t)
+                            if (((t + 1) * 2 * NM) / NL - 1 == ks * NM + q) issue_one(ktn, nxt, t);
                     } else {
 #pragma unroll
-                        for (int t = 0; t < NL / 4; ++t)
-                            if ((t * NM) / (NL / 4) + (NM / (NL / 4) - 1) == q) issue_one(ktn, nxt, ks * (NL / 4) + t);
+                        for (int t = 0; t < NL; ++t)
+                            if (((t + 1) * 4 * NM) / NL - 1 == ks * NM + q) issue_one(ktn, nxt, t);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -588,7 +639,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #endif
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE = 2>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE = 2, bool CONVFAST = false>
 static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     GemmParams p = gp;
     p.tiles_m = (p.M + BM - 1) / BM;
@@ -598,7 +649,14 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     const int nk_all = (p.K + (128 / (int)sizeof(T)) - 1) / (128 / (int)sizeof(T));
     const int splits = p.split_tiles > 0 ? (nk_all + p.split_tiles - 1) / p.split_tiles : 1;
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits, (unsigned)batch), block(WM * WN * 64);
-    if (p.conv) {
+    if constexpr (CONVFAST) {            // this configuration exists for the conv FAST kernel only
+        if (!p.conv) return CVAR_EINVAL;
+        auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, true, NSTAGE, true>;
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
+        CVAR_CHECK_LAUNCH();
+        return CVAR_OK;
+    } else if (p.conv) {
         auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, true, NSTAGE>;
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
@@ -627,11 +685,22 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     // small-M problems (early scales, ada_lin) use a 64-row tile to put more blocks on the chip
     if (p.M <= 64) return launch_cfg<T, 64, 128, 1, 4>(p, batch, st);
     // channel counts of the VQVAE (160, 320) are multiples of 160 but not of 128: a 160-wide tile wastes no MFMA work
-    if (p.N % 160 == 0 && p.N % 128 != 0 && p.M >= 4096) return launch_cfg<T, 128, 160, 4, 1>(p, batch, st);
+    if (p.N % 160 == 0 && p.N % 128 != 0 && p.M >= 4096) {
+        // stride-1 3x3 convs of the decoder / encoder trunks: 256x160 tile on the scalar-state conv addressing (conv FAST)
+        const long in_bytes = p.conv ? (long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin * (long)sizeof(T) : 0;
+        if constexpr (sizeof(T) == 2) {
+            if (p.conv && p.stride == 1 && !p.up && p.Cin % 32 == 0 && p.split_tiles == 0 && in_bytes < (1L << 31) &&
+                (long)159 * p.ldw * 2 + (long)p.K * 2 + 256 < (1L << 31) && gemm_cfg_override() != 0) {
+                GemmParams q = p;
+                q.conv_bytes = (unsigned)in_bytes;
+                return launch_cfg<T, 256, 160, 4, 1, 2, true>(q, batch, st);
+            }
+        }
+        return launch_cfg<T, 128, 160, 4, 1>(p, batch, st);
+    }
     // large streaming GEMMs: 256x256 tile, 8 waves (2x4) - halves the operand bytes per flop and doubles the MFMA work
     // per barrier; measured +10..15 % over 128x128 on the d24 shapes.  CVAR_GEMM_CFG=0 forces the 128x128 tile (A/B runs).
     const int ov = gemm_cfg_override();
-    if (ov == 2 && p.M >= 2048 && p.N % 128 == 0) return launch_cfg<T, 256, 128, 4, 2, 3>(p, batch, st);
     // bf16: 4 waves (2x2), one per SIMD, 128x128 per wave with the accumulators in AGPRs and a hand-placed issue order;
     // CVAR_GEMM_CFG=1 selects the 8-wave (2x4) variant instead (A/B runs; also the fp32 parity-mode configuration)
     if (sizeof(T) == 2 && ov != 0 && ov != 1 && p.M >= 2048 && p.N % 256 == 0) return launch_cfg<T, 256, 256, 2, 2>(p, batch, st);
@@ -710,7 +779,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     p.C = d->C; p.out_dtype = d->out_dtype; p.ldc = d->ldc;
     p.remap_l = d->remap_l; p.remap_L = d->remap_L; p.remap_off = d->remap_off;
     p.tiles_m = p.tiles_n = 0;
-    p.cv_adv = p.cv_rem = 0;
+    p.cv_adv = p.cv_rem = 0; p.conv_bytes = 0;
     make_fast_div(p.remap_l, &p.remap_magic, &p.remap_shift);
     make_fast_div(p.gate ? p.gate_rows : 1, &p.gate_magic, &p.gate_shift);
     p.split_tiles = 0; p.split_stride = 0;
