@@ -452,28 +452,33 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             char* c_lane = Cb + (cz + n) * OES;
             const char* r_lane = res ? (const char*)p.residual + (rz + n) * RES_ES : nullptr;
             const float* g_lane = gate ? p.gate + n : nullptr;
-#pragma clang loop unroll(full)
-            for (int ih = 0; ih < 2 * MI; ++ih) {
-                const int i = ih >> 1, half = ih & 1;
-                // gate / residual operands of all NPASS passes are requested first: their latency hides behind the staging
-                // writes, and the passes below then never wait on a load that was queued behind the previous pass's store
-                f32x4_t gq[gate ? NPASS : 1][2], rq[res == 1 ? NPASS : 1][2];
-                bf16x8_t rb[res == 2 ? NPASS : 1];
+            // gate / residual operands are requested one half-pass AHEAD, i.e. before the previous half-pass's stores are issued:
+            // vmcnt retires in order, so a load queued behind stores would make its consumer wait for the store latency too
+            f32x4_t gq[2][gate ? NPASS : 1][2], rq[2][res == 1 ? NPASS : 1][2];
+            bf16x8_t rb[2][res == 2 ? NPASS : 1];
+            auto fetch_operands = [&](int ih) {
+                const int i = ih >> 1, half = ih & 1, bsel = ih & 1;
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) {
                     const int m = mrow + i * 32 + 16 * half + ps * RPP;
                     if (lane_on && m < p.M && ((16 % RPP == 0) || ps * RPP + erow < 16)) {
                         if constexpr (gate) {
                             const float* gp = g_lane + (long)fast_div(m, p.gate_magic, p.gate_shift) * p.ldg;
-                            gq[ps][0] = *(const f32x4_t*)gp; gq[ps][1] = *(const f32x4_t*)(gp + 4);
+                            gq[bsel][ps][0] = *(const f32x4_t*)gp; gq[bsel][ps][1] = *(const f32x4_t*)(gp + 4);
                         }
                         if constexpr (res == 1) {
                             const float* rp = (const float*)(r_lane + (long)m * p.ldr * 4);
-                            rq[ps][0] = *(const f32x4_t*)rp; rq[ps][1] = *(const f32x4_t*)(rp + 4);
+                            rq[bsel][ps][0] = *(const f32x4_t*)rp; rq[bsel][ps][1] = *(const f32x4_t*)(rp + 4);
                         }
-                        if constexpr (res == 2) rb[ps] = *(const bf16x8_t*)(r_lane + (long)m * p.ldr * 2);
+                        if constexpr (res == 2) rb[bsel][ps] = *(const bf16x8_t*)(r_lane + (long)m * p.ldr * 2);
                     }
                 }
+            };
+            if constexpr (gate || res != 0) fetch_operands(0);
+#pragma clang loop unroll(full)
+            for (int ih = 0; ih < 2 * MI; ++ih) {
+                const int i = ih >> 1, half = ih & 1, bsel = ih & 1;
+                if constexpr (gate || res != 0) { if (ih + 1 < 2 * MI) fetch_operands(ih + 1); }
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -495,14 +500,14 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                         }
                         if constexpr (gate) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { v[e] *= gq[ps][0][e]; v[4 + e] *= gq[ps][1][e]; }
+                            for (int e = 0; e < 4; ++e) { v[e] *= gq[bsel][ps][0][e]; v[4 + e] *= gq[bsel][ps][1][e]; }
                         }
                         if constexpr (res == 1) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { v[e] += rq[ps][0][e]; v[4 + e] += rq[ps][1][e]; }
+                            for (int e = 0; e < 4; ++e) { v[e] += rq[bsel][ps][0][e]; v[4 + e] += rq[bsel][ps][1][e]; }
                         } else if constexpr (res == 2) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rb[ps][e]);
+                            for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32((bf16_t)rb[bsel][ps][e]);
                         }
                         long orow = m;
                         if constexpr (remap) {
@@ -526,16 +531,21 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
         typedef integral_constant<int, 0> I0; typedef integral_constant<int, 1> I1; typedef integral_constant<int, 2> I2;
         const bool obf = p.out_dtype == CVAR_BF16, rm = p.remap_l > 0;
         if (vec_ok) {
+            // each kernel kind only carries the variants its callers use (a variant's registers count against the whole kernel)
             if (!p.gate && !p.residual && p.act == CVAR_ACT_NONE) {
-                if (obf && rm) { run(Y{}, I0{}, NO{}, I0{}, Y{}); done = true; }
-                else if (obf && !rm) { run(Y{}, I0{}, NO{}, I0{}, NO{}); done = true; }
+                if (obf && !rm) { run(Y{}, I0{}, NO{}, I0{}, NO{}); done = true; }
                 else if (!obf && !rm) { run(NO{}, I0{}, NO{}, I0{}, NO{}); done = true; }
-            } else if (!p.gate && !p.residual && p.act == CVAR_ACT_GELU_TANH && obf && !rm) {
-                run(Y{}, I1{}, NO{}, I0{}, NO{}); done = true;
-            } else if (p.gate && p.residual && p.res_dtype == CVAR_F32 && p.act == CVAR_ACT_NONE && !obf && !rm) {
-                run(NO{}, I0{}, Y{}, I1{}, NO{}); done = true;
-            } else if (!p.gate && p.residual && p.res_dtype == CVAR_BF16 && p.act == CVAR_ACT_NONE && obf && !rm) {
-                run(Y{}, I0{}, NO{}, I2{}, NO{}); done = true;
+                else if constexpr (!CONV) { if (obf && rm) { run(Y{}, I0{}, NO{}, I0{}, Y{}); done = true; } }
+            } else if constexpr (!CONV) {
+                if (!p.gate && !p.residual && p.act == CVAR_ACT_GELU_TANH && obf && !rm) {
+                    run(Y{}, I1{}, NO{}, I0{}, NO{}); done = true;
+                } else if (p.gate && p.residual && p.res_dtype == CVAR_F32 && p.act == CVAR_ACT_NONE && !obf && !rm) {
+                    run(NO{}, I0{}, Y{}, I1{}, NO{}); done = true;
+                }
+            } else {
+                if (!p.gate && p.residual && p.res_dtype == CVAR_BF16 && p.act == CVAR_ACT_NONE && obf && !rm) {
+                    run(Y{}, I0{}, NO{}, I2{}, NO{}); done = true;
+                }
             }
         }
     }
