@@ -695,7 +695,7 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     // small-M problems (early scales, ada_lin) use a 64-row tile to put more blocks on the chip
     if (p.M <= 64) return launch_cfg<T, 64, 128, 1, 4>(p, batch, st);
     // channel counts of the VQVAE (160, 320) are multiples of 160 but not of 128: a 160-wide tile wastes no MFMA work
-    if (p.N % 160 == 0 && p.N % 128 != 0 && p.M >= 4096) {
+    if (p.N % 160 == 0 && (p.N % 128 != 0 || p.conv) && p.M >= 4096) {
         // stride-1 3x3 convs of the decoder / encoder trunks: 256x160 tile on the scalar-state conv addressing (conv FAST)
         const long in_bytes = p.conv ? (long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin * (long)sizeof(T) : 0;
         if constexpr (sizeof(T) == 2) {
