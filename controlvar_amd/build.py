@@ -14,6 +14,9 @@ OBJ = os.path.join(HERE, 'csrc', 'build')
 LIB = os.path.join(HERE, 'libcvar_hip.so')
 SOURCES = ['gemm.hip', 'ops.hip', 'attn.hip', 'sample.hip', 'msq.hip', 'train.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wno-unused-result']
+# per-source extras.  attn.hip: keep MFMA results in VGPRs - the softmax consumes every score with vector ALU ops, and the AGPR form
+# costs one v_accvgpr_read per score and tile (plus writes for the rescale)
+EXTRA = {'attn.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 
 
 def _hipcc() -> str:
@@ -29,12 +32,13 @@ def _digest(paths) -> str:
         with open(p, 'rb') as f:
             h.update(f.read())
     h.update(' '.join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA.items())).encode())
     return h.hexdigest()
 
 
 def _compile(src: str) -> str:
     obj = os.path.join(OBJ, os.path.splitext(src)[0] + '.o')
-    cmd = [_hipcc(), *FLAGS, '-c', os.path.join(CSRC, src), '-o', obj]
+    cmd = [_hipcc(), *FLAGS, *EXTRA.get(src, []), '-c', os.path.join(CSRC, src), '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')
