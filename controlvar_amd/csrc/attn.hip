@@ -148,7 +148,8 @@ static int cvar_attention_impl(const void* qkv, int dtype, int R, int H, int Lma
 // ================================================================================================
 constexpr int FA_VT_STRIDE = 68;      // elements per V^T row (64 keys + pad): 136 B, 8-B aligned, 2-way-free writes
 
-__global__ __launch_bounds__(256) void attn_mfma_bf16_kernel(const AttnParams p) {
+// 3 waves per SIMD (<= 168 VGPRs): the softmax phase of one wave overlaps the MFMA phases of the other two (+10 % over 2)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_mfma_bf16_kernel(const AttnParams p) {
     constexpr int D = 64, KT = 64;
     __shared__ __attribute__((aligned(16))) char Ks[KT * 128];
     __shared__ __attribute__((aligned(16))) bf16_t Vt[D * FA_VT_STRIDE];
