@@ -5,6 +5,7 @@
 // query row (q, o in registers), K/V tiles of 64 keys are staged in LDS as fp32 and read as wave-wide
 // broadcasts; block-wise online softmax (one rescale per 64-key tile).
 #include "cvar_common.h"
+#include <type_traits>
 
 struct AttnParams {
     const void* qkv;
@@ -210,8 +211,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     float m = -INFINITY, lsum = 0.f;
     const float c2 = p.scale * 1.4426950408889634f;
 
-    load_tile(0);
-    for (int kt0 = 0; kt0 < kv_end; kt0 += KT) {
+    // One KV tile.  MASK is a compile-time flag: tiles that every query of the wave sees completely (all but the last one at
+    // inference, all but the level-boundary ones under the training mask) run without any per-score compare / select - left
+    // as a run-time flag the compiler if-converts the masking into ~100 extra vector instructions on every tile.
+    auto tile = [&](int kt0, auto MASK) {
         store_tile();
         __syncthreads();
         if (kt0 + KT < kv_end) load_tile(kt0 + KT);
@@ -228,13 +231,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
         }
         // softmax bookkeeping in the exp2 domain: p = 2^(s*c - m), c = scale*log2(e)  (one fma + one v_exp_f32 per score)
-        const bool need_mask = kt0 + KT > wave_min_kv;
         float tmax = -INFINITY;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                if (need_mask) {
+                if constexpr (decltype(MASK)::value) {
                     const int key = kt0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hi;
                     if (key >= kvlen) s[kb][i] = -INFINITY;
                 }
@@ -278,7 +280,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][t], o[db], 0, 0, 0);
                 }
         __syncthreads();
-    }
+    };
+    typedef std::integral_constant<bool, true> MaskOn;
+    typedef std::integral_constant<bool, false> MaskOff;
+    load_tile(0);
+    int kt0 = 0;
+    // wave_min_kv is wave-uniform per construction but tiles are shared by the workgroup (barriers inside): the split point
+    // must be the same for all four waves, so it is taken over the workgroup's first query
+    const int wg_min_kv = kv_len_of(p, p.q_off + min((int)blockIdx.x * 128, p.l - 1));
+    for (; kt0 + KT <= wg_min_kv && kt0 < kv_end; kt0 += KT) tile(kt0, MaskOff{});
+    for (; kt0 < kv_end; kt0 += KT) tile(kt0, MaskOn{});
     lsum += __shfl_xor(lsum, 32, 64);
     if (qi < p.l) {
         if (p.lse && hi == 0) p.lse[(r * p.H + h) * (long)p.l + qi] = (m + log2f(lsum)) * 0.6931471805599453f;
