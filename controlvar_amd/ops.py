@@ -258,3 +258,26 @@ def sumsq(x, partial, slot):
 
 def clip_coef(partial, count, pre_scale, max_norm, out2):
     check(_lib.load().cvar_clip_coef(_ptr(partial), count, pre_scale, max_norm, _ptr(out2), _stream()), 'cvar_clip_coef')
+
+
+# ---- tokenizer input pipeline (preprocess.py)
+def resample_u8(src: torch.Tensor, src_h: int, src_w: int, channels: int, axis: int, dst_extent: int, bounds: torch.Tensor,
+                coeffs: torch.Tensor, ksize: int, dst: torch.Tensor):
+    check(_lib.load().cvar_resample_u8(_ptr(src), src_h, src_w, channels, axis, dst_extent, _ptr(bounds), _ptr(coeffs), ksize, _ptr(dst),
+                                       _stream()), 'cvar_resample_u8')
+    return dst
+
+
+def crop_flip_normalize(src: torch.Tensor, src_h: int, src_w: int, channels: int, top: int, left: int, out_h: int, out_w: int,
+                        flip: bool, dst: torch.Tensor):
+    check(_lib.load().cvar_crop_flip_normalize(_ptr(src), src_h, src_w, channels, top, left, out_h, out_w, int(flip), _ptr(dst),
+                                               _stream()), 'cvar_crop_flip_normalize')
+    return dst
+
+
+def ignore_mask(cond: torch.Tensor, B: int, H: int, W: int, patch_nums: Sequence[int], first_masked_scale: int, image_first: int,
+                out: torch.Tensor, L: int):
+    arr = (C.c_int * len(patch_nums))(*patch_nums)
+    check(_lib.load().cvar_ignore_mask(_ptr(cond), B, H, W, arr, len(patch_nums), first_masked_scale, image_first, _ptr(out), L,
+                                       _stream()), 'cvar_ignore_mask')
+    return out

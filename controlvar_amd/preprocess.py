@@ -1,0 +1,156 @@
+"""Tokenizer input pipeline on the device.
+
+What the reference does per sample on the CPU (datasets/imagenetC.py:128-188 + datasets/transforms_image.py:103-121):
+
+    image = PIL RGB;  cond = condition image .resize(image.size)                      (PIL default filter: BICUBIC)
+    Resize(288, LANCZOS) on both -> RandomCrop(256) or CenterCrop(256) -> RandomHorizontalFlip -> ToTensor -> Normalize(.5, .5)
+    ignore_mask / ignore_mask_ from the background of a segmentation-mask condition
+
+Here JPEG decoding stays on the host; everything after it runs on the GPU from the decoded uint8 HWC array:
+
+* ``resample_tables`` restates Pillow's ``precompute_coeffs`` + ``normalize_coeffs_8bpc`` (src/libImaging/Resample.c) in
+  double precision on the host - a few hundred numbers per axis;
+* ``cvar_resample_u8`` applies them (two integer passes, horizontal first, uint8 between the passes as in
+  ``ImagingResample``) - bit-identical to ``Image.resize``;
+* ``cvar_crop_flip_normalize`` / ``cvar_ignore_mask`` finish the sample.
+
+Random choices (crop offset, flip) are inputs: the caller owns the RNG, as with the reference's ``random`` module.
+Not yet on the device: COCO-RLE decoding and the colour map of segmentation conditions (imagenetC.py:15-37; pycocotools).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+PRECISION_BITS = 32 - 8 - 2                       # Resample.c
+
+
+def _sinc(x: float) -> float:                     # sinc_filter
+    if x == 0.0:
+        return 1.0
+    x = x * math.pi
+    return math.sin(x) / x                        # math.sin is the C library's sin, the one Pillow calls
+
+
+def _lanczos(x: float) -> float:                  # lanczos_filter: truncated sinc, support 3
+    if -3.0 <= x < 3.0:
+        return _sinc(x) * _sinc(x / 3)
+    return 0.0
+
+
+def _bicubic(x: float) -> float:                  # bicubic_filter, a = -0.5, support 2
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+FILTERS = {'lanczos': (_lanczos, 3.0), 'bicubic': (_bicubic, 2.0)}
+
+
+def resample_tables(in_size: int, out_size: int, filt: str) -> Tuple[np.ndarray, np.ndarray, int]:
+    """bounds (out, 2) int32, fixed-point coeffs (out, ksize) int32, ksize: precompute_coeffs over the full axis (in0 = 0,
+    in1 = in_size) followed by normalize_coeffs_8bpc, in the C code's operation order (plain Python floats are C doubles)."""
+    f, fsupport = FILTERS[filt]
+    scale = float(in_size) / out_size
+    filterscale = max(scale, 1.0)
+    support = fsupport * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    fixed = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    one = float(1 << PRECISION_BITS)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)                 # (int) truncates toward zero, then the clamp
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [f((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v                                                # same left-to-right accumulation as the C loop
+        if ww != 0.0:
+            w = [v / ww for v in w]
+        for x, v in enumerate(w):
+            fixed[xx, x] = int(-0.5 + v * one) if v < 0 else int(0.5 + v * one)
+        bounds[xx] = (xmin, xmax)
+    return bounds, fixed, ksize
+
+
+def resized_size(h: int, w: int, size: int) -> Tuple[int, int]:
+    """torchvision F.resize with an int size (shorter side -> size, the longer one int(size * long / short))"""
+    short, long = (w, h) if w <= h else (h, w)
+    if short == size:
+        return h, w
+    new_short, new_long = size, int(size * long / short)
+    return (new_long, new_short) if w <= h else (new_short, new_long)
+
+
+def center_crop_offsets(h: int, w: int, out_h: int, out_w: int) -> Tuple[int, int]:
+    """torchvision F.center_crop: int(round((h - out_h) / 2.0)) with Python's round (half to even)"""
+    return int(round((h - out_h) / 2.0)), int(round((w - out_w) / 2.0))
+
+
+# ------------------------------------------------------------------------------------------------------------- device side
+def _tables_to_device(tables, device):
+    import torch
+    b, k, ksize = tables
+    return torch.from_numpy(b).to(device), torch.from_numpy(np.ascontiguousarray(k)).to(device), ksize
+
+
+def resize_u8(img, out_h: int, out_w: int, filt: str):
+    """``Image.resize((out_w, out_h), filt)`` of a uint8 HWC device tensor: horizontal pass, then vertical pass (ImagingResample)"""
+    import torch
+    from . import ops
+    h, w, c = img.shape
+    cur = img.contiguous()
+    if out_w != w:
+        b, k, ks = _tables_to_device(resample_tables(w, out_w, filt), img.device)
+        nxt = torch.empty(h, out_w, c, dtype=torch.uint8, device=img.device)
+        ops.resample_u8(cur, h, w, c, 0, out_w, b, k, ks, nxt)
+        cur, w = nxt, out_w
+    if out_h != h:
+        b, k, ks = _tables_to_device(resample_tables(h, out_h, filt), img.device)
+        nxt = torch.empty(out_h, w, c, dtype=torch.uint8, device=img.device)
+        ops.resample_u8(cur, h, w, c, 1, out_h, b, k, ks, nxt)
+        cur = nxt
+    return cur
+
+
+def preprocess_pair(image_u8, cond_u8, image_size: int = 256, mid_res: float = 1.125, crop: Optional[Tuple[int, int]] = None, flip: bool = False):
+    """One (image, condition) sample: uint8 HWC device tensors -> two fp32 (3, image_size, image_size) tensors in [-1, 1].
+    crop = (top, left) for the RandomCrop branch, None for the CenterCrop branch (create_image_mask_transforms, :103-121)."""
+    import torch
+    from . import ops
+    h, w, _ = image_u8.shape
+    if tuple(cond_u8.shape[:2]) != (h, w):
+        cond_u8 = resize_u8(cond_u8, h, w, 'bicubic')                           # cond.resize(image.size), imagenetC.py:147
+    mid = round(mid_res * image_size)
+    nh, nw = resized_size(h, w, mid)
+    outs = []
+    top, left = crop if crop is not None else center_crop_offsets(nh, nw, image_size, image_size)
+    for src in (image_u8, cond_u8):
+        r = resize_u8(src, nh, nw, 'lanczos') if (nh, nw) != (h, w) else src.contiguous()
+        dst = torch.empty(3, image_size, image_size, dtype=torch.float32, device=src.device)
+        ops.crop_flip_normalize(r, nh, nw, 3, top, left, image_size, image_size, bool(flip), dst)
+        outs.append(dst)
+    return outs[0], outs[1]
+
+
+def ignore_masks(cond, patch_nums: Sequence[int], first_masked_scale: int = 5) -> Dict[str, object]:
+    """imagenetC.py:152-178 for a batch of segmentation-mask conditions (B, 3, H, W): {'ignore_mask', 'ignore_mask_'} (B, L)"""
+    import torch
+    from . import ops
+    B, _, H, W = cond.shape
+    L = sum(2 * p * p for p in patch_nums)
+    out = {}
+    for key, image_first in (('ignore_mask', 0), ('ignore_mask_', 1)):
+        t = torch.empty(B, L, dtype=torch.float32, device=cond.device)
+        ops.ignore_mask(cond.contiguous(), B, H, W, patch_nums, first_masked_scale, image_first, t, L)
+        out[key] = t
+    return out

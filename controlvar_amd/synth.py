@@ -104,3 +104,23 @@ def synth_images(batch: int, size: int = 256, seed: int = 0) -> torch.Tensor:
     smooth = torch.nn.functional.interpolate(low, size=(size, size), mode='bilinear', align_corners=False)
     noise = torch.rand((batch, 3, size, size), generator=g) * 2 - 1
     return (0.75 * smooth + 0.25 * noise).clamp_(-1, 1).contiguous()
+
+
+# ---- synthetic "decoded JPEG" + segmentation-style condition for the input-pipeline tests (tests/golden/preprocess.npz)
+PREPROC_CASES = [(375, 500, 0), (500, 333, 1), (288, 300, 2), (120, 90, 3), (1024, 683, 4)]     # (h, w, seed)
+
+
+def synth_photo_pair(h: int, w: int, seed: int):
+    """uint8 (h, w, 3) image (smooth field + noise) and a 512x512x3 condition (flat-colour discs on black), numpy only"""
+    import numpy as np
+    rng = np.random.default_rng(1000 + seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = 127 + 90 * np.sin(yy / 17.0 + seed) * np.cos(xx / 23.0) + rng.normal(0, 25, (h, w))
+    img = np.clip(np.stack([base, base[::-1], base[:, ::-1]], -1), 0, 255).astype(np.uint8)
+    cond = np.zeros((512, 512, 3), np.uint8)
+    for k in range(4):
+        cy, cx, r = rng.integers(60, 450, 3)
+        r = int(r) // 4 + 20
+        m = (np.mgrid[0:512, 0:512][0] - cy) ** 2 + (np.mgrid[0:512, 0:512][1] - cx) ** 2 < r * r
+        cond[m] = rng.integers(0, 5, 3) * 64
+    return img, cond

@@ -205,6 +205,31 @@ int cvar_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr
 int cvar_sumsq(const float* x, int64_t n, double* partial256, void* stream);
 int cvar_clip_coef(const double* partials, int64_t count, float pre_scale, float max_norm, float* out2, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Input pipeline of the tokenizer: what datasets/imagenetC.py:128-188 and
+ * datasets/transforms_image.py:103-121 do on the CPU with PIL / torchvision.
+ *
+ * cvar_resample_u8: ONE pass of PIL's 8-bit separable resampler (Pillow src/libImaging/Resample.c,
+ *   ImagingResampleHorizontal_8bpc / ImagingResampleVertical_8bpc) over an interleaved uint8 image
+ *   src[src_h][src_w][channels].  axis 0 resamples rows to `dst_extent` columns, axis 1 columns to
+ *   `dst_extent` rows.  bounds[dst_extent][2] = (first source index, tap count), coeffs[dst_extent][ksize] =
+ *   fixed-point taps with 22 fraction bits - both DEVICE arrays filled from the host tables of
+ *   precompute_coeffs / normalize_coeffs_8bpc (controlvar_amd/preprocess.py).  Replaces Image.resize
+ *   (F.resize LANCZOS, transforms_image.py:16-18; cond.resize(image.size), imagenetC.py:147).
+ * cvar_crop_flip_normalize: F.crop / F.center_crop + F.hflip + to_tensor + normalize(0.5, 0.5)
+ *   (transforms_image.py:22-66,84-89): window (top, left, out_h, out_w) of src -> fp32 dst[channels][out_h][out_w].
+ * cvar_ignore_mask: loss-ignore weights of a segmentation-mask condition (imagenetC.py:152-185):
+ *   cond (B,3,H,W) fp32 in [-1,1]; out (B, L) fp32, L = sum 2*pn^2; the control half of every scale with index
+ *   >= first_masked_scale carries the nearest-downsampled (background ? 0 : 1) map, everything else 1.
+ *   image_first = 0: token order [control | image] per scale ('ignore_mask'); 1: [image | control] ('ignore_mask_').
+ */
+int cvar_resample_u8(const void* src, int src_h, int src_w, int channels, int axis, int dst_extent,
+                     const int* bounds, const int* coeffs, int ksize, void* dst, void* stream);
+int cvar_crop_flip_normalize(const void* src, int src_h, int src_w, int channels, int top, int left, int out_h, int out_w,
+                             int flip, float* dst, void* stream);
+int cvar_ignore_mask(const float* cond, int B, int H, int W, const int* patch_nums_host, int n_scales, int first_masked_scale,
+                     int image_first, float* out, int L, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

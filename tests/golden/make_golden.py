@@ -387,6 +387,46 @@ def case_checkpoint():
          opt_step_dtype=np.array(str(osd['state'][0]['step'].dtype)), **out)
 
 
+from controlvar_amd.synth import PREPROC_CASES, synth_photo_pair as preproc_inputs      # noqa: E402
+
+
+def case_preprocess():
+    """N2: the third-party pieces of the reference's input pipeline, recorded from the libraries themselves (Pillow here;
+    torch for the nearest-neighbour ignore mask): Image.resize(LANCZOS) to the torchvision F.resize(288) size, the default
+    (BICUBIC) cond.resize(image.size), and F.interpolate(mode='nearest') of the background mask (imagenetC.py:147-178)."""
+    import hashlib
+    import PIL
+    from PIL import Image
+    import torch.nn.functional as F
+    from controlvar_amd.preprocess import resized_size
+    out = {'pillow_version': np.array(PIL.__version__)}
+    for h, w, seed in PREPROC_CASES:
+        img, cond = preproc_inputs(h, w, seed)
+        nh, nw = resized_size(h, w, 288)
+        big = np.asarray(Image.fromarray(img).resize((nw, nh), Image.LANCZOS)) if (nh, nw) != (h, w) else img
+        c1 = np.asarray(Image.fromarray(cond).resize((w, h)))                      # PIL default filter
+        c2 = np.asarray(Image.fromarray(c1).resize((nw, nh), Image.LANCZOS)) if (nh, nw) != (h, w) else c1
+        tag = f'{h}x{w}'
+        for name, arr in (('img288', big), ('cond_fit', c1), ('cond288', c2)):
+            out[f'{tag}_{name}_sha'] = np.array(hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest())
+            out[f'{tag}_{name}_shape'] = np.array(arr.shape)
+            out[f'{tag}_{name}_sample'] = arr[::37, ::29].copy()
+    # ignore masks by the reference's own tensor code (imagenetC.py:152-178) on a normalised 256x256 condition
+    _, cond = preproc_inputs(375, 500, 0)
+    c = np.asarray(Image.fromarray(cond).resize((256, 256), Image.NEAREST)).astype(np.float32)
+    ct = ((torch.from_numpy(c).permute(2, 0, 1) / 255.0) - 0.5) / 0.5
+    ignore_mask = torch.ones_like(ct.sum(dim=0))
+    ignore_mask[ct.sum(dim=0) == -3] = 0
+    a, b = [], []
+    for si, pm in enumerate(PN):
+        if si < 5:
+            a += [torch.ones(pm ** 2), torch.ones(pm ** 2)]; b += [torch.ones(pm ** 2), torch.ones(pm ** 2)]
+        else:
+            m_ = F.interpolate(ignore_mask[None, None], (pm, pm), mode='nearest').permute((0, 2, 3, 1)).reshape((-1,))
+            a += [m_, torch.ones(pm ** 2)]; b += [torch.ones(pm ** 2), m_]
+    save('preprocess', ign_cond=ct, ignore_mask=torch.concat(a), ignore_mask_=torch.concat(b), **out)
+
+
 CASES = {
     'interp': case_interp,
     'tok_tiny': lambda: case_tokenizer(32, 3, 'ch32'),
@@ -402,6 +442,7 @@ CASES = {
     'lr': case_lr,
     'train': case_train_step,
     'checkpoint': case_checkpoint,
+    'preprocess': case_preprocess,
 }
 
 if __name__ == '__main__':

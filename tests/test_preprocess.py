@@ -1,0 +1,105 @@
+"""N2 input pipeline: Pillow's resampler / torchvision's transform chain / the ignore-mask rule.
+CPU: host tables + numpy oracle against the Pillow-recorded fixture (and the installed Pillow, when there is one).
+GPU: the HIP kernels against the oracle, bit for bit."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from controlvar_amd import preprocess as P
+from controlvar_amd.spec import DEFAULT_PATCH_NUMS as PN
+from controlvar_amd.synth import PREPROC_CASES, synth_photo_pair
+from oracle import resample_ref as R
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_torchvision_size_rules():
+    assert P.resized_size(375, 500, 288) == (288, 384)          # shorter side -> 288, longer int(288 * 500 / 375)
+    assert P.resized_size(500, 333, 288) == (432, 288)          # int(288 * 500 / 333) = 432
+    assert P.resized_size(288, 300, 288) == (288, 300)          # already at size: returned unchanged
+    assert P.resized_size(1024, 683, 288) == (431, 288)
+    assert P.center_crop_offsets(288, 384, 256, 256) == (16, 64)
+    assert P.center_crop_offsets(289, 385, 256, 256) == (16, 64)    # round(16.5) = 16, round(64.5) = 64: half to even
+    assert P.center_crop_offsets(291, 387, 256, 256) == (18, 66)    # round(17.5) = 18
+
+
+def test_tables_are_pillow_shaped():
+    b, k, ks = P.resample_tables(500, 288, 'lanczos')
+    assert ks == int(np.ceil(3.0 * 500 / 288)) * 2 + 1 and k.shape == (288, ks) and b.shape == (288, 2)
+    assert (b[:, 0] >= 0).all() and (b[:, 0] + b[:, 1] <= 500).all()
+    assert np.abs(k.sum(1) - (1 << 22)).max() <= ks                 # rows sum to 1.0 up to per-tap rounding
+    b2, k2, ks2 = P.resample_tables(100, 288, 'bicubic')            # upscaling: filterscale clamps at 1
+    assert ks2 == 5
+
+
+@pytest.mark.parametrize('h,w,seed', PREPROC_CASES)
+def test_oracle_resize_equals_pillow_fixture(h, w, seed):
+    g = golden('preprocess')
+    img, cond = synth_photo_pair(h, w, seed)
+    nh, nw = P.resized_size(h, w, 288)
+    big = R.resize(img, nh, nw, 'lanczos') if (nh, nw) != (h, w) else img
+    c1 = R.resize(cond, h, w, 'bicubic')
+    c2 = R.resize(c1, nh, nw, 'lanczos') if (nh, nw) != (h, w) else c1
+    tag = f'{h}x{w}'
+    for name, arr in (('img288', big), ('cond_fit', c1), ('cond288', c2)):
+        assert tuple(g[f'{tag}_{name}_shape']) == arr.shape
+        np.testing.assert_array_equal(arr[::37, ::29], g[f'{tag}_{name}_sample'])
+        assert sha(arr) == str(g[f'{tag}_{name}_sha']), (tag, name)
+
+
+def test_oracle_resize_equals_installed_pillow():
+    Image = pytest.importorskip('PIL.Image')
+    rng = np.random.default_rng(5)
+    for (h, w, oh, ow, f) in [(97, 61, 288, 181, 'lanczos'), (301, 777, 288, 743, 'lanczos'), (40, 40, 333, 129, 'bicubic'), (640, 480, 123, 77, 'bicubic')]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        want = np.asarray(Image.fromarray(img).resize((ow, oh), Image.LANCZOS if f == 'lanczos' else Image.BICUBIC))
+        np.testing.assert_array_equal(R.resize(img, oh, ow, f), want)
+
+
+def test_oracle_ignore_masks_equal_reference_tensor_code():
+    g = golden('preprocess')
+    a, b = R.ignore_masks(np.asarray(g['ign_cond']), PN)
+    np.testing.assert_array_equal(a, g['ignore_mask'])
+    np.testing.assert_array_equal(b, g['ignore_mask_'])
+    assert a.shape == (1360,) and 0 < a.mean() < 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('h,w,seed', PREPROC_CASES[:4])
+def test_device_pipeline_is_bit_identical(gpu_device, h, w, seed):
+    img, cond = synth_photo_pair(h, w, seed)
+    di, dc = torch.from_numpy(img).to(gpu_device), torch.from_numpy(cond).to(gpu_device)
+    nh, nw = P.resized_size(h, w, 288)
+    if (nh, nw) != (h, w):
+        got = P.resize_u8(di, nh, nw, 'lanczos').cpu().numpy()
+        np.testing.assert_array_equal(got, R.resize(img, nh, nw, 'lanczos'))
+        assert sha(got) == str(golden('preprocess')[f'{h}x{w}_img288_sha'])          # == Pillow's own output
+    if min(nh, nw) < 256:
+        return                                                                            # (the 120x90 case only exercises the resize)
+    for crop, flip in ((None, False), ((7, 3), True)):
+        gi, gc = P.preprocess_pair(di, dc, crop=crop, flip=flip)
+        wi, wc = R.preprocess_pair(img, cond, crop=crop, flip=flip)
+        assert gi.shape == (3, 256, 256) and gi.dtype == torch.float32
+        np.testing.assert_array_equal(gi.cpu().numpy(), wi)
+        np.testing.assert_array_equal(gc.cpu().numpy(), wc)
+
+
+@pytest.mark.gpu
+def test_device_ignore_masks(gpu_device):
+    g = golden('preprocess')
+    cond = torch.from_numpy(np.asarray(g['ign_cond'])).to(gpu_device)
+    batch = torch.stack([cond, -torch.ones_like(cond), torch.zeros_like(cond)])          # real mask, all background, no background
+    out = P.ignore_masks(batch, PN)
+    np.testing.assert_array_equal(out['ignore_mask'][0].cpu().numpy(), g['ignore_mask'])
+    np.testing.assert_array_equal(out['ignore_mask_'][0].cpu().numpy(), g['ignore_mask_'])
+    a1, _ = R.ignore_masks(-np.ones((3, 256, 256), np.float32), PN)
+    np.testing.assert_array_equal(out['ignore_mask'][1].cpu().numpy(), a1)
+    assert float(out['ignore_mask'][2].min()) == 1.0
+    from controlvar_amd import ops
+    with pytest.raises(Exception):
+        ops.ignore_mask(batch, 3, 256, 256, PN, 5, 0, torch.empty(3, 100, device=gpu_device), 100)      # L mismatch -> CVAR_EINVAL
