@@ -120,3 +120,38 @@ extern "C" int cvar_ignore_mask(const float* cond, int B, int H, int W, const in
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;
 }
+
+// cvar_rle_paint: the raster half of process_anns (datasets/imagenetC.py:15-29).  Every kept annotation is a column-major
+// run-length mask (COCO RLE: runs alternate 0 / 1 starting with 0); run_ends holds, per annotation, the exclusive prefix
+// sums of its runs.  A pixel takes the colour of the LAST annotation that covers it (mask[m] = colour in file order), black
+// otherwise.  The string codec and the centroid -> colour rule stay on the host (controlvar_amd/preprocess.py).
+__global__ void rle_paint_kernel(const int* __restrict__ run_ends, const int* __restrict__ ann_off, const unsigned char* __restrict__ colours,
+                                 int n_ann, int H, int W, unsigned char* __restrict__ out) {
+    const long total = (long)H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i % W);
+        const int pos = x * H + y;                       // column-major position of the pixel inside the RLE stream
+        int hit = -1;
+        for (int a = 0; a < n_ann; ++a) {
+            const int* e = run_ends + ann_off[a];
+            int lo = 0, hi = ann_off[a + 1] - ann_off[a];            // first run r with e[r] > pos
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (e[mid] > pos) hi = mid; else lo = mid + 1;
+            }
+            if (lo < ann_off[a + 1] - ann_off[a] && (lo & 1)) hit = a;   // odd runs are the ones
+        }
+        unsigned char* o = out + i * 3;
+        if (hit >= 0) { o[0] = colours[3 * hit]; o[1] = colours[3 * hit + 1]; o[2] = colours[3 * hit + 2]; }
+        else { o[0] = 0; o[1] = 0; o[2] = 0; }
+    }
+}
+
+extern "C" int cvar_rle_paint(const int* run_ends, const int* ann_offsets, const void* colours, int n_ann, int H, int W, void* out, void* stream) {
+    if (!out || H <= 0 || W <= 0 || n_ann < 0 || (n_ann > 0 && (!run_ends || !ann_offsets || !colours))) return CVAR_EINVAL;
+    const long total = (long)H * W;
+    hipLaunchKernelGGL(rle_paint_kernel, dim3((int)min((long)2048, (total + 255) / 256)), dim3(256), 0, as_stream(stream), run_ends, ann_offsets,
+                       (const unsigned char*)colours, n_ann, H, W, (unsigned char*)out);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}

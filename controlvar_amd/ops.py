@@ -281,3 +281,8 @@ def ignore_mask(cond: torch.Tensor, B: int, H: int, W: int, patch_nums: Sequence
     check(_lib.load().cvar_ignore_mask(_ptr(cond), B, H, W, arr, len(patch_nums), first_masked_scale, image_first, _ptr(out), L,
                                        _stream()), 'cvar_ignore_mask')
     return out
+
+
+def rle_paint(run_ends: torch.Tensor, ann_offsets: torch.Tensor, colours: torch.Tensor, n_ann: int, H: int, W: int, out: torch.Tensor):
+    check(_lib.load().cvar_rle_paint(_ptr(run_ends), _ptr(ann_offsets), _ptr(colours), n_ann, H, W, _ptr(out), _stream()), 'cvar_rle_paint')
+    return out

@@ -154,3 +154,106 @@ def ignore_masks(cond, patch_nums: Sequence[int], first_masked_scale: int = 5) -
         ops.ignore_mask(cond.contiguous(), B, H, W, patch_nums, first_masked_scale, image_first, t, L)
         out[key] = t
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------- segmentation condition
+def create_color_map() -> np.ndarray:
+    """imagenetC.py:31-37: the 5x5x5 colour cube without black -> (124, 3)"""
+    lv = [0, 64, 128, 192, 255]
+    return np.array([[r, g, b] for r in lv for g in lv for b in lv])[1:]
+
+
+def rle_from_string(s) -> list:
+    """COCO compressed RLE string -> run lengths.  pycocotools (common/maskApi.c, rleFrString; the dependency is not vendored
+    in the reference and not installed here, so this codec is restated from the published algorithm - parity UNPINNED):
+    6-bit characters offset by 48, 5 payload bits + continuation bit 0x20, sign-extended by bit 0x10 of the last group,
+    and every value after the third is a delta against the value two places back."""
+    if isinstance(s, str):
+        s = s.encode('ascii')
+    cnts, p = [], 0
+    while p < len(s):
+        x, k, more = 0, 0, 1
+        while more:
+            c = s[p] - 48
+            x |= (c & 0x1f) << (5 * k)
+            more = c & 0x20
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if len(cnts) > 2:
+            x += cnts[-2]
+        cnts.append(x)
+    return cnts
+
+
+def rle_to_string(cnts: Sequence[int]) -> str:
+    """inverse of rle_from_string (rleToString); used by the tests"""
+    out = bytearray()
+    for i, x in enumerate(cnts):
+        x = int(x)
+        if i > 2:
+            x -= int(cnts[i - 2])
+        more = True
+        while more:
+            c = x & 0x1f
+            x >>= 5
+            more = (x != -1) if (c & 0x10) else (x != 0)
+            if more:
+                c |= 0x20
+            out.append(c + 48)
+    return out.decode('ascii')
+
+
+def _runs_of(segmentation) -> Tuple[list, int, int]:
+    h, w = segmentation['size']
+    counts = segmentation['counts']
+    runs = rle_from_string(counts) if isinstance(counts, (str, bytes)) else [int(c) for c in counts]
+    if sum(runs) != h * w:
+        raise ValueError(f'RLE covers {sum(runs)} pixels, size says {h}x{w}')
+    return runs, h, w
+
+
+def annotation_colours(anns, image_size: int, colormap: Optional[np.ndarray] = None, min_area: int = 5000):
+    """host half of process_anns (imagenetC.py:15-29): area filter, centroid of each mask from its runs, colour index
+    ``(x * y) % len(colormap)`` with ``x = int(mean(cols) // (W / 11))``, ``y = int(mean(rows) // (H / 11))``.
+    Returns (run_ends int32, ann_offsets int32, colours uint8 (n, 3)) ready for cvar_rle_paint."""
+    colormap = create_color_map() if colormap is None else colormap
+    ends, offsets, colours = [], [0], []
+    for ann in anns:
+        if ann['area'] < min_area:
+            continue
+        runs, h, w = _runs_of(ann['segmentation'])
+        if (h, w) != (image_size, image_size):
+            raise ValueError(f'mask of size {h}x{w}, expected {image_size} (the reference paints into a fixed 512 canvas)')
+        e = np.cumsum(np.asarray(runs, np.int64))
+        starts, stops = e[0::2][: len(e[1::2])], e[1::2]                      # the "ones" runs [start, stop) in column-major order
+        n = int((stops - starts).sum())
+        # sum of column / row indices over all set pixels, exactly (integers): position i -> column i // h, row i % h
+        sx = sy = 0
+        for a, b in zip(starts.tolist(), stops.tolist()):
+            idx = np.arange(a, b, dtype=np.int64)
+            sx += int((idx // h).sum()); sy += int((idx % h).sum())
+        mean_x, mean_y = np.float64(sx) / np.float64(n), np.float64(sy) / np.float64(n)
+        x = int(np.floor_divide(mean_x, w / 11))
+        y = int(np.floor_divide(mean_y, h / 11))
+        assert x * y < 124
+        colours.append(colormap[(x * y) % len(colormap)])
+        ends.append(e)
+        offsets.append(offsets[-1] + len(e))
+    run_ends = np.concatenate(ends).astype(np.int32) if ends else np.zeros(0, np.int32)
+    return run_ends, np.asarray(offsets, np.int32), np.asarray(colours, np.uint8).reshape(-1, 3)
+
+
+def paint_annotations(anns, image_size: int = 512, device='cuda'):
+    """process_anns(anns, 512, colormap).astype(uint8) as a (512, 512, 3) uint8 device tensor"""
+    import torch
+    from . import ops
+    run_ends, offsets, colours = annotation_colours(anns, image_size)
+    out = torch.empty(image_size, image_size, 3, dtype=torch.uint8, device=device)
+    n = len(offsets) - 1
+    if n == 0:
+        return out.zero_()
+    ops.rle_paint(torch.from_numpy(run_ends).to(device), torch.from_numpy(offsets).to(device), torch.from_numpy(colours).to(device),
+                  n, image_size, image_size, out)
+    return out

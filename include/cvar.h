@@ -222,6 +222,10 @@ int cvar_clip_coef(const double* partials, int64_t count, float pre_scale, float
  *   cond (B,3,H,W) fp32 in [-1,1]; out (B, L) fp32, L = sum 2*pn^2; the control half of every scale with index
  *   >= first_masked_scale carries the nearest-downsampled (background ? 0 : 1) map, everything else 1.
  *   image_first = 0: token order [control | image] per scale ('ignore_mask'); 1: [image | control] ('ignore_mask_').
+ * cvar_rle_paint: raster half of process_anns (imagenetC.py:15-29): n_ann column-major COCO-RLE masks given as exclusive
+ *   prefix sums of their runs (run_ends, annotation a = [ann_offsets[a], ann_offsets[a+1])), painted in order onto a black
+ *   out[H][W][3] with colours[a][3]; later annotations overwrite earlier ones.  (RLE string decoding, the area filter and the
+ *   centroid -> colour index rule are host code: controlvar_amd/preprocess.py.)
  */
 int cvar_resample_u8(const void* src, int src_h, int src_w, int channels, int axis, int dst_extent,
                      const int* bounds, const int* coeffs, int ksize, void* dst, void* stream);
@@ -229,6 +233,7 @@ int cvar_crop_flip_normalize(const void* src, int src_h, int src_w, int channels
                              int flip, float* dst, void* stream);
 int cvar_ignore_mask(const float* cond, int B, int H, int W, const int* patch_nums_host, int n_scales, int first_masked_scale,
                      int image_first, float* out, int L, void* stream);
+int cvar_rle_paint(const int* run_ends, const int* ann_offsets, const void* colours, int n_ann, int H, int W, void* out, void* stream);
 
 #ifdef __cplusplus
 }

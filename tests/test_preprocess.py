@@ -103,3 +103,58 @@ def test_device_ignore_masks(gpu_device):
     from controlvar_amd import ops
     with pytest.raises(Exception):
         ops.ignore_mask(batch, 3, 256, 256, PN, 5, 0, torch.empty(3, 100, device=gpu_device), 100)      # L mismatch -> CVAR_EINVAL
+
+
+# ---------------------------------------------------------------- segmentation condition: RLE -> colour map (imagenetC.py:15-37)
+def _random_anns(seed, n=6, size=512):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:size, 0:size]
+    anns = []
+    for k in range(n):
+        cy, cx = rng.integers(40, size - 40, 2)
+        ry, rx = rng.integers(10, 140, 2)
+        m = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1).astype(np.uint8)
+        flat = m.T.reshape(-1)                                       # column-major
+        change = np.flatnonzero(np.diff(flat)) + 1
+        edges = np.concatenate([[0], change, [flat.size]])
+        runs = np.diff(edges).tolist()
+        if flat[0] == 1:
+            runs = [0] + runs
+        anns.append({'area': int(m.sum()), 'segmentation': {'size': [size, size], 'counts': P.rle_to_string(runs)}, '_runs': runs})
+    return anns
+
+
+def test_rle_string_codec_round_trip_and_small_cases():
+    assert P.rle_to_string([0, 4]) == '04' and P.rle_from_string('04') == [0, 4]
+    assert P.rle_from_string(P.rle_to_string([5, 3, 40, 2, 1000, 7])) == [5, 3, 40, 2, 1000, 7]
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        runs = rng.integers(0, 70000, rng.integers(1, 60)).tolist()
+        assert P.rle_from_string(P.rle_to_string(runs)) == runs       # deltas (negative values) and multi-character groups
+    for ann in _random_anns(1):
+        assert P.rle_from_string(ann['segmentation']['counts']) == ann['_runs']
+    assert P.create_color_map().shape == (124, 3) and tuple(P.create_color_map()[0]) == (0, 0, 64)
+
+
+def test_annotation_colours_follow_the_centroid_rule():
+    anns = _random_anns(2)
+    want = R.process_anns(anns, 512, P.create_color_map())
+    run_ends, offsets, colours = P.annotation_colours(anns, 512)
+    kept = [a for a in anns if a['area'] >= 5000]
+    assert len(offsets) - 1 == len(kept) == len(colours) and len(kept) >= 2
+    for a, col in zip(kept, colours):                                  # the last-painted colour survives somewhere unless fully covered
+        assert tuple(col) in {tuple(c) for c in P.create_color_map()}
+    assert want.shape == (512, 512, 3) and want.max() > 0
+    with pytest.raises(ValueError):
+        P.annotation_colours([{'area': 9999, 'segmentation': {'size': [256, 256], 'counts': P.rle_to_string([256 * 256])}}], 512)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('seed', [2, 3, 4])
+def test_device_mask_painting_equals_process_anns(gpu_device, seed):
+    anns = _random_anns(seed, n=8)
+    want = R.process_anns(anns, 512, P.create_color_map()).astype(np.uint8)
+    got = P.paint_annotations(anns, 512, gpu_device).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    empty = P.paint_annotations([a for a in anns if a['area'] < 5000], 512, gpu_device)
+    assert int(empty.max()) == 0
