@@ -83,6 +83,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     constexpr int SUB_M = BM / WM, SUB_N = BN / WN;
     constexpr int MI = SUB_M / 32, NJ = SUB_N / 32;
     static_assert(SUB_M % 32 == 0 && SUB_N % 32 == 0, "sub-tile must be 32x32 blocks");
+    // accumulator blocks are kept transposed (swapped MFMA operands) when a 32-row staging region per wave fits the pipeline LDS
+    constexpr bool TRANS = NW * 32 * (SUB_N + 4) * 4 <= NSTAGE * STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -343,7 +345,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #pragma unroll
                 for (int q = 0; q < NM; ++q) {
                     const int i = q / NJ, j = q % NJ;
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[ks & 1][j], a[ks & 1][i], acc[i][j], 0, 0, 0)
+                                      : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][i], b[ks & 1][j], acc[i][j], 0, 0, 0);
                     // reads of k-step ks+1: read r goes behind MFMA floor(r * NM / NR) (evenly spread, all done before the last MFMA)
                     if (ks < 3) {
 #pragma unroll
@@ -380,7 +383,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0)
+                                          : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
             } else {
                 f32x4_t a[MI], b[NJ];
 #pragma unroll
@@ -395,7 +399,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int j = 0; j < NJ; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+                            acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][e], a[i][e], acc[i][j], 0, 0, 0)
+                                              : __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -413,8 +418,35 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     constexpr int LPR = SUB_N / 8;                        // lanes per output row
     constexpr int RPP = 64 / LPR;                         // rows per pass (lanes >= RPP*LPR idle when LPR does not divide 64)
     constexpr int NPASS = (16 + RPP - 1) / RPP;
-    static_assert(NW * 16 * EROW * 4 <= NSTAGE * STAGE, "epilogue staging must fit the pipeline LDS");
-    float* stg = (float*)smem + wave * (16 * EROW);
+    // The MFMAs are issued with swapped operands (W fragment first), so a 32x32 accumulator block is held TRANSPOSED: lane & 31
+    // is the output row, register r the column (r&3) + 8*(r>>2) + 4*(lane>>5) - four consecutive columns per register quad.
+    // Staging a block is then 4 ds_write_b128 per 32 columns instead of 16 ds_write_b32 (LDS stores are the narrow port:
+    // 64-85 B/clk); rows of EROW = SUB_N + 4 floats keep the 8-lane store groups on distinct banks.
+    constexpr bool FULL32 = TRANS;
+    constexpr int SROWS = FULL32 ? 32 : 16;
+    static_assert(NW * SROWS * EROW * 4 <= NSTAGE * STAGE, "epilogue staging must fit the pipeline LDS");
+    float* stg = (float*)smem + wave * (SROWS * EROW);
+    // rows of block i land in the staging region: the whole transposed block at once (4 x b128 per 32 columns), or - tiles whose
+    // pipeline LDS is too small for 32 staged rows per wave keep the plain MFMA layout (lane = column) - 16 rows as b32 stores
+    auto stage_block = [&](int i, int half) {
+        if (FULL32) {
+            if (half != 0) return;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4_t q = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    *(f32x4_t*)(stg + lrow * EROW + j * 32 + 8 * g + 4 * hi) = q;
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8)
+                    stg[((r8 & 3) + 8 * (r8 >> 2) + 4 * hi) * EROW + j * 32 + lrow] = acc[i][j][8 * half + r8];
+        }
+    };
+    const int srow_half = FULL32 ? 16 : 0;             // staging row of output row 16*half + rr is rr + srow_half * half
     char* Cb = (char*)p.C;
     const long cz = zb * p.strideC + (long)blockIdx.y * p.split_stride, rz = zb * p.strideR;
     const int erow = lane / LPR, ecol = (lane % LPR) * 8;
@@ -479,18 +511,14 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             for (int ih = 0; ih < 2 * MI; ++ih) {
                 const int i = ih >> 1, half = ih & 1, bsel = ih & 1;
                 if constexpr (gate || res != 0) { if (ih + 1 < 2 * MI) fetch_operands(ih + 1); }
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int r8 = 0; r8 < 8; ++r8)
-                        stg[((r8 & 3) + 8 * (r8 >> 2) + 4 * hi) * EROW + j * 32 + lrow] = acc[i][j][8 * half + r8];
+                stage_block(i, half);
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) {
                     const int roff = i * 32 + 16 * half + ps * RPP;          // wave-uniform, known at compile time
                     const int m = mrow + roff;
                     if (lane_on && m < p.M && ((16 % RPP == 0) || ps * RPP + erow < 16)) {
-                        const f32x4_t a0 = *(const f32x4_t*)(stg_r + ps * RPP * EROW);
-                        const f32x4_t a1 = *(const f32x4_t*)(stg_r + ps * RPP * EROW + 4);
+                        const f32x4_t a0 = *(const f32x4_t*)(stg_r + (ps * RPP + srow_half * half) * EROW);
+                        const f32x4_t a1 = *(const f32x4_t*)(stg_r + (ps * RPP + srow_half * half) * EROW + 4);
                         float v[8];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[e] = a0[e] * p.alpha + bias8[e]; v[4 + e] = a1[e] * p.alpha + bias8[4 + e]; }
@@ -558,11 +586,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #ifdef CVAR_GEMM_TIMING
         const unsigned long long te0 = __builtin_amdgcn_s_memtime();
 #endif
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r8 = 0; r8 < 8; ++r8)
-                stg[((r8 & 3) + 8 * (r8 >> 2) + 4 * hi) * EROW + j * 32 + lrow] = acc[i][j][8 * half + r8];
+        stage_block(i, half);
 #ifdef CVAR_GEMM_TIMING
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned long long te1 = __builtin_amdgcn_s_memtime();
@@ -575,8 +599,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             if (!lane_on || rr >= 16 || m >= p.M) continue;
             float v[8];
             {
-                const f32x4_t a0 = *(const f32x4_t*)(stg + rr * EROW + ecol);
-                const f32x4_t a1 = *(const f32x4_t*)(stg + rr * EROW + ecol + 4);
+                const f32x4_t a0 = *(const f32x4_t*)(stg + (rr + srow_half * half) * EROW + ecol);
+                const f32x4_t a1 = *(const f32x4_t*)(stg + (rr + srow_half * half) * EROW + ecol + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = a0[e] * p.alpha; v[4 + e] = a1[e] * p.alpha; }
             }
