@@ -737,7 +737,7 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     const int ov = gemm_cfg_override();
     // bf16: 4 waves (2x2), one per SIMD, 128x128 per wave with the accumulators in AGPRs and a hand-placed issue order;
     // CVAR_GEMM_CFG=1 selects the 8-wave (2x4) variant instead (A/B runs; also the fp32 parity-mode configuration)
-    if (sizeof(T) == 2 && ov != 0 && ov != 1 && p.M >= 2048 && p.N % 256 == 0) return launch_cfg<T, 256, 256, 2, 2>(p, batch, st);
+    if (sizeof(T) == 2 && ov != 0 && ov != 1 && (p.M >= 2048 || (p.split_tiles > 0 && p.M > 1024)) && p.N % 256 == 0) return launch_cfg<T, 256, 256, 2, 2>(p, batch, st);
     if (ov != 0 && p.M >= 2048 && p.N % 256 == 0) return launch_cfg<T, 256, 256, 2, 4>(p, batch, st);
     return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
 }
@@ -822,8 +822,22 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     const int kt_elems = 128 / es;
     const int nk_all = (d->K + kt_elems - 1) / kt_elems;
     const int tm = d->M <= 64 ? (d->M + 63) / 64 : (d->M + 127) / 128, tn = (d->N + 127) / 128;
-    if (!d->conv && d->batch == 1 && d->M <= 1024 && (d->N % 4) == 0 && tm * tn < 128 && nk_all >= 8 && g_splitk_ws) {
-        int splits = min(16, max(2, 320 / (tm * tn)));
+    // (b) long-K GEMMs with a few hundred output tiles at most - the weight gradients of training (K = tokens of the batch):
+    //     256x256 tiles, and the number of K slices s <= 8 that minimises ceil(tiles * s / 256) / s (rounds of the chip per slice)
+    int long_k_splits = 0;
+    if (!d->conv && d->batch == 1 && d->dtype == CVAR_BF16 && d->M > 1024 && d->M % 256 == 0 && d->N % 256 == 0 && nk_all >= 128 && g_splitk_ws) {
+        const int tiles = (d->M / 256) * (d->N / 256);
+        if (tiles < 256) {
+            double best = 1e30;
+            for (int sp = 1; sp <= 8; ++sp) {
+                const double cost = (double)((tiles * sp + 255) / 256) / sp + 0.01 * sp;     // small bias against needless slices
+                if (cost < best && (size_t)sp * d->M * d->N * sizeof(float) <= g_splitk_ws_bytes) { best = cost; long_k_splits = sp; }
+            }
+            if (long_k_splits < 2) long_k_splits = 0;
+        }
+    }
+    if (long_k_splits || (!d->conv && d->batch == 1 && d->M <= 1024 && (d->N % 4) == 0 && tm * tn < 128 && nk_all >= 8 && g_splitk_ws)) {
+        int splits = long_k_splits ? long_k_splits : min(16, max(2, 320 / (tm * tn)));
         int per = (nk_all + splits - 1) / splits;
         if (per < 2) per = 2;
         splits = (nk_all + per - 1) / per;
