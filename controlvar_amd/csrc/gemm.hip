@@ -146,7 +146,10 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     const char* const a_tile = CONV ? Abase : Abase + (long)m0 * p.lda * ES;
     const char* const w_tile = Wbase + (long)n0 * p.ldw * ES;
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_tile, 0, CONV ? (int)p.conv_bytes : 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_tile, 0, 0x7fffffff, 0x00020000);
+    // W's range ends with the last row of the matrix: when K is not a multiple of the K tile (conv: K = 9 Cin) the last row's
+    // tail would otherwise read whatever follows the weights - the A side is zero there, but 0 x Inf/NaN garbage is NaN
+    const long w_bytes = ((long)(p.N - n0 - 1) * p.ldw + p.K) * ES;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_tile, 0, (int)min(w_bytes, (long)0x7fffffff), 0x00020000);
     // conv FAST (stride 1, no upsample, Cin % 32 == 0, input < 2 GiB): each 32-element half of a K tile lies inside ONE tap, so
     // (tap, channel) of the two halves are wave-uniform scalars advanced per K tile; a lane keeps its pixel's byte offset and a
     // 9-bit mask of in-range taps per piece, and because the swizzled chunk of a lane is the same for all its pieces
@@ -339,7 +342,6 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             // (every second MFMA) and one DMA piece with its address math (every fourth), so the matrix pipe never waits
             // behind a bunch of LDS / DMA issues.
             constexpr int NM = MI * NJ, NR = MI + NJ;           // MFMAs / fragment reads per k-step
-            static_assert(NR <= NM && NL <= 2 * NM, "schedule needs a slot per read and per early DMA piece");
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -358,11 +360,11 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                     if (DMA_EARLY == 1) {
 #pragma unroll
                         for (int t = 0; t < NL; ++t)
-                            if (((t + 1) * 2 * NM) / NL - 1 == ks * NM + q) issue_one(ktn, nxt, t);
+                            if (max(((t + 1) * 2 * NM) / NL - 1, 0) == ks * NM + q) issue_one(ktn, nxt, t);
                     } else {
 #pragma unroll
                         for (int t = 0; t < NL; ++t)
-                            if (((t + 1) * 4 * NM) / NL - 1 == ks * NM + q) issue_one(ktn, nxt, t);
+                            if (max(((t + 1) * 4 * NM) / NL - 1, 0) == ks * NM + q) issue_one(ktn, nxt, t);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -719,6 +721,18 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     // small-M problems (early scales, ada_lin) use a 64-row tile to put more blocks on the chip
     if (p.M <= 64) return launch_cfg<T, 64, 128, 1, 4>(p, batch, st);
     // channel counts of the VQVAE (160, 320) are multiples of 160 but not of 128: a 160-wide tile wastes no MFMA work
+    // few output channels (the decoder's conv_out: 160 -> 3): a 256x32 tile wastes 10x instead of 42x of the MFMA work of a
+    // 128-wide tile; the kernel is then bound by streaming the activations, as it should be
+    if constexpr (sizeof(T) == 2) {
+        if (p.conv && p.N <= 32 && p.M >= 4096 && p.stride == 1 && !p.up && p.Cin % 32 == 0 && p.split_tiles == 0 && gemm_cfg_override() != 0) {
+            const long in_bytes = (long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin * (long)sizeof(T);
+            if (in_bytes < (1L << 31)) {
+                GemmParams q = p;
+                q.conv_bytes = (unsigned)in_bytes;
+                return launch_cfg<T, 256, 32, 4, 1, 2, true>(q, batch, st);
+            }
+        }
+    }
     if (p.N % 160 == 0 && (p.N % 128 != 0 || p.conv) && p.M >= 4096) {
         // stride-1 3x3 convs of the decoder / encoder trunks: 256x160 tile on the scalar-state conv addressing (conv FAST)
         const long in_bytes = p.conv ? (long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin * (long)sizeof(T) : 0;
