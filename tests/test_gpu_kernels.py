@@ -347,3 +347,26 @@ def test_gemm_split_k(gpu_device, dtype, M, N, K):
     arena = torch.zeros(R, Lmax, N, device=gpu_device, dtype=dtype)
     ops.gemm(Ad, Wd, arena, M=M, N=N, K=K, bias=b.to(gpu_device), remap=(l, Lmax, off))
     assert close(arena[:, off:off + l].reshape(M, N), acc, dtype, 2e-4) and arena[:, :off].abs().max() == 0
+
+
+def test_conv_fast_never_reads_past_the_weights(gpu_device):
+    """K = 9*Cin is not a multiple of the 64-element K tile: the tail of the LAST weight row lies past the tensor.  The
+    activations are zero there, but 0 x NaN is NaN - the weights are placed directly in front of NaNs to prove the kernel's
+    buffer range stops at the last weight (regression: decoder output depended on what the allocator had left behind)."""
+    dtype = torch.bfloat16
+    B, H, W, cin, cout = 2, 48, 48, 160, 160
+    x = rnd(B, cin, H, W, seed=41)
+    w = rnd(cout, cin, 3, 3, seed=42, scale=1.0 / math.sqrt(9 * cin))
+    b = rnd(cout, seed=43)
+    ref = F.conv2d(x.to(dtype).float(), w.to(dtype).float(), b, padding=1)
+    xd = to_dev(x.permute(0, 2, 3, 1).reshape(B * H * W, cin), dtype, gpu_device)
+    n = cout * 9 * cin
+    buf = torch.full((n + 4096,), float('nan'), device=gpu_device, dtype=dtype)
+    buf[:n] = w.permute(0, 2, 3, 1).reshape(-1).to(dtype).to(gpu_device)
+    wd = buf[:n].view(cout, 9 * cin)
+    out = torch.empty(B * H * W, cout, device=gpu_device, dtype=torch.float32)
+    ops.gemm(xd, wd, out, M=B * H * W, N=cout, K=9 * cin, bias=b.to(gpu_device),
+             conv=dict(Hin=H, Win=W, Cin=cin, Hout=H, Wout=W, stride=1, up=0))
+    got = out.cpu().reshape(B, H, W, cout).permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    assert close(got, ref, dtype)
