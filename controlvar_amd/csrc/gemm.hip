@@ -65,8 +65,9 @@ static void make_fast_div(long d, unsigned* magic, int* shift) {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2, bool FAST = false>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2, bool FAST = false, bool CUP = false>
 __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParams p) {
+    static_assert(!CUP || (CONV && FAST), "CUP (nearest x2 upsample folded into the conv) is a conv FAST variant");
     constexpr int NW = WM * WN;
     constexpr bool FRAG_PIPE = (BM == 256) && (!CONV || FAST);
 #ifndef CVAR_DMA_EARLY
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     //   offset = pixel + (half ? delta1 : delta0),  valid = mask >> (half ? tap1 : tap0) & 1,  invalid -> out-of-range offset -> zeros
     unsigned c_vm[CONV ? A_PER_W : 1];
     const int lane_half = (slot ^ ((((wave * 8 + lr)) >> 1) & 7)) >> 2;
-    int cf_tap = 0, cf_ci = 0, lane_D = 0, lane_T = 31;
+    int cf_tap = 0, cf_ci = 0, lane_D = 0, lane_T = 15, lane_ky = 0, lane_kx = 0;
     static_assert(!(CONV && FAST) || (NW % 2 == 0), "lane-constant half needs an even wave count");
     if (FAST && !CONV) {
 #pragma unroll
@@ -176,12 +177,20 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             if (b >= 0) {
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
-                    if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) vm |= 1u << t;
+                    const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;           // tap position on the OUTPUT grid (= input grid unless CUP)
+                    if (iy >= 0 && iy < p.Hout && ix >= 0 && ix < p.Wout) vm |= 1u << t;
                 }
             }
+            if (CUP) {
+                // nearest x2 upsample folded in: tap (ky, kx) of output pixel (oy, ox) reads input pixel
+                // ((oy + ky - 1) >> 1, (ox + kx - 1) >> 1) = (oy >> 1) + ((py + ky - 1) >> 1), ... with py = oy & 1: a -1 / 0 / +1
+                // step around the base pixel (oy >> 1, ox >> 1); the parities ride in bits 16, 17 of the tap mask (the tap index never exceeds 15)
+                vm |= (unsigned)(oy & 1) << 16 | (unsigned)(ox & 1) << 17;
+                a_off[jj] = (unsigned)(((max(b, 0) * p.Hin + (oy >> 1)) * p.Win + (ox >> 1)) * p.Cin * ES + (chunk & 3) * 16);
+            } else {
+                a_off[jj] = (unsigned)(((max(b, 0) * p.Hin + oy) * p.Win + ox) * p.Cin * ES + (chunk & 3) * 16);
+            }
             c_vm[jj] = vm;
-            a_off[jj] = (unsigned)(((max(b, 0) * p.Hin + oy) * p.Win + ox) * p.Cin * ES + (chunk & 3) * 16);
         }
     }
     if (FAST) {
@@ -202,7 +211,13 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
         };
         const int d0 = delta(t0, c0), d1 = delta(t1, c1);
         lane_D = lane_half ? d1 : d0;
-        lane_T = lane_half ? min(t1, 31) : min(t0, 31);
+        lane_T = lane_half ? min(t1, 15) : min(t0, 15);     // taps >= 9 (K tail) index mask bits 9..15, which are always 0
+        if (CUP) {
+            const int tt = min(lane_T, 8);
+            lane_ky = (tt * 11) >> 5;
+            lane_kx = tt - lane_ky * 3;
+            lane_D = (lane_half ? c1 : c0) * ES;          // channel part only; the pixel step depends on the piece's row parity
+        }
         int c2 = c1 + 32, t2 = t1;
         if (c2 >= p.Cin) { c2 -= p.Cin; ++t2; }
         cf_tap = t2; cf_ci = c2;
@@ -228,7 +243,13 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             // buffer_load_dwordx4 v_off, s[rsrc], s_koff offen lds: resource and K offset are scalar, the lane offset is fixed
             if (idx < A_PER_W) {
                 if (CONV) {
-                    const int off = ((c_vm[idx] >> lane_T) & 1u) ? (int)(a_off[idx] + (unsigned)lane_D) : (int)0x80000000;
+                    int step = lane_D;
+                    if (CUP) {
+                        const int dy = ((int)((c_vm[idx] >> 16) & 1u) + lane_ky - 1) >> 1;
+                        const int dx = ((int)((c_vm[idx] >> 17) & 1u) + lane_kx - 1) >> 1;
+                        step += (dy * p.Win + dx) * p.Cin * ES;
+                    }
+                    const int off = ((c_vm[idx] >> lane_T) & 1u) ? (int)(a_off[idx] + (unsigned)step) : (int)0x80000000;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(sbase + (wave + idx * NW) * 1024), 16, off, 0, 0, 0);
                 } else {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(sbase + (wave + idx * NW) * 1024), 16, (int)a_off[idx], kt * 128, 0, 0);
@@ -675,7 +696,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #endif
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE = 2, bool CONVFAST = false>
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE = 2, bool CONVFAST = false, bool CUP = false>
 static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     GemmParams p = gp;
     p.tiles_m = (p.M + BM - 1) / BM;
@@ -687,7 +708,7 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits, (unsigned)batch), block(WM * WN * 64);
     if constexpr (CONVFAST) {            // this configuration exists for the conv FAST kernel only
         if (!p.conv) return CVAR_EINVAL;
-        auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, true, NSTAGE, true>;
+        auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, true, NSTAGE, true, CUP>;
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
         CVAR_CHECK_LAUNCH();
@@ -737,11 +758,12 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
         // stride-1 3x3 convs of the decoder / encoder trunks: 256x160 tile on the scalar-state conv addressing (conv FAST)
         const long in_bytes = p.conv ? (long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin * (long)sizeof(T) : 0;
         if constexpr (sizeof(T) == 2) {
-            if (p.conv && p.stride == 1 && !p.up && p.Cin % 32 == 0 && p.split_tiles == 0 && in_bytes < (1L << 31) &&
-                (long)159 * p.ldw * 2 + (long)p.K * 2 + 256 < (1L << 31) && gemm_cfg_override() != 0) {
+            if (p.conv && p.stride == 1 && p.Cin % 32 == 0 && p.split_tiles == 0 && in_bytes < (1L << 31) &&
+                (long)159 * p.ldw * 2 + (long)p.K * 2 + 256 < (1L << 31) && gemm_cfg_override() != 0 &&
+                (!p.up || (p.Hout == 2 * p.Hin && p.Wout == 2 * p.Win))) {
                 GemmParams q = p;
                 q.conv_bytes = (unsigned)in_bytes;
-                return launch_cfg<T, 256, 160, 4, 1, 2, true>(q, batch, st);
+                return p.up ? launch_cfg<T, 256, 160, 4, 1, 2, true, true>(q, batch, st) : launch_cfg<T, 256, 160, 4, 1, 2, true>(q, batch, st);
             }
         }
         return launch_cfg<T, 128, 160, 4, 1>(p, batch, st);
