@@ -177,8 +177,13 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             if (b >= 0) {
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;           // tap position on the OUTPUT grid (= input grid unless CUP)
-                    if (iy >= 0 && iy < p.Hout && ix >= 0 && ix < p.Wout) vm |= 1u << t;
+                    if (p.stride == 2) {                                          // (0,1,0,1)-padded stride 2: taps start AT the pixel
+                        const int iy = 2 * oy + t / 3, ix = 2 * ox + t % 3;
+                        if (iy < p.Hin && ix < p.Win) vm |= 1u << t;
+                    } else {
+                        const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;       // tap position on the OUTPUT grid (= input grid unless CUP)
+                        if (iy >= 0 && iy < p.Hout && ix >= 0 && ix < p.Wout) vm |= 1u << t;
+                    }
                 }
             }
             if (CUP) {
@@ -188,7 +193,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                 vm |= (unsigned)(oy & 1) << 16 | (unsigned)(ox & 1) << 17;
                 a_off[jj] = (unsigned)(((max(b, 0) * p.Hin + (oy >> 1)) * p.Win + (ox >> 1)) * p.Cin * ES + (chunk & 3) * 16);
             } else {
-                a_off[jj] = (unsigned)(((max(b, 0) * p.Hin + oy) * p.Win + ox) * p.Cin * ES + (chunk & 3) * 16);
+                const int sy = p.stride == 2 ? 2 * oy : oy, sx = p.stride == 2 ? 2 * ox : ox;
+                a_off[jj] = (unsigned)(((max(b, 0) * p.Hin + sy) * p.Win + sx) * p.Cin * ES + (chunk & 3) * 16);
             }
             c_vm[jj] = vm;
         }
@@ -207,7 +213,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
         if (c1 >= p.Cin) { c1 -= p.Cin; ++t1; }
         auto delta = [&](int t, int c) {
             const int tt = min(t, 8), ky = (tt * 11) >> 5, kx = tt - ky * 3;
-            return (((ky - 1) * p.Win + (kx - 1)) * p.Cin + c) * ES;
+            const int pad = p.stride == 2 ? 0 : 1;
+            return (((ky - pad) * p.Win + (kx - pad)) * p.Cin + c) * ES;
         };
         const int d0 = delta(t0, c0), d1 = delta(t1, c1);
         lane_D = lane_half ? d1 : d0;
@@ -758,7 +765,7 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
         // stride-1 3x3 convs of the decoder / encoder trunks: 256x160 tile on the scalar-state conv addressing (conv FAST)
         const long in_bytes = p.conv ? (long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin * (long)sizeof(T) : 0;
         if constexpr (sizeof(T) == 2) {
-            if (p.conv && p.stride == 1 && p.Cin % 32 == 0 && p.split_tiles == 0 && in_bytes < (1L << 31) &&
+            if (p.conv && (p.stride == 1 || (p.stride == 2 && !p.up)) && p.Cin % 32 == 0 && p.split_tiles == 0 && in_bytes < (1L << 31) &&
                 (long)159 * p.ldw * 2 + (long)p.K * 2 + 256 < (1L << 31) && gemm_cfg_override() != 0 &&
                 (!p.up || (p.Hout == 2 * p.Hin && p.Wout == 2 * p.Win))) {
                 GemmParams q = p;

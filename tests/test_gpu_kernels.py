@@ -112,24 +112,29 @@ def test_conv3x3(gpu_device, dtype, mode, cin, cout):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('cin,cout,up', [(32, 160, 0), (160, 320, 1)])
+@pytest.mark.parametrize('cin,cout,up', [(32, 160, 0), (160, 320, 1), (160, 160, 2)])     # up = 2 stands for the stride-2 downsample
 def test_conv3x3_wide_tile(gpu_device, dtype, cin, cout, up):
     """M >= 4096 and N % 160 == 0: exercises the 128x160 tile configuration (VQVAE channel counts)."""
-    B, H, W = 2, 48, 48
+    s2 = up == 2
+    up = 0 if s2 else up
+    B, H, W = (2, 97, 96) if s2 else (2, 48, 48)             # odd height: the (0,1,0,1) pad row is exercised
     x = rnd(B, cin, H, W, seed=31)
     w = rnd(cout, cin, 3, 3, seed=32, scale=1.0 / math.sqrt(9 * cin))
     b = rnd(cout, seed=33)
     xr, wr = x.to(dtype).float(), w.to(dtype).float()
-    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    Ho, Wo = (2 * H, 2 * W) if up else ((H // 2, W // 2) if s2 else (H, W))
     res = rnd(B, cout, Ho, Wo, seed=34)
-    src = F.interpolate(xr, scale_factor=2, mode='nearest') if up else xr
-    ref = F.conv2d(src, wr, b, padding=1) + res.to(dtype).float()
+    if s2:
+        ref = F.conv2d(F.pad(xr, (0, 1, 0, 1)), wr, b, stride=2, padding=0)[:, :, :Ho, :Wo] + res.to(dtype).float()
+    else:
+        src = F.interpolate(xr, scale_factor=2, mode='nearest') if up else xr
+        ref = F.conv2d(src, wr, b, padding=1) + res.to(dtype).float()
     xd = to_dev(x.permute(0, 2, 3, 1).reshape(B * H * W, cin), dtype, gpu_device)
     wd = to_dev(w.permute(0, 2, 3, 1).reshape(cout, 9 * cin), dtype, gpu_device)
     resd = to_dev(res.permute(0, 2, 3, 1).reshape(B * Ho * Wo, cout), dtype, gpu_device)
     out = torch.empty(B * Ho * Wo, cout, device=gpu_device, dtype=dtype)
     ops.gemm(xd, wd, out, M=B * Ho * Wo, N=cout, K=9 * cin, bias=b.to(gpu_device), residual=resd,
-             conv=dict(Hin=H, Win=W, Cin=cin, Hout=Ho, Wout=Wo, stride=1, up=up))
+             conv=dict(Hin=H, Win=W, Cin=cin, Hout=Ho, Wout=Wo, stride=2 if s2 else 1, up=up))
     got = out.float().cpu().reshape(B, Ho, Wo, cout).permute(0, 3, 1, 2)
     assert close(got, ref, dtype, bf16_rel=2e-2)
 
