@@ -11,7 +11,7 @@ import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CVAR_LIB') or os.path.join(HERE, 'libcvar_hip.so')      # CVAR_LIB: A/B runs against another build
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 CVAR_F32, CVAR_BF16 = 0, 1
 ACT_NONE, ACT_GELU_TANH = 0, 1
@@ -45,6 +45,8 @@ SIGNATURES = {
     'cvar_gemm': (c_i, [C.POINTER(GemmDesc), c_p]),
     'cvar_resample_u8': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p]),
     'cvar_crop_flip_normalize': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    'cvar_sumsq_multi': (c_i, [c_p, c_i, c_p, c_p]),
+    'cvar_adamw_multi': (c_i, [c_p, c_i, C.POINTER(c_f), C.POINTER(c_f), c_i, c_f, c_f, c_f, c_i, c_p, c_f, c_p]),
     'cvar_rle_paint': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     'cvar_ignore_mask': (c_i, [c_p, c_i, c_i, c_i, C.POINTER(c_i), c_i, c_i, c_i, c_p, c_i, c_p]),
     'cvar_gemm_set_workspace': (c_i, [c_p, c_l]),

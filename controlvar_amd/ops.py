@@ -256,6 +256,24 @@ def sumsq(x, partial, slot):
     check(_lib.load().cvar_sumsq(_ptr(x), x.numel(), _ptr(partial) + 8 * 256 * slot, _stream()), 'cvar_sumsq')
 
 
+def adam_table(entries, device) -> torch.Tensor:
+    """device table of cvar_adam_tensor {p, g, m, v, n, group, pad} (6 x int64 per entry) for the multi-tensor optimizer calls"""
+    rows = []
+    for (p, g, m, v, group) in entries:
+        rows.append([p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), int(group) & 0xffffffff])
+    return torch.tensor(rows, dtype=torch.int64).to(device)
+
+
+def sumsq_multi(table: torch.Tensor, n: int, partial: torch.Tensor):
+    check(_lib.load().cvar_sumsq_multi(_ptr(table), n, _ptr(partial), _stream()), 'cvar_sumsq_multi')
+
+
+def adamw_multi(table: torch.Tensor, n: int, lrs: Sequence[float], wds: Sequence[float], b1, b2, eps, step, gscale_dev=None, gscale=1.0):
+    la = (C.c_float * len(lrs))(*lrs)
+    wa = (C.c_float * len(wds))(*wds)
+    check(_lib.load().cvar_adamw_multi(_ptr(table), n, la, wa, len(lrs), b1, b2, eps, step, _ptr(gscale_dev), gscale, _stream()), 'cvar_adamw_multi')
+
+
 def clip_coef(partial, count, pre_scale, max_norm, out2):
     check(_lib.load().cvar_clip_coef(_ptr(partial), count, pre_scale, max_norm, _ptr(out2), _stream()), 'cvar_clip_coef')
 

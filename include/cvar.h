@@ -204,6 +204,13 @@ int cvar_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr
  * out2 = {pre_scale * sqrt(sum), min(1, max_norm / (norm + 1e-6))}. */
 int cvar_sumsq(const float* x, int64_t n, double* partial256, void* stream);
 int cvar_clip_coef(const double* partials, int64_t count, float pre_scale, float max_norm, float* out2, void* stream);
+/* Multi-tensor forms of the two above: ONE launch over a device table of cvar_adam_tensor (a d24 model has ~830 parameters).
+ * Per tensor the arithmetic and summation order are exactly cvar_sumsq's / cvar_adamw's; partials is [n_tensors][256];
+ * lr / weight decay come per parameter group (<= 8 groups, utils/lr_control.py:67-101) as small host arrays. */
+typedef struct { float* p; const float* g; float* m; float* v; int64_t n; int32_t group; int32_t pad; } cvar_adam_tensor;
+int cvar_sumsq_multi(const void* table_dev /* cvar_adam_tensor[n_tensors] */, int n_tensors, double* partials, void* stream);
+int cvar_adamw_multi(const void* table_dev, int n_tensors, const float* lr_by_group_host, const float* wd_by_group_host, int n_groups,
+                     float beta1, float beta2, float eps, int step, const float* gscale_dev, float gscale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Input pipeline of the tokenizer: what datasets/imagenetC.py:128-188 and
