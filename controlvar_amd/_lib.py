@@ -11,10 +11,10 @@ import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CVAR_LIB') or os.path.join(HERE, 'libcvar_hip.so')      # CVAR_LIB: A/B runs against another build
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 CVAR_F32, CVAR_BF16 = 0, 1
-ACT_NONE, ACT_GELU_TANH = 0, 1
+ACT_NONE, ACT_GELU_TANH, ACT_GELU_GRAD = 0, 1, 2
 
 c_p = C.c_void_p
 c_i = C.c_int
@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ('residual', c_p), ('res_dtype', c_i), ('ldr', c_l),
         ('C', c_p), ('out_dtype', c_i), ('ldc', c_l),
         ('remap_l', c_i), ('remap_L', c_i), ('remap_off', c_i),
+        ('pre_act', c_p), ('aux', c_p),
     ]
 
 

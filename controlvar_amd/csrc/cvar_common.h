@@ -89,5 +89,13 @@ __device__ __forceinline__ float gelu_tanh_fast(float t) {
     return t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(arg));
 }
 
+__device__ __forceinline__ float gelu_tanh_grad(float t) {
+    // g(t) = t * sig(2u), u = k (t + 0.044715 t^3)  ->  g' = sig + t * sig * (1 - sig) * 2k (1 + 3*0.044715 t^2)
+    const float k2 = 2.0f * 0.7978845608028654f;
+    const float u2 = k2 * (t + 0.044715f * t * t * t);
+    const float sg = 1.0f / (1.0f + __expf(-u2));
+    return sg + t * sg * (1.0f - sg) * k2 * (1.0f + 0.134145f * t * t);
+}
+
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -38,6 +38,7 @@ struct GemmParams {
     const float* gate; long ldg; int gate_rows;
     const void* residual; int res_dtype; long ldr;
     void* C; int out_dtype; long ldc;
+    void* C2; const void* aux;     // optional: pre-activation copy (act GELU_TANH) / gelu' operand (act GELU_GRAD), laid out like C
     int remap_l, remap_L, remap_off;
     int tiles_m, tiles_n;
     int cv_adv, cv_rem;       // conv: a K tile advances (tap, ci) by (KT / Cin, KT % Cin) plus one carry
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     const bool vec_ok = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && ((p.strideC & 7) == 0) && (((uintptr_t)p.C & 15) == 0) &&
                         (!p.residual || (((p.ldr & 7) == 0) && ((p.strideR & 7) == 0) && (((uintptr_t)p.residual & 15) == 0))) &&
                         (!p.gate || (((p.ldg & 3) == 0) && (((uintptr_t)p.gate & 15) == 0))) &&
-                        (!p.bias || (((uintptr_t)p.bias & 15) == 0));
+                        (!p.bias || (((uintptr_t)p.bias & 15) == 0)) && (!p.C2 || (((uintptr_t)p.C2 & 15) == 0));
     // per-lane constants of the row-major phase: the column group never changes, so bias is loaded once
     const int n = n0 + wn * SUB_N + ecol;
     const bool lane_on = (erow < RPP) && (n < p.N);
@@ -518,6 +519,9 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             // vmcnt retires in order, so a load queued behind stores would make its consumer wait for the store latency too
             f32x4_t gq[2][gate ? NPASS : 1][2], rq[2][res == 1 ? NPASS : 1][2];
             bf16x8_t rb[2][res == 2 ? NPASS : 1];
+            bf16x8_t xb[2][act == CVAR_ACT_GELU_GRAD ? NPASS : 1];        // gelu' operand (bf16 variants only)
+            const char* x_lane = act == CVAR_ACT_GELU_GRAD ? (const char*)p.aux + (cz + n) * 2 : nullptr;
+            char* c2_lane = p.C2 ? (char*)p.C2 + (cz + n) * OES : nullptr;
             auto fetch_operands = [&](int ih) {
                 const int i = ih >> 1, half = ih & 1, bsel = ih & 1;
 #pragma unroll
@@ -533,14 +537,15 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                             rq[bsel][ps][0] = *(const f32x4_t*)rp; rq[bsel][ps][1] = *(const f32x4_t*)(rp + 4);
                         }
                         if constexpr (res == 2) rb[bsel][ps] = *(const bf16x8_t*)(r_lane + (long)m * p.ldr * 2);
+                        if constexpr (act == CVAR_ACT_GELU_GRAD) xb[bsel][ps] = *(const bf16x8_t*)(x_lane + (long)m * p.ldc * 2);
                     }
                 }
             };
-            if constexpr (gate || res != 0) fetch_operands(0);
+            if constexpr (gate || res != 0 || act == CVAR_ACT_GELU_GRAD) fetch_operands(0);
 #pragma clang loop unroll(full)
             for (int ih = 0; ih < 2 * MI; ++ih) {
                 const int i = ih >> 1, half = ih & 1, bsel = ih & 1;
-                if constexpr (gate || res != 0) { if (ih + 1 < 2 * MI) fetch_operands(ih + 1); }
+                if constexpr (gate || res != 0 || act == CVAR_ACT_GELU_GRAD) { if (ih + 1 < 2 * MI) fetch_operands(ih + 1); }
                 stage_block(i, half);
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) {
@@ -553,8 +558,20 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[e] = a0[e] * p.alpha + bias8[e]; v[4 + e] = a1[e] * p.alpha + bias8[4 + e]; }
                         if constexpr (act == CVAR_ACT_GELU_TANH) {
+                            if (c2_lane) {                                   // fc1 forward of training: keep the pre-activation too
+                                if constexpr (out_bf) *(bf16x8_t*)(c2_lane + (long)m * p.ldc * OES) = pack_bf16x8(v);
+                                else {
+                                    const f32x4_t q0 = {v[0], v[1], v[2], v[3]}, q1 = {v[4], v[5], v[6], v[7]};
+                                    *(f32x4_t*)(c2_lane + (long)m * p.ldc * OES) = q0;
+                                    *(f32x4_t*)(c2_lane + (long)m * p.ldc * OES + 16) = q1;
+                                }
+                            }
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] = (ES == 2) ? gelu_tanh_fast(v[e]) : gelu_tanh_f(v[e]);
+                        }
+                        if constexpr (act == CVAR_ACT_GELU_GRAD) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] *= gelu_tanh_grad(bf16_to_f32((bf16_t)xb[bsel][ps][e]));
                         }
                         if constexpr (gate) {
 #pragma unroll
@@ -597,6 +614,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             } else if constexpr (!CONV) {
                 if (!p.gate && !p.residual && p.act == CVAR_ACT_GELU_TANH && obf && !rm) {
                     run(Y{}, I1{}, NO{}, I0{}, NO{}); done = true;
+                } else if (!p.gate && !p.residual && p.act == CVAR_ACT_GELU_GRAD && obf && ES == 2 && !rm && (((uintptr_t)p.aux & 15) == 0)) {
+                    run(Y{}, I2{}, NO{}, I0{}, NO{}); done = true;
                 } else if (p.gate && p.residual && p.res_dtype == CVAR_F32 && p.act == CVAR_ACT_NONE && !obf && !rm) {
                     run(NO{}, I0{}, Y{}, I1{}, NO{}); done = true;
                 }
@@ -644,8 +663,15 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += bias8[e];
                 if (p.act == CVAR_ACT_GELU_TANH) {
+                    if (p.C2) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) st_any(p.C2, p.out_dtype, cz + (long)m * p.ldc + n + e, v[e]);
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (ES == 2) ? gelu_tanh_fast(v[e]) : gelu_tanh_f(v[e]);
+                } else if (p.act == CVAR_ACT_GELU_GRAD) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= gelu_tanh_grad(ld_any(p.aux, p.out_dtype, cz + (long)m * p.ldc + n + e));
                 }
                 if (grow) {
                     const f32x4_t g0 = *(const f32x4_t*)(grow + n), g1 = *(const f32x4_t*)(grow + n + 4);
@@ -680,7 +706,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                     if (n + e >= p.N) break;
                     float x = v[e];
                     if (p.bias) x += p.bias[n + e];
-                    if (p.act == CVAR_ACT_GELU_TANH) x = gelu_tanh_f(x);
+                    if (p.act == CVAR_ACT_GELU_TANH) { if (p.C2) st_any(p.C2, p.out_dtype, cz + (long)m * p.ldc + n + e, x); x = gelu_tanh_f(x); }
+                    else if (p.act == CVAR_ACT_GELU_GRAD) x *= gelu_tanh_grad(ld_any(p.aux, p.out_dtype, cz + (long)m * p.ldc + n + e));
                     if (grow) x *= grow[n + e];
                     if (p.residual) x += ld_any(p.residual, p.res_dtype, rz + (long)m * p.ldr + n + e);
                     st_any(Cb, p.out_dtype, cz + orow * p.ldc + n + e, x);
@@ -813,7 +840,8 @@ __global__ __launch_bounds__(256) void cvar_splitk_epilogue_kernel(const float* 
         for (int e = 0; e < 4; ++e) {
             float x = v[e] * p.alpha;
             if (p.bias) x += p.bias[n + e];
-            if (p.act == CVAR_ACT_GELU_TANH) x = gelu_tanh_f(x);
+            if (p.act == CVAR_ACT_GELU_TANH) { if (p.C2) st_any(p.C2, p.out_dtype, (long)m * p.ldc + n + e, x); x = gelu_tanh_f(x); }
+            else if (p.act == CVAR_ACT_GELU_GRAD) x *= gelu_tanh_grad(ld_any(p.aux, p.out_dtype, (long)m * p.ldc + n + e));
             if (grow) x *= grow[n + e];
             if (p.residual) x += ld_any(p.residual, p.res_dtype, (long)m * p.ldr + n + e);
             st_any(p.C, p.out_dtype, orow * p.ldc + n + e, x);
@@ -848,6 +876,9 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
         return CVAR_EUNSUPPORTED;
     }
     if (d->gate && d->gate_rows <= 0) return CVAR_EINVAL;
+    if (d->act == CVAR_ACT_GELU_GRAD && !d->aux) return CVAR_EINVAL;
+    if (d->pre_act && d->act != CVAR_ACT_GELU_TANH) return CVAR_EINVAL;
+    if ((d->pre_act || d->aux) && d->remap_l > 0) return CVAR_EUNSUPPORTED;
     GemmParams p;
     p.M = d->M; p.N = d->N; p.K = d->K;
     p.A = (const char*)d->A; p.lda = d->lda; p.W = (const char*)d->W; p.ldw = d->ldw;
@@ -858,6 +889,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     p.gate = d->gate; p.ldg = d->ldg; p.gate_rows = d->gate_rows;
     p.residual = d->residual; p.res_dtype = d->res_dtype; p.ldr = d->ldr;
     p.C = d->C; p.out_dtype = d->out_dtype; p.ldc = d->ldc;
+    p.C2 = d->pre_act; p.aux = d->aux;
     p.remap_l = d->remap_l; p.remap_L = d->remap_L; p.remap_off = d->remap_off;
     p.tiles_m = p.tiles_n = 0;
     p.cv_adv = p.cv_rem = 0; p.conv_bytes = 0;
@@ -891,7 +923,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
         const size_t need = (size_t)splits * d->M * d->N * sizeof(float);
         if (splits > 1 && need <= g_splitk_ws_bytes) {
             GemmParams ps = p;
-            ps.alpha = 1.0f; ps.bias = nullptr; ps.act = CVAR_ACT_NONE; ps.gate = nullptr; ps.residual = nullptr;
+            ps.alpha = 1.0f; ps.bias = nullptr; ps.act = CVAR_ACT_NONE; ps.gate = nullptr; ps.residual = nullptr; ps.C2 = nullptr; ps.aux = nullptr;
             ps.C = g_splitk_ws; ps.out_dtype = CVAR_F32; ps.ldc = d->N; ps.remap_l = 0; ps.strideC = 0;
             ps.split_tiles = per; ps.split_stride = (long)d->M * d->N;
             const int rc = d->dtype == CVAR_BF16 ? launch_typed<bf16_t>(ps, 1, st) : launch_typed<float>(ps, 1, st);

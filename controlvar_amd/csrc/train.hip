@@ -37,13 +37,6 @@ extern "C" int cvar_gate_residual(float* x, const void* f, int dtype, const floa
 }
 
 // ---- GELU(tanh) forward / backward ---------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_tanh_grad(float t) {
-    // g(t) = t * sig(2u), u = k (t + 0.044715 t^3)  ->  g' = sig + t * sig * (1 - sig) * 2k (1 + 3*0.044715 t^2)
-    const float k2 = 2.0f * 0.7978845608028654f;
-    const float u2 = k2 * (t + 0.044715f * t * t * t);
-    const float sg = 1.0f / (1.0f + __expf(-u2));
-    return sg + t * sg * (1.0f - sg) * k2 * (1.0f + 0.134145f * t * t);
-}
 template <typename T, bool BWD>
 __global__ void gelu_kernel(const T* __restrict__ a, T* __restrict__ io, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {

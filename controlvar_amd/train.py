@@ -94,7 +94,7 @@ def filter_params(model, nowd_keys: Iterable[str] = NOWD_KEYS):
 import torch  # noqa: E402
 
 from . import ops  # noqa: E402
-from ._lib import ACT_NONE  # noqa: E402
+from ._lib import ACT_GELU_GRAD, ACT_GELU_TANH, ACT_NONE  # noqa: E402
 
 
 def _pad8(n: int) -> int:
@@ -308,8 +308,9 @@ class TrainEngine:
             self.X1s[i].copy_(x)
             ops.gate_residual(self.X1s[i], self.F1[i], ada, a0, n_ada, L, dp1[i].contiguous() if dp1 is not None else None, M, C)
             ops.ln_modulate(self.X1s[i], ada, a0 + 3 * C, a0 + 5 * C, n_ada, L, self.U2[i], M, C, eps)
-            ops.gemm(self.U2[i], P['w_fc1'], self.A[i], M=M, N=hid, K=C, w_off=i * hid * C, bias=P['b_fc1'][i])
-            ops.gelu(self.A[i], self.Hh[i])
+            # fc1 with the GELU in its epilogue; the pre-activation the backward needs is stored alongside (no separate gelu pass)
+            ops.gemm(self.U2[i], P['w_fc1'], self.Hh[i], M=M, N=hid, K=C, w_off=i * hid * C, bias=P['b_fc1'][i], act=ACT_GELU_TANH,
+                     pre_act=self.A[i])
             ops.gemm(self.Hh[i], P['w_fc2'], self.F2[i], M=M, N=C, K=hid, w_off=i * C * hid, bias=P['b_fc2'][i])
             self.Xs[i + 1].copy_(self.X1s[i])
             ops.gate_residual(self.Xs[i + 1], self.F2[i], ada, a0 + C, n_ada, L, dp2[i].contiguous() if dp2 is not None else None, M, C)
@@ -354,12 +355,11 @@ class TrainEngine:
             go = i * self.slab
             # FFN branch
             ops.gated_grad(self.dX, self.F2[i], ada, a0 + C, n_ada, dp2[i].contiguous() if dp2 is not None else None, self.DF, self.dada, a0 + C, n_ada, B, L, C, ws)
-            ops.gemm(self.DF, self.WT['fc2'], self.DH, M=M, N=hid, K=C, w_off=i * hid * C)
+            ops.gemm(self.DF, self.WT['fc2'], self.DH, M=M, N=hid, K=C, w_off=i * hid * C, act=ACT_GELU_GRAD, aux=self.A[i])   # dH = (dF W2) * gelu'(A)
             ops.transpose(self.DF, TA, 1, M, C, C, ld_out=Mp)
             ops.transpose(self.Hh[i], TB, 1, M, hid, hid, ld_out=Mp)
             ops.gemm(TA, TB, G, M=C, N=hid, K=Mp, c_off=go + so['w_fc2'])
             ops.rowsum(TA, Mp, G, C, M, out_off=go + so['b_fc2'])
-            ops.gelu_bwd(self.A[i], self.DH)
             ops.gemm(self.DH, self.WT['fc1'], self.DU, M=M, N=C, K=hid, w_off=i * C * hid)
             ops.transpose(self.DH, TA, 1, M, hid, hid, ld_out=Mp)
             ops.transpose(self.U2[i], TB, 1, M, C, C, ld_out=Mp)

@@ -24,7 +24,7 @@ extern "C" {
 
 typedef enum { CVAR_OK = 0, CVAR_EINVAL = -1, CVAR_EUNSUPPORTED = -2, CVAR_ELAUNCH = -3 } cvar_status;
 typedef enum { CVAR_F32 = 0, CVAR_BF16 = 1 } cvar_dtype;
-typedef enum { CVAR_ACT_NONE = 0, CVAR_ACT_GELU_TANH = 1 } cvar_act;
+typedef enum { CVAR_ACT_NONE = 0, CVAR_ACT_GELU_TANH = 1, CVAR_ACT_GELU_GRAD = 2 } cvar_act;
 
 int cvar_abi_version(void);                 /* bumps on any signature change */
 const char* cvar_status_str(int status);
@@ -59,6 +59,11 @@ typedef struct {
     const void* residual; int res_dtype; int64_t ldr;
     void* C; int out_dtype; int64_t ldc;
     int remap_l, remap_L, remap_off;
+    /* training-side fusions (both optional, same dtype / leading dimension as C):
+     *   pre_act  act == GELU_TANH: also store the pre-activation (alpha*acc + bias) here - the tensor backward needs (fc1 forward);
+     *   aux      act == GELU_GRAD: multiply by gelu'(aux[m,n]) instead of applying an activation: dH = (dY W2) * gelu'(A) (fc2 dgrad) */
+    void* pre_act;
+    const void* aux;
 } cvar_gemm_desc;
 int cvar_gemm(const cvar_gemm_desc* d, void* stream);
 /* Optional caller-owned device workspace for split-K (fp32 partial tiles of small-M GEMMs, summed in a fixed order by a

@@ -203,3 +203,30 @@ def test_transpose_tiles_and_rowsum(gpu_device, dtype, n, c):
     rs = torch.ones(c, device=gpu_device)
     ops.rowsum(out[0], npad, rs, c, n, accumulate=True)
     assert close(rs, 1 + xd.float().cpu()[0, :, 8:].sum(0), F32, 2e-4)
+
+
+@pytest.mark.parametrize('dtype', [F32, BF16])
+@pytest.mark.parametrize('M,N,K', [(300, 200, 96), (4096, 512, 128), (512, 256, 2048)])   # scalar epilogue / specialised 256x256 / split-K
+def test_gemm_fused_gelu_forward_keeps_preactivation_and_gelu_grad_epilogue(gpu_device, dtype, M, N, K):
+    """fc1 forward of training: C = gelu(A W^T + b) with the pre-activation stored next to it; fc2 dgrad: C = (A W^T) * gelu'(aux)."""
+    from controlvar_amd._lib import ACT_GELU_GRAD, ACT_GELU_TANH
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1.0 / math.sqrt(K)), rnd(N, seed=3)
+    ar, wr = a.to(dtype).float(), w.to(dtype).float()
+    pre_ref = ar @ wr.t() + b
+    ad, wd = dev(a, dtype, gpu_device), dev(w, dtype, gpu_device)
+    out = torch.empty(M, N, device=gpu_device, dtype=dtype)
+    pre = torch.empty(M, N, device=gpu_device, dtype=dtype)
+    ops.gemm(ad, wd, out, M=M, N=N, K=K, bias=b.to(gpu_device), act=ACT_GELU_TANH, pre_act=pre)
+    assert close(pre, pre_ref, dtype)
+    assert close(out, F.gelu(pre_ref, approximate='tanh'), dtype)
+    # gelu' epilogue against autograd of the same function, with the stored (rounded) pre-activation as the operand
+    aux = pre.float().cpu().requires_grad_(True)
+    F.gelu(aux, approximate='tanh').sum().backward()
+    dref = (ar @ wr.t()) * aux.grad
+    dh = torch.empty(M, N, device=gpu_device, dtype=dtype)
+    ops.gemm(ad, wd, dh, M=M, N=N, K=K, act=ACT_GELU_GRAD, aux=pre)
+    assert close(dh, dref, dtype, f32_tol=2e-4)
+    with pytest.raises(Exception):
+        ops.gemm(ad, wd, dh, M=M, N=N, K=K, act=ACT_GELU_GRAD)                 # aux missing -> CVAR_EINVAL
+    with pytest.raises(Exception):
+        ops.gemm(ad, wd, dh, M=M, N=N, K=K, pre_act=pre)                       # pre_act without the GELU -> CVAR_EINVAL
