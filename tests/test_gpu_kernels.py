@@ -375,3 +375,28 @@ def test_conv_fast_never_reads_past_the_weights(gpu_device):
     got = out.cpu().reshape(B, H, W, cout).permute(0, 3, 1, 2)
     assert torch.isfinite(got).all()
     assert close(got, ref, dtype)
+
+
+def test_entry_points_reject_bad_arguments_with_a_status(gpu_device):
+    """ABI rule: nothing throws or aborts across the boundary - bad arguments come back as a negative cvar_status
+    (surfaced by the ctypes layer as CvarError), and the device stays usable afterwards."""
+    from controlvar_amd import _lib
+    from controlvar_amd._lib import CvarError
+    lib = _lib.load()
+    x = torch.zeros(64, 64, device=gpu_device, dtype=torch.bfloat16)
+    o = torch.zeros(64, 64, device=gpu_device, dtype=torch.float32)
+    with pytest.raises(CvarError):
+        ops.gemm(x, x, o, M=0, N=64, K=64)                                                   # empty problem
+    with pytest.raises(TypeError):
+        ops.gemm(x, x.float(), o, M=64, N=64, K=64)                                           # operand dtypes differ (host check)
+    with pytest.raises(CvarError):
+        ops.gemm(x, x, o, M=64, N=64, K=64, gate=o, ldg=64, gate_rows=0)                      # gate without rows
+    with pytest.raises(CvarError):
+        ops.attention(x, x, 1, 1, 64, 60, 8, 0.1, None)                                       # q_off + l > Lmax
+    with pytest.raises(CvarError):
+        ops.ln_modulate(o, o, 0, 0, 64, 0, x, 64, 64, 1e-6)                                   # rows_per == 0
+    assert lib.cvar_gemm(None, None) < 0 and lib.cvar_status_str(-1) and lib.cvar_status_str(0)
+    # the device is still fine
+    ops.gemm(x, x, o, M=64, N=64, K=64)
+    torch.cuda.synchronize()
+    assert torch.equal(o, torch.zeros_like(o))
