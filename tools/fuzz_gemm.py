@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep of cvar_gemm (plain + conv, all epilogue combinations, awkward shapes) against torch fp32 math on
+the bf16-rounded operands.  Operands live inside NaN-filled arenas, so any read outside a tensor shows up as a NaN.
+usage: fuzz_gemm.py [n_cases] [seed]"""
+import sys, os, math, random
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch, torch.nn.functional as F
+from controlvar_amd import ops
+from controlvar_amd._lib import ACT_GELU_TANH, ACT_NONE
+
+dev = torch.device('cuda:0')
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+
+
+def arena(t, dtype):
+    """copy t (cpu fp32) into the middle of a NaN-filled device buffer of `dtype`; returns the view"""
+    pad = 4096
+    buf = torch.full((t.numel() + 2 * pad,), float('nan'), device=dev, dtype=dtype)
+    v = buf[pad:pad + t.numel()].view(t.shape)
+    v.copy_(t.to(dtype))
+    return v
+
+
+def one(case):
+    dtype = torch.bfloat16 if rng.random() < 0.8 else torch.float32
+    g = torch.Generator().manual_seed(case)
+    conv = rng.random() < 0.4
+    if conv:
+        cin = rng.choice([32, 64, 96, 160, 320, 24])
+        cout = rng.choice([3, 16, 32, 160, 320, 128, 200])
+        H, W = rng.choice([(16, 16), (48, 48), (64, 40), (33, 47), (96, 96)])
+        B = rng.choice([1, 2, 3])
+        mode = rng.choice(['s1', 's1', 'up', 's2'])
+        x = torch.randn(B, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)
+        xr, wr = x.to(dtype).float(), w.to(dtype).float()
+        if mode == 's1':
+            ref = F.conv2d(xr, wr, None, padding=1); Ho, Wo = H, W
+        elif mode == 'up':
+            ref = F.conv2d(F.interpolate(xr, scale_factor=2, mode='nearest'), wr, None, padding=1); Ho, Wo = 2 * H, 2 * W
+        else:
+            Ho, Wo = H // 2, W // 2
+            ref = F.conv2d(F.pad(xr, (0, 1, 0, 1)), wr, None, stride=2, padding=0)[:, :, :Ho, :Wo]
+        M, N, K = B * Ho * Wo, cout, 9 * cin
+        A = arena(x.permute(0, 2, 3, 1).reshape(B * H * W, cin), dtype)
+        Wd = arena(w.permute(0, 2, 3, 1).reshape(cout, 9 * cin), dtype)
+        ref = ref.permute(0, 2, 3, 1).reshape(M, N)
+        kw = dict(conv=dict(Hin=H, Win=W, Cin=cin, Hout=Ho, Wout=Wo, stride=2 if mode == 's2' else 1, up=1 if mode == 'up' else 0))
+        desc = f'conv {mode} B{B} {H}x{W} {cin}->{cout}'
+    else:
+        M = rng.choice([1, 7, 64, 200, 512, 1000, 2048, 4096, 5000, 8192 + 128])
+        N = rng.choice([8, 24, 100, 128, 256, 320, 512, 1536, 4096 + 256])
+        K = rng.choice([8, 40, 64, 128, 200, 512, 1536, 2048])
+        a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / math.sqrt(K)
+        ref = a.to(dtype).float() @ w.to(dtype).float().t()
+        A, Wd = arena(a, dtype), arena(w, dtype)
+        kw = {}
+        desc = f'gemm {M}x{N}x{K}'
+    bias = torch.randn(N, generator=g) if rng.random() < 0.7 else None
+    act = ACT_GELU_TANH if rng.random() < 0.3 else ACT_NONE
+    use_gate = (not conv) and rng.random() < 0.3
+    use_res = rng.random() < 0.4
+    out_dtype = rng.choice([dtype, torch.float32])
+    y = ref.clone()
+    if bias is not None: y = y + bias
+    if act == ACT_GELU_TANH: y = F.gelu(y, approximate='tanh')
+    gate_rows = rng.choice([1, 3, 64, 500]) if use_gate else 1
+    if use_gate:
+        gt = torch.randn((M + gate_rows - 1) // gate_rows, N, generator=g)
+        y = y * gt.repeat_interleave(gate_rows, 0)[:M]
+    res_dtype = rng.choice([dtype, torch.float32])
+    if use_res:
+        r = torch.randn(M, N, generator=g)
+        y = y + r.to(res_dtype).float()
+    out = arena(torch.zeros(M, N), out_dtype)
+    ops.gemm(A, Wd, out, M=M, N=N, K=K, bias=arena(bias, torch.float32) if bias is not None else None, act=act,
+             gate=arena(gt, torch.float32) if use_gate else None, ldg=N if use_gate else 0, gate_rows=gate_rows,
+             residual=arena(r, res_dtype) if use_res else None, **kw)
+    got = out.float().cpu()
+    tol = (3e-2 if out_dtype == torch.bfloat16 or dtype == torch.bfloat16 else 2e-4)
+    err = ((got - y).abs() / (y.abs() + 1)).max().item() if torch.isfinite(got).all() else float('nan')
+    ok = err == err and err < tol
+    return ok, f'{desc} {str(dtype)[6:]}->{str(out_dtype)[6:]} bias={bias is not None} act={act} gate={gate_rows if use_gate else 0} res={str(res_dtype)[6:] if use_res else 0}: err {err:.3e}'
+
+
+bad = 0
+for c in range(n_cases):
+    ok, msg = one(c)
+    if not ok:
+        bad += 1
+        print('FAIL', c, msg, flush=True)
+print(f'{n_cases - bad}/{n_cases} cases ok')
+sys.exit(1 if bad else 0)
