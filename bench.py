@@ -158,7 +158,7 @@ def main():
                                'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                                'traffic': traffic, 'launches': len(prof), 'avg_launch_ms': round(ms / len(prof), 4),
                                'gemm_share_of_step': round(ms * 1e-3 / dt, 3)}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:            # reported baseline: rank 0 at N=1 only
             out['cpu_baseline'] = cpu_baseline(a.cpu_depth or a.depth)
         print(json.dumps(out))
     if world > 1:
