@@ -74,6 +74,9 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #ifndef CVAR_DMA_EARLY
 #define CVAR_DMA_EARLY 1
 #endif
+#ifndef CVAR_DMA_SPAN
+#define CVAR_DMA_SPAN 2      // the next tile's DMA pieces are issued inside the first CVAR_DMA_SPAN of the 4 k-steps
+#endif
     constexpr int DMA_EARLY = CVAR_DMA_EARLY;
     constexpr int ES = sizeof(T);
     constexpr int KCH = 16 / ES;         // elements per 16-byte chunk
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                     if (DMA_EARLY == 1) {
 #pragma unroll
                         for (int t = 0; t < NL; ++t)
-                            if (max(((t + 1) * 2 * NM) / NL - 1, 0) == ks * NM + q) issue_one(ktn, nxt, t);
+                            if (max(((t + 1) * CVAR_DMA_SPAN * NM) / NL - 1, 0) == ks * NM + q) issue_one(ktn, nxt, t);
                     } else {
 #pragma unroll
                         for (int t = 0; t < NL; ++t)
