@@ -580,7 +580,7 @@ __device__ __forceinline__ bf16x8_t bw_read_tfrag(const bf16_t* T, int row, int 
     return f;
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_dq_mfma_kernel(const AttnBwdParams p) {   // 162 VGPRs, no spills
     constexpr int D = 64, KT = 64;
     __shared__ __attribute__((aligned(16))) char Ks[KT * 128];
     __shared__ __attribute__((aligned(16))) char Vs[KT * 128];
