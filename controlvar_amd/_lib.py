@@ -11,7 +11,7 @@ import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CVAR_LIB') or os.path.join(HERE, 'libcvar_hip.so')      # CVAR_LIB: A/B runs against another build
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 CVAR_F32, CVAR_BF16 = 0, 1
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_GRAD = 0, 1, 2
@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
         ('residual', c_p), ('res_dtype', c_i), ('ldr', c_l),
         ('C', c_p), ('out_dtype', c_i), ('ldc', c_l),
         ('remap_l', c_i), ('remap_L', c_i), ('remap_off', c_i),
-        ('pre_act', c_p), ('aux', c_p),
+        ('pre_act', c_p), ('aux', c_p), ('gate_scale', c_p),
     ]
 
 

@@ -38,7 +38,9 @@ struct GemmParams {
     const float* gate; long ldg; int gate_rows;
     const void* residual; int res_dtype; long ldr;
     void* C; int out_dtype; long ldc;
-    void* C2; const void* aux;     // optional: pre-activation copy (act GELU_TANH) / gelu' operand (act GELU_GRAD), laid out like C
+    void* C2; const void* aux;     // optional: copy of alpha*acc+bias in the OPERAND dtype (before act / gate / residual) / gelu' operand (act GELU_GRAD); ld = ldc
+    const float* gate_scale;       // optional per-gate-row multiplier (DropPath keep-scale of training)
+    int in_dtype;                  // operand dtype (for the split-K epilogue kernel, which is not templated on it)
     int remap_l, remap_L, remap_off;
     int tiles_m, tiles_n;
     int cv_adv, cv_rem;       // conv: a K tile advances (tap, ci) by (KT / Cin, KT % Cin) plus one carry
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             bf16x8_t rb[2][res == 2 ? NPASS : 1];
             bf16x8_t xb[2][act == CVAR_ACT_GELU_GRAD ? NPASS : 1];        // gelu' operand (bf16 variants only)
             const char* x_lane = act == CVAR_ACT_GELU_GRAD ? (const char*)p.aux + (cz + n) * 2 : nullptr;
-            char* c2_lane = p.C2 ? (char*)p.C2 + (cz + n) * OES : nullptr;
+            char* c2_lane = p.C2 ? (char*)p.C2 + (cz + n) * ES : nullptr;      // operand dtype
             auto fetch_operands = [&](int ih) {
                 const int i = ih >> 1, half = ih & 1, bsel = ih & 1;
 #pragma unroll
@@ -532,8 +534,14 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                     const int m = mrow + i * 32 + 16 * half + ps * RPP;
                     if (lane_on && m < p.M && ((16 % RPP == 0) || ps * RPP + erow < 16)) {
                         if constexpr (gate) {
-                            const float* gp = g_lane + (long)fast_div(m, p.gate_magic, p.gate_shift) * p.ldg;
+                            const int grow_i = fast_div(m, p.gate_magic, p.gate_shift);
+                            const float* gp = g_lane + (long)grow_i * p.ldg;
                             gq[bsel][ps][0] = *(const f32x4_t*)gp; gq[bsel][ps][1] = *(const f32x4_t*)(gp + 4);
+                            if (p.gate_scale) {
+                                const float gs = p.gate_scale[grow_i];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { gq[bsel][ps][0][e] *= gs; gq[bsel][ps][1][e] *= gs; }
+                            }
                         }
                         if constexpr (res == 1) {
                             const float* rp = (const float*)(r_lane + (long)m * p.ldr * 4);
@@ -560,15 +568,15 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                         float v[8];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[e] = a0[e] * p.alpha + bias8[e]; v[4 + e] = a1[e] * p.alpha + bias8[4 + e]; }
-                        if constexpr (act == CVAR_ACT_GELU_TANH) {
-                            if (c2_lane) {                                   // fc1 forward of training: keep the pre-activation too
-                                if constexpr (out_bf) *(bf16x8_t*)(c2_lane + (long)m * p.ldc * OES) = pack_bf16x8(v);
-                                else {
-                                    const f32x4_t q0 = {v[0], v[1], v[2], v[3]}, q1 = {v[4], v[5], v[6], v[7]};
-                                    *(f32x4_t*)(c2_lane + (long)m * p.ldc * OES) = q0;
-                                    *(f32x4_t*)(c2_lane + (long)m * p.ldc * OES + 16) = q1;
-                                }
+                        if (c2_lane) {                   // training forward: the branch value the backward needs (fc1 pre-activation, proj / fc2 output)
+                            if constexpr (ES == 2) *(bf16x8_t*)(c2_lane + (long)m * p.ldc * ES) = pack_bf16x8(v);
+                            else {
+                                const f32x4_t q0 = {v[0], v[1], v[2], v[3]}, q1 = {v[4], v[5], v[6], v[7]};
+                                *(f32x4_t*)(c2_lane + (long)m * p.ldc * ES) = q0;
+                                *(f32x4_t*)(c2_lane + (long)m * p.ldc * ES + 16) = q1;
                             }
+                        }
+                        if constexpr (act == CVAR_ACT_GELU_TANH) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] = (ES == 2) ? gelu_tanh_fast(v[e]) : gelu_tanh_f(v[e]);
                         }
@@ -665,11 +673,11 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             if (vec_ok) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += bias8[e];
-                if (p.act == CVAR_ACT_GELU_TANH) {
-                    if (p.C2) {
+                if (p.C2) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) st_any(p.C2, p.out_dtype, cz + (long)m * p.ldc + n + e, v[e]);
-                    }
+                    for (int e = 0; e < 8; ++e) st_any(p.C2, ES == 2 ? CVAR_BF16 : CVAR_F32, cz + (long)m * p.ldc + n + e, v[e]);
+                }
+                if (p.act == CVAR_ACT_GELU_TANH) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (ES == 2) ? gelu_tanh_fast(v[e]) : gelu_tanh_f(v[e]);
                 } else if (p.act == CVAR_ACT_GELU_GRAD) {
@@ -678,8 +686,9 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                 }
                 if (grow) {
                     const f32x4_t g0 = *(const f32x4_t*)(grow + n), g1 = *(const f32x4_t*)(grow + n + 4);
+                    const float gs = p.gate_scale ? p.gate_scale[fast_div(m, p.gate_magic, p.gate_shift)] : 1.0f;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] *= g0[e]; v[4 + e] *= g1[e]; }
+                    for (int e = 0; e < 4; ++e) { v[e] *= g0[e] * gs; v[4 + e] *= g1[e] * gs; }
                 }
                 if (p.residual) {
                     if (p.res_dtype == CVAR_BF16) {
@@ -709,9 +718,10 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                     if (n + e >= p.N) break;
                     float x = v[e];
                     if (p.bias) x += p.bias[n + e];
-                    if (p.act == CVAR_ACT_GELU_TANH) { if (p.C2) st_any(p.C2, p.out_dtype, cz + (long)m * p.ldc + n + e, x); x = gelu_tanh_f(x); }
+                    if (p.C2) st_any(p.C2, ES == 2 ? CVAR_BF16 : CVAR_F32, cz + (long)m * p.ldc + n + e, x);
+                    if (p.act == CVAR_ACT_GELU_TANH) x = gelu_tanh_f(x);
                     else if (p.act == CVAR_ACT_GELU_GRAD) x *= gelu_tanh_grad(ld_any(p.aux, p.out_dtype, cz + (long)m * p.ldc + n + e));
-                    if (grow) x *= grow[n + e];
+                    if (grow) x *= grow[n + e] * (p.gate_scale ? p.gate_scale[fast_div(m, p.gate_magic, p.gate_shift)] : 1.0f);
                     if (p.residual) x += ld_any(p.residual, p.res_dtype, rz + (long)m * p.ldr + n + e);
                     st_any(Cb, p.out_dtype, cz + orow * p.ldc + n + e, x);
                 }
@@ -843,9 +853,10 @@ __global__ __launch_bounds__(256) void cvar_splitk_epilogue_kernel(const float* 
         for (int e = 0; e < 4; ++e) {
             float x = v[e] * p.alpha;
             if (p.bias) x += p.bias[n + e];
-            if (p.act == CVAR_ACT_GELU_TANH) { if (p.C2) st_any(p.C2, p.out_dtype, (long)m * p.ldc + n + e, x); x = gelu_tanh_f(x); }
+            if (p.C2) st_any(p.C2, p.in_dtype, (long)m * p.ldc + n + e, x);
+            if (p.act == CVAR_ACT_GELU_TANH) x = gelu_tanh_f(x);
             else if (p.act == CVAR_ACT_GELU_GRAD) x *= gelu_tanh_grad(ld_any(p.aux, p.out_dtype, (long)m * p.ldc + n + e));
-            if (grow) x *= grow[n + e];
+            if (grow) x *= grow[n + e] * (p.gate_scale ? p.gate_scale[fast_div(m, p.gate_magic, p.gate_shift)] : 1.0f);
             if (p.residual) x += ld_any(p.residual, p.res_dtype, (long)m * p.ldr + n + e);
             st_any(p.C, p.out_dtype, orow * p.ldc + n + e, x);
         }
@@ -880,7 +891,8 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     }
     if (d->gate && d->gate_rows <= 0) return CVAR_EINVAL;
     if (d->act == CVAR_ACT_GELU_GRAD && !d->aux) return CVAR_EINVAL;
-    if (d->pre_act && d->act != CVAR_ACT_GELU_TANH) return CVAR_EINVAL;
+    if (d->pre_act && d->act == CVAR_ACT_GELU_GRAD) return CVAR_EINVAL;
+    if (d->gate_scale && !d->gate) return CVAR_EINVAL;
     if ((d->pre_act || d->aux) && d->remap_l > 0) return CVAR_EUNSUPPORTED;
     GemmParams p;
     p.M = d->M; p.N = d->N; p.K = d->K;
@@ -892,7 +904,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     p.gate = d->gate; p.ldg = d->ldg; p.gate_rows = d->gate_rows;
     p.residual = d->residual; p.res_dtype = d->res_dtype; p.ldr = d->ldr;
     p.C = d->C; p.out_dtype = d->out_dtype; p.ldc = d->ldc;
-    p.C2 = d->pre_act; p.aux = d->aux;
+    p.C2 = d->pre_act; p.aux = d->aux; p.gate_scale = d->gate_scale; p.in_dtype = d->dtype;
     p.remap_l = d->remap_l; p.remap_L = d->remap_L; p.remap_off = d->remap_off;
     p.tiles_m = p.tiles_n = 0;
     p.cv_adv = p.cv_rem = 0; p.conv_bytes = 0;
@@ -926,7 +938,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
         const size_t need = (size_t)splits * d->M * d->N * sizeof(float);
         if (splits > 1 && need <= g_splitk_ws_bytes) {
             GemmParams ps = p;
-            ps.alpha = 1.0f; ps.bias = nullptr; ps.act = CVAR_ACT_NONE; ps.gate = nullptr; ps.residual = nullptr; ps.C2 = nullptr; ps.aux = nullptr;
+            ps.alpha = 1.0f; ps.bias = nullptr; ps.act = CVAR_ACT_NONE; ps.gate = nullptr; ps.residual = nullptr; ps.C2 = nullptr; ps.aux = nullptr; ps.gate_scale = nullptr;
             ps.C = g_splitk_ws; ps.out_dtype = CVAR_F32; ps.ldc = d->N; ps.remap_l = 0; ps.strideC = 0;
             ps.split_tiles = per; ps.split_stride = (long)d->M * d->N;
             const int rc = d->dtype == CVAR_BF16 ? launch_typed<bf16_t>(ps, 1, st) : launch_typed<float>(ps, 1, st);

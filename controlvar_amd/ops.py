@@ -56,7 +56,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
          residual: Optional[torch.Tensor] = None, ldr: int = 0,
          remap: Optional[Sequence[int]] = None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0, strideR: int = 0,
          conv: Optional[dict] = None, a_off: int = 0, w_off: int = 0, c_off: int = 0,
-         pre_act: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None):
+         pre_act: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None, gate_scale: Optional[torch.Tensor] = None):
     """C = epilogue(A @ W^T).  Offsets (*_off) are in elements of the respective tensor."""
     d = GemmDesc()
     d.M, d.N, d.K, d.dtype = M, N, K, dt(A)
@@ -82,7 +82,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
     d.out_dtype, d.ldc = dt(out), ldc or N
     if remap is not None:
         d.remap_l, d.remap_L, d.remap_off = remap
-    d.pre_act, d.aux = _ptr(pre_act), _ptr(aux)
+    d.pre_act, d.aux, d.gate_scale = _ptr(pre_act), _ptr(aux), _ptr(gate_scale)
     if GEMM_PROFILE is None:
         check(_lib.load().cvar_gemm(C.byref(d), _stream()), 'cvar_gemm')
     else:

@@ -304,16 +304,16 @@ class TrainEngine:
             if cfg.uses_cos_attn:
                 ops.cos_qk_norm(self.arena[i], B, H, L, 0, L, P['scale_mul'], sm_off=i * H, norms=self.NORMS[i])
             ops.attention(self.arena[i], self.O[i], B, H, L, 0, L, scale, lvl_end, lse=self.LSE[i])
-            ops.gemm(self.O[i], P['w_proj'], self.F1[i], M=M, N=C, K=C, w_off=i * C * C, bias=P['b_proj'][i])
-            self.X1s[i].copy_(x)
-            ops.gate_residual(self.X1s[i], self.F1[i], ada, a0, n_ada, L, dp1[i].contiguous() if dp1 is not None else None, M, C)
+            # x1 = x + (gamma1 * keep1) * proj(o): gate / DropPath scale / residual in the GEMM epilogue; the branch output the backward
+            # needs (d gamma1 = sum dx * f) is stored next to it
+            ops.gemm(self.O[i], P['w_proj'], self.X1s[i], M=M, N=C, K=C, w_off=i * C * C, bias=P['b_proj'][i], gate=ada, ldg=n_ada, gate_rows=L,
+                     gate_off=a0, gate_scale=dp1[i].contiguous() if dp1 is not None else None, residual=x, pre_act=self.F1[i])
             ops.ln_modulate(self.X1s[i], ada, a0 + 3 * C, a0 + 5 * C, n_ada, L, self.U2[i], M, C, eps)
             # fc1 with the GELU in its epilogue; the pre-activation the backward needs is stored alongside (no separate gelu pass)
             ops.gemm(self.U2[i], P['w_fc1'], self.Hh[i], M=M, N=hid, K=C, w_off=i * hid * C, bias=P['b_fc1'][i], act=ACT_GELU_TANH,
                      pre_act=self.A[i])
-            ops.gemm(self.Hh[i], P['w_fc2'], self.F2[i], M=M, N=C, K=hid, w_off=i * C * hid, bias=P['b_fc2'][i])
-            self.Xs[i + 1].copy_(self.X1s[i])
-            ops.gate_residual(self.Xs[i + 1], self.F2[i], ada, a0 + C, n_ada, L, dp2[i].contiguous() if dp2 is not None else None, M, C)
+            ops.gemm(self.Hh[i], P['w_fc2'], self.Xs[i + 1], M=M, N=C, K=hid, w_off=i * C * hid, bias=P['b_fc2'][i], gate=ada, ldg=n_ada, gate_rows=L,
+                     gate_off=a0 + C, gate_scale=dp2[i].contiguous() if dp2 is not None else None, residual=self.X1s[i], pre_act=self.F2[i])
         ah = depth * 6 * C
         ops.ln_modulate(self.Xs[depth], ada, ah, ah + C, n_ada, L, self.UH, M, C, eps)
         ops.gemm(self.UH, P['w_head'], self.logits, M=M, N=V, K=C, bias=P['b_head'])

@@ -59,11 +59,15 @@ typedef struct {
     const void* residual; int res_dtype; int64_t ldr;
     void* C; int out_dtype; int64_t ldc;
     int remap_l, remap_L, remap_off;
-    /* training-side fusions (both optional, same dtype / leading dimension as C):
-     *   pre_act  act == GELU_TANH: also store the pre-activation (alpha*acc + bias) here - the tensor backward needs (fc1 forward);
-     *   aux      act == GELU_GRAD: multiply by gelu'(aux[m,n]) instead of applying an activation: dH = (dY W2) * gelu'(A) (fc2 dgrad) */
+    /* training-side fusions (all optional; leading dimension ldc):
+     *   pre_act     also store alpha*acc + bias - the value BEFORE activation / gate / residual - in the OPERAND dtype: the tensor
+     *               backward needs (fc1's pre-activation; the proj / fc2 branch output f of x + gate*f);
+     *   aux         act == GELU_GRAD: multiply by gelu'(aux[m,n]) (dtype of C) instead of applying an activation:
+     *               dH = (dY W2) * gelu'(A) (fc2 data gradient);
+     *   gate_scale  per-gate-row multiplier of the gate (DropPath keep-scale per sample, basic_var.py:208-209 under training) */
     void* pre_act;
     const void* aux;
+    const float* gate_scale;
 } cvar_gemm_desc;
 int cvar_gemm(const cvar_gemm_desc* d, void* stream);
 /* Optional caller-owned device workspace for split-K (fp32 partial tiles of small-M GEMMs, summed in a fixed order by a

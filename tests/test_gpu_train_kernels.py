@@ -229,4 +229,17 @@ def test_gemm_fused_gelu_forward_keeps_preactivation_and_gelu_grad_epilogue(gpu_
     with pytest.raises(Exception):
         ops.gemm(ad, wd, dh, M=M, N=N, K=K, act=ACT_GELU_GRAD)                 # aux missing -> CVAR_EINVAL
     with pytest.raises(Exception):
-        ops.gemm(ad, wd, dh, M=M, N=N, K=K, pre_act=pre)                       # pre_act without the GELU -> CVAR_EINVAL
+        ops.gemm(ad, wd, dh, M=M, N=N, K=K, act=ACT_GELU_GRAD, aux=pre, pre_act=pre)       # pre_act has no meaning with the gelu' epilogue
+    # proj / fc2 forward of training: x1 = x + (gate * keep) * f with f = A W^T + b stored alongside (operand dtype)
+    rows = 100
+    ng = (M + rows - 1) // rows
+    gate, keep, x = rnd(ng, N, seed=5), torch.rand(ng, generator=torch.Generator().manual_seed(6)) + 0.5, rnd(M, N, seed=7)
+    x1 = torch.empty(M, N, device=gpu_device, dtype=F32)
+    f = torch.empty(M, N, device=gpu_device, dtype=dtype)
+    ops.gemm(ad, wd, x1, M=M, N=N, K=K, bias=b.to(gpu_device), gate=gate.to(gpu_device), ldg=N, gate_rows=rows, gate_scale=keep.to(gpu_device),
+             residual=x.to(gpu_device), pre_act=f)
+    assert close(f, pre_ref, dtype)
+    g_rows = (gate * keep[:, None]).repeat_interleave(rows, 0)[:M]
+    assert close(x1, x + g_rows * pre_ref, F32 if dtype == F32 else BF16)
+    with pytest.raises(Exception):
+        ops.gemm(ad, wd, x1, M=M, N=N, K=K, gate_scale=keep.to(gpu_device))   # gate_scale without a gate -> CVAR_EINVAL
