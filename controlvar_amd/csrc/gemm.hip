@@ -919,12 +919,14 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     // (b) long-K GEMMs with a few hundred output tiles at most - the weight gradients of training (K = tokens of the batch):
     //     256x256 tiles, and the number of K slices s <= 8 that minimises ceil(tiles * s / 256) / s (rounds of the chip per slice)
     int long_k_splits = 0;
-    if (!d->conv && d->batch == 1 && d->dtype == CVAR_BF16 && d->M > 1024 && d->M % 256 == 0 && d->N % 256 == 0 && nk_all >= 128 && g_splitk_ws) {
+    if (!d->conv && d->batch == 1 && d->dtype == CVAR_BF16 && d->M > 1024 && d->M % 256 == 0 && d->N % 256 == 0 && g_splitk_ws &&
+        (nk_all >= 128 || (nk_all >= 24 && (d->M / 256) * (d->N / 256) <= 64 && !d->remap_l))) {
         const int tiles = (d->M / 256) * (d->N / 256);
         if (tiles < 256) {
             double best = 1e30;
             for (int sp = 1; sp <= 8; ++sp) {
                 const double cost = (double)((tiles * sp + 255) / 256) / sp + 0.01 * sp;     // small bias against needless slices
+                if (nk_all / sp < 6) break;                                                   // at least 6 K tiles per slice
                 if (cost < best && (size_t)sp * d->M * d->N * sizeof(float) <= g_splitk_ws_bytes) { best = cost; long_k_splits = sp; }
             }
             if (long_k_splits < 2) long_k_splits = 0;
