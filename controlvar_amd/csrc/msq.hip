@@ -152,6 +152,9 @@ __global__ __launch_bounds__(256) void ms_encode_kernel(const MsEncodeParams p) 
     __shared__ float red_d[256], red_d2[256];
     __shared__ int red_i[256];
     __shared__ int sidx[256];
+    __shared__ float wave_bd[4][256];
+    __shared__ int wave_bi[4][256];
+    __shared__ float zzs[256];
     const int tid = threadIdx.x;
     const long b = blockIdx.x;
     for (int o = tid; o < MS_MAP; o += 256) { fr[o] = p.f[b * MS_MAP + o]; fh[o] = 0.f; }
@@ -160,6 +163,87 @@ __global__ __launch_bounds__(256) void ms_encode_kernel(const MsEncodeParams p) 
         const int pn = p.pn[si], n = pn * pn;
         // z[t][c] = area(f_rest) -> bufA (token-major)
         ms_area_tokens(fr, p.down + p.down_off[si], tmp, bufA, pn, false);
+        if (!p.margin_out && (p.V & 255) == 0) {
+            // ---- nearest code, fast form (no margin requested).  The pyramid fills the LDS, so a workgroup is one wave per SIMD
+            // and nothing hides a load: the token-per-thread search below walks the 512 KB codebook row by row at ~1000 cycles a
+            // code (86 % of the kernel).  Here a LANE owns a code: wave w searches codes [w V/4, (w+1) V/4) in groups of 64 (one
+            // coalesced 8 KB load per group, the next group's rows prefetched), tokens come from LDS as broadcast reads, and a
+            // lane keeps the first minimum over ITS codes for a block of 8 tokens; one lexicographic (distance, index) wave
+            // reduction per token block and a merge of the four waves in code order give exactly the first-minimum index of the
+            // sequential search - every distance is the same fmaf chain as before.
+            const int lane = tid & 63, w = tid >> 6;
+            if (tid < n) {
+                float zz = 0.f;
+#pragma unroll
+                for (int c = 0; c < MS_C; ++c) zz = fmaf(bufA[tid * MS_C + c], bufA[tid * MS_C + c], zz);
+                zzs[tid] = zz;
+            }
+            __syncthreads();
+            const int per_wave = p.V / 4, groups = per_wave / 64;
+            constexpr int TB = 8;
+            for (int t0 = 0; t0 < n; t0 += TB) {
+                float bd8[TB]; int bi8[TB];
+#pragma unroll
+                for (int u = 0; u < TB; ++u) { bd8[u] = INFINITY; bi8[u] = 0; }
+                f32x4_t e4[MS_C / 4], nx[MS_C / 4];
+                {
+                    const float* er = p.E + (long)(w * per_wave + lane) * MS_C;
+#pragma unroll
+                    for (int q = 0; q < MS_C / 4; ++q) nx[q] = *(const f32x4_t*)(er + 4 * q);
+                }
+                for (int g = 0; g < groups; ++g) {
+                    const int v = w * per_wave + g * 64 + lane;
+#pragma unroll
+                    for (int q = 0; q < MS_C / 4; ++q) e4[q] = nx[q];
+                    if (g + 1 < groups) {
+                        const float* er = p.E + (long)(v + 64) * MS_C;
+#pragma unroll
+                        for (int q = 0; q < MS_C / 4; ++q) nx[q] = *(const f32x4_t*)(er + 4 * q);
+                    }
+                    float ee = 0.f;
+#pragma unroll
+                    for (int q = 0; q < MS_C / 4; ++q) {
+                        ee = fmaf(e4[q][0], e4[q][0], ee); ee = fmaf(e4[q][1], e4[q][1], ee);
+                        ee = fmaf(e4[q][2], e4[q][2], ee); ee = fmaf(e4[q][3], e4[q][3], ee);
+                    }
+#pragma unroll
+                    for (int u = 0; u < TB; ++u) {
+                        const int t = min(t0 + u, n - 1);                  // tail tokens repeat the last one (results ignored)
+                        const float* zt = bufA + t * MS_C;
+                        float dot = 0.f;
+#pragma unroll
+                        for (int q = 0; q < MS_C / 4; ++q) {
+                            const f32x4_t z4 = *(const f32x4_t*)(zt + 4 * q);
+                            dot = fmaf(z4[0], e4[q][0], dot); dot = fmaf(z4[1], e4[q][1], dot);
+                            dot = fmaf(z4[2], e4[q][2], dot); dot = fmaf(z4[3], e4[q][3], dot);
+                        }
+                        const float d = __fadd_rn(__fadd_rn(zzs[t], ee), __fmul_rn(-2.0f, dot));
+                        if (d < bd8[u]) { bd8[u] = d; bi8[u] = v; }           // codes of a lane come in increasing order: first minimum
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < TB; ++u) {
+                    float d = bd8[u]; int i = bi8[u];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const float d2 = __shfl_xor(d, o, 64);
+                        const int i2 = __shfl_xor(i, o, 64);
+                        if (d2 < d || (d2 == d && i2 < i)) { d = d2; i = i2; }
+                    }
+                    if (lane == 0 && t0 + u < n) { wave_bd[w][t0 + u] = d; wave_bi[w][t0 + u] = i; }
+                }
+            }
+            __syncthreads();
+            if (tid < n) {
+                float bd = wave_bd[0][tid]; int bi = wave_bi[0][tid];
+#pragma unroll
+                for (int q = 1; q < 4; ++q)                                      // waves hold increasing code ranges: strict '<'
+                    if (wave_bd[q][tid] < bd) { bd = wave_bd[q][tid]; bi = wave_bi[q][tid]; }
+                sidx[tid] = bi;
+                p.idx_out[b * p.Ltot + p.idx_off[si] + tid] = bi;
+            }
+            __syncthreads();
+        } else {
         // nearest code: thread = (token, part)
         const int P = n >= 256 ? 1 : 256 / n;
         const int t = tid / P, part = tid % P;
@@ -201,6 +285,7 @@ __global__ __launch_bounds__(256) void ms_encode_kernel(const MsEncodeParams p) 
             if (p.margin_out) p.margin_out[b * p.Ltot + p.idx_off[si] + t] = bd2 - bd;
         }
         __syncthreads();
+        }
         // stages with more than 256 tokens do not occur (S*S == 256)
         ms_gather_up(sidx, p.E, p.up + p.up_off[si], bufA, tmp, pn);
         const int k = p.phi_map[si];

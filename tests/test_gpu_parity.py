@@ -354,3 +354,23 @@ def test_full_size_d24_properties(gpu_device):
     assert all(torch.equal(c, d) for c, d in zip(code, code2))                     # encode is deterministic
     fh = vae.idxBl_to_h(code)                                                      # and its teacher-forcing features are finite
     assert all(torch.isfinite(f).all() for f in fh)
+
+
+def test_ms_encode_fast_search_equals_sequential_search_incl_ties(gpu_device):
+    """The lane-owns-a-code search (no margin requested: what img_to_idxBl runs) must return exactly the first-minimum index
+    of the sequential token-per-thread search (margin path).  With the second half of the codebook a copy of the first half
+    every minimum has an exact tie 2048 entries later: both paths must pick the lower index."""
+    vae = make_vae(32, BF16, gpu_device)
+    sd = vae.state_dict()
+    E = sd['quantize.embedding.weight'].clone()
+    E[2048:] = E[:2048]
+    sd['quantize.embedding.weight'] = E
+    vae.load_state_dict(sd)
+    vae._packed = None
+    g = torch.Generator().manual_seed(4)
+    f = (torch.randn(9, 32, 16, 16, generator=g) * 0.6).to(gpu_device)
+    slow = vae._ms_encode(f, want_fhat=True, want_margin=True)
+    fast = vae._ms_encode(f, want_fhat=True, want_margin=False)
+    assert torch.equal(slow[0], fast[0]) and torch.equal(slow[1], fast[1])
+    assert int(fast[0].max()) < 2048                                   # ties resolved to the first index
+    assert float(slow[2].min()) == 0.0                                 # and they really were ties
