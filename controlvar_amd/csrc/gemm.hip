@@ -823,9 +823,12 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     // GEMMs whose epilogue reads a gate / residual (proj, fc2: fp32 read-modify-write of the residual stream) are measured 2-9 %
     // faster on the 8-wave variant - twice the waves work on the epilogue's loads and stores; CVAR_GEMM_CFG=3 forces 4 waves everywhere
     const bool heavy_epilogue = (p.gate != nullptr || p.residual != nullptr) && ov != 3;
-    if (sizeof(T) == 2 && ov != 0 && ov != 1 && !heavy_epilogue && (p.M >= 2048 || (p.split_tiles > 0 && p.M > 1024)) && p.N % 256 == 0)
+    // N = 1920 / 5760 of d30 (C = 30 * 64) is a multiple of 128 only: the last 256-wide tile is half empty (2-6 % waste), still far
+    // better than dropping the whole GEMM to the 128x128 tile
+    const bool n_ok = p.N % 256 == 0 || (p.N % 128 == 0 && p.N >= 1536);
+    if (sizeof(T) == 2 && ov != 0 && ov != 1 && !heavy_epilogue && (p.M >= 2048 || (p.split_tiles > 0 && p.M > 1024)) && n_ok)
         return launch_cfg<T, 256, 256, 2, 2>(p, batch, st);
-    if (ov != 0 && p.M >= 2048 && p.N % 256 == 0) return launch_cfg<T, 256, 256, 2, 4>(p, batch, st);
+    if (ov != 0 && p.M >= 2048 && n_ok) return launch_cfg<T, 256, 256, 2, 4>(p, batch, st);
     return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
 }
 

@@ -50,7 +50,7 @@ def one(case):
         desc = f'conv {mode} B{B} {H}x{W} {cin}->{cout}'
     else:
         M = rng.choice([1, 7, 64, 200, 512, 1000, 2048, 4096, 5000, 8192 + 128])
-        N = rng.choice([8, 24, 100, 128, 256, 320, 512, 1536, 4096 + 256])
+        N = rng.choice([8, 24, 100, 128, 256, 320, 512, 1536, 1920, 5760, 4096 + 256])
         K = rng.choice([8, 40, 64, 128, 200, 512, 1536, 2048])
         a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / math.sqrt(K)
         ref = a.to(dtype).float() @ w.to(dtype).float().t()
