@@ -922,9 +922,10 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     // (b) long-K GEMMs with a few hundred output tiles at most - the weight gradients of training (K = tokens of the batch):
     //     256x256 tiles, and the number of K slices s <= 8 that minimises ceil(tiles * s / 256) / s (rounds of the chip per slice)
     int long_k_splits = 0;
-    if (!d->conv && d->batch == 1 && d->dtype == CVAR_BF16 && d->M > 1024 && d->M % 256 == 0 && d->N % 256 == 0 && g_splitk_ws &&
-        (nk_all >= 128 || (nk_all >= 24 && (d->M / 256) * (d->N / 256) <= 64 && !d->remap_l))) {
-        const int tiles = (d->M / 256) * (d->N / 256);
+    const int t256 = ((d->M + 255) / 256) * ((d->N + 255) / 256);
+    if (!d->conv && d->batch == 1 && d->dtype == CVAR_BF16 && d->M > 1024 && d->M % 128 == 0 && d->N % 128 == 0 && d->N >= 1536 && g_splitk_ws &&
+        (nk_all >= 128 || (nk_all >= 24 && t256 <= 64 && !d->remap_l))) {
+        const int tiles = t256;
         if (tiles < 256) {
             double best = 1e30;
             for (int sp = 1; sp <= 8; ++sp) {
