@@ -815,20 +815,20 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
         }
         return launch_cfg<T, 128, 160, 4, 1>(p, batch, st);
     }
-    // large streaming GEMMs: 256x256 tile, 8 waves (2x4) - halves the operand bytes per flop and doubles the MFMA work
-    // per barrier; measured +10..15 % over 128x128 on the d24 shapes.  CVAR_GEMM_CFG=0 forces the 128x128 tile (A/B runs).
+    // large streaming GEMMs: 256x256 tile - halves the operand bytes per flop and doubles the MFMA work per barrier; measured
+    // +10..15 % over 128x128 on the d24 shapes.  CVAR_GEMM_CFG=0 forces the 128x128 tile, =1 the 8-wave tile everywhere (A/B runs).
     const int ov = gemm_cfg_override();
-    // bf16: 4 waves (2x2), one per SIMD, 128x128 per wave with the accumulators in AGPRs and a hand-placed issue order;
-    // CVAR_GEMM_CFG=1 selects the 8-wave (2x4) variant instead (A/B runs; also the fp32 parity-mode configuration)
-    // GEMMs whose epilogue reads a gate / residual (proj, fc2: fp32 read-modify-write of the residual stream) are measured 2-9 %
-    // faster on the 8-wave variant - twice the waves work on the epilogue's loads and stores; CVAR_GEMM_CFG=3 forces 4 waves everywhere
-    const bool heavy_epilogue = (p.gate != nullptr || p.residual != nullptr) && ov != 3;
     // N = 1920 / 5760 of d30 (C = 30 * 64) is a multiple of 128 only: the last 256-wide tile is half empty (2-6 % waste), still far
     // better than dropping the whole GEMM to the 128x128 tile
     const bool n_ok = p.N % 256 == 0 || (p.N % 128 == 0 && p.N >= 1536);
-    if (sizeof(T) == 2 && ov != 0 && ov != 1 && !heavy_epilogue && (p.M >= 2048 || (p.split_tiles > 0 && p.M > 1024)) && n_ok)
+    // Two 256x256 variants share the loop and the epilogue code: 8 waves (2x4, two per SIMD, 128x64 per wave) and 4 waves (2x2, one
+    // per SIMD, 128x128 per wave, accumulators in AGPRs).  The 4-wave one wins isolated GEMMs by 1-3 % (fewer LDS reads per MFMA),
+    // the 8-wave one wins in the model by 1-2 % at every depth (d12 ... d30): twice the waves share the epilogue's loads / stores /
+    // GELU and fill each other's DMA-issue bubbles.  Default: 8 waves; CVAR_GEMM_CFG=3 selects the 4-wave variant (A/B runs), and the
+    // split-K slices of long-K GEMMs (training weight gradients: plain fp32 partial stores) use it as well.
+    if (sizeof(T) == 2 && (ov == 3 || (ov != 0 && ov != 1 && p.split_tiles > 0)) && (p.M >= 2048 || (p.split_tiles > 0 && p.M > 1024)) && n_ok)
         return launch_cfg<T, 256, 256, 2, 2>(p, batch, st);
-    if (ov != 0 && p.M >= 2048 && n_ok) return launch_cfg<T, 256, 256, 2, 4>(p, batch, st);
+    if (ov != 0 && (p.M >= 2048 || (p.split_tiles > 0 && p.M > 1024)) && n_ok) return launch_cfg<T, 256, 256, 2, 4>(p, batch, st);
     return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
 }
 
