@@ -14,11 +14,27 @@
 //   * conv mode gathers A rows from NHWC activations (3x3 taps, stride 1 or the (0,1,0,1)-padded stride 2,
 //     optional nearest x2 upsample folded into the address);
 //   * blockIdx -> tile mapping is XCD-aware (contiguous tile ranges per XCD L2) and grouped along M.
+// This file is compiled three times (compile time: every (tile, epilogue) combination is a kernel): as gemm.hip - the C ABI, the
+// bf16 GEMM kernels, split-K; from gemm_conv.hip (CVAR_GEMM_CONV_TU) - the bf16 implicit-conv kernels; from gemm_f32.hip
+// (CVAR_GEMM_F32_TU) - everything fp32 (parity mode).
 #include "cvar_common.h"
 #include <stdlib.h>
+#if defined(CVAR_GEMM_CONV_TU)
+#define CVAR_TU_CONV 1
+#define CVAR_TU_PLAIN 0
+#elif defined(CVAR_GEMM_F32_TU)
+#define CVAR_TU_CONV 1
+#define CVAR_TU_PLAIN 1
+#else
+#define CVAR_TU_CONV 0
+#define CVAR_TU_PLAIN 1
+#endif
 #include <type_traits>
 
-__device__ __attribute__((aligned(16))) unsigned int cvar_zero_chunk[4] = {0u, 0u, 0u, 0u};
+static __device__ __attribute__((aligned(16))) unsigned int cvar_zero_chunk[4] = {0u, 0u, 0u, 0u};   // one per translation unit
+#if defined(CVAR_GEMM_TIMING) && defined(CVAR_GEMM_F32_TU)
+#undef CVAR_GEMM_TIMING
+#endif
 #ifdef CVAR_GEMM_TIMING
 __device__ unsigned long long cvar_gemm_dbg[64 * 8 * 8];
 __device__ unsigned long long cvar_gemm_dbg_tot[8];
@@ -508,7 +524,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     // Specialised epilogues for the combinations the hot path uses on the large tiles: every flag is a compile-time constant,
     // pointers are hoisted to one per-lane base plus a wave-uniform row offset per pass, so a pass is ~20 vector instructions
     // instead of the generic code's flag tests and 64-bit address rebuilds.
-    constexpr bool SPEC = (BM * BN >= 128 * 160);
+    constexpr bool SPEC = (BM * BN >= 128 * 160) && ES == 2;      // bf16 kernels only: the fp32 parity mode is not a throughput path, and every variant costs compile time
     bool done = false;
     if constexpr (SPEC) {
         auto run = [&](auto OUTBF, auto ACT, auto GATE, auto RES, auto REMAP) {
@@ -753,17 +769,26 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     const int nk_all = (p.K + (128 / (int)sizeof(T)) - 1) / (128 / (int)sizeof(T));
     const int splits = p.split_tiles > 0 ? (nk_all + p.split_tiles - 1) / p.split_tiles : 1;
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits, (unsigned)batch), block(WM * WN * 64);
+    // Which kernels a translation unit instantiates: the bf16 conv kernels live in their own unit (gemm_conv.hip), the bf16 GEMM
+    // kernels in gemm.hip, everything fp32 in gemm_f32.hip - three compilations that run in parallel.
+    constexpr bool WITH_CONV = CVAR_TU_CONV || sizeof(T) == 4, WITH_PLAIN = CVAR_TU_PLAIN || sizeof(T) == 4;
     if constexpr (CONVFAST) {            // this configuration exists for the conv FAST kernel only
         if (!p.conv) return CVAR_EINVAL;
-        auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, true, NSTAGE, true, CUP>;
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
-        CVAR_CHECK_LAUNCH();
-        return CVAR_OK;
+        if constexpr (WITH_CONV) {
+            auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, true, NSTAGE, true, CUP>;
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
+            CVAR_CHECK_LAUNCH();
+            return CVAR_OK;
+        } else return CVAR_EUNSUPPORTED;
     } else if (p.conv) {
-        auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, true, NSTAGE>;
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
+        if constexpr (WITH_CONV) {
+            auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, true, NSTAGE>;
+            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
+        } else return CVAR_EUNSUPPORTED;
+    } else if constexpr (!WITH_PLAIN) {
+        return CVAR_EUNSUPPORTED;
     } else if (p.K % (128 / (int)sizeof(T)) == 0 && (long)(BM - 1) * p.lda * (long)sizeof(T) + (long)p.K * (long)sizeof(T) < (1L << 31) &&
                (long)(BN - 1) * p.ldw * (long)sizeof(T) + (long)p.K * (long)sizeof(T) < (1L << 31)) {
         auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, false, NSTAGE, true>;
@@ -831,6 +856,14 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     if (ov != 0 && (p.M >= 2048 || (p.split_tiles > 0 && p.M > 1024)) && n_ok) return launch_cfg<T, 256, 256, 2, 4>(p, batch, st);
     return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
 }
+
+int cvar_gemm_launch_f32(const GemmParams& p, int batch, hipStream_t st);            // defined in the CVAR_GEMM_F32_TU compilation
+int cvar_gemm_launch_conv_bf16(const GemmParams& p, int batch, hipStream_t st);      // defined in the CVAR_GEMM_CONV_TU compilation
+#if defined(CVAR_GEMM_F32_TU)
+int cvar_gemm_launch_f32(const GemmParams& p, int batch, hipStream_t st) { return launch_typed<float>(p, batch, st); }
+#elif defined(CVAR_GEMM_CONV_TU)
+int cvar_gemm_launch_conv_bf16(const GemmParams& p, int batch, hipStream_t st) { return launch_typed<bf16_t>(p, batch, st); }
+#else
 
 // ---- split-K: the small-M GEMMs of the early scales (and of small batches) have too few tiles to fill 256 CUs and are
 // bound by the serial load->MFMA latency chain of one block's K loop.  They are split along K into slices that write fp32
@@ -947,7 +980,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
             ps.alpha = 1.0f; ps.bias = nullptr; ps.act = CVAR_ACT_NONE; ps.gate = nullptr; ps.residual = nullptr; ps.C2 = nullptr; ps.aux = nullptr; ps.gate_scale = nullptr;
             ps.C = g_splitk_ws; ps.out_dtype = CVAR_F32; ps.ldc = d->N; ps.remap_l = 0; ps.strideC = 0;
             ps.split_tiles = per; ps.split_stride = (long)d->M * d->N;
-            const int rc = d->dtype == CVAR_BF16 ? launch_typed<bf16_t>(ps, 1, st) : launch_typed<float>(ps, 1, st);
+            const int rc = d->dtype == CVAR_BF16 ? launch_typed<bf16_t>(ps, 1, st) : cvar_gemm_launch_f32(ps, 1, st);
             if (rc != CVAR_OK) return rc;
             const long nvec = (long)d->M * (d->N / 4);
             hipLaunchKernelGGL(cvar_splitk_epilogue_kernel, dim3((unsigned)min((long)2048, (nvec + 255) / 256)), dim3(256), 0, st, g_splitk_ws, splits, p);
@@ -955,5 +988,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
             return CVAR_OK;
         }
     }
-    return d->dtype == CVAR_BF16 ? launch_typed<bf16_t>(p, d->batch, st) : launch_typed<float>(p, d->batch, st);
+    if (d->dtype == CVAR_BF16) return d->conv ? cvar_gemm_launch_conv_bf16(p, d->batch, st) : launch_typed<bf16_t>(p, d->batch, st);
+    return cvar_gemm_launch_f32(p, d->batch, st);
 }
+#endif   // main translation unit
