@@ -96,6 +96,14 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #define CVAR_DMA_SPAN 2      // the next tile's DMA pieces are issued inside the first CVAR_DMA_SPAN of the 4 k-steps
 #endif
     constexpr int DMA_EARLY = CVAR_DMA_EARLY;
+    // the next tile's DMA pieces are issued inside the first SPAN_NUM / SPAN_DEN of the tile's 4 k-steps: one wave per SIMD pays
+    // every DMA issue with a matrix-pipe bubble, so they are spread over 2 k-steps; with two waves per SIMD the partner wave fills
+    // the bubble and the earliest issue (1 k-step) wins (measured 989 vs 979 vs 964 TFLOP/s in situ for 1 / 2 / 3 k-steps)
+#ifdef CVAR_DMA_SPAN8_NUM
+    constexpr int SPAN_NUM = NW >= 8 ? CVAR_DMA_SPAN8_NUM : CVAR_DMA_SPAN, SPAN_DEN = NW >= 8 ? CVAR_DMA_SPAN8_DEN : 1;
+#else
+    constexpr int SPAN_NUM = NW >= 8 ? 1 : CVAR_DMA_SPAN, SPAN_DEN = 1;
+#endif
     constexpr int ES = sizeof(T);
     constexpr int KCH = 16 / ES;         // elements per 16-byte chunk
     constexpr int KT = 128 / ES;         // elements of K per tile
@@ -410,7 +418,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                     if (DMA_EARLY == 1) {
 #pragma unroll
                         for (int t = 0; t < NL; ++t)
-                            if (max(((t + 1) * CVAR_DMA_SPAN * NM) / NL - 1, 0) == ks * NM + q) issue_one(ktn, nxt, t);
+                            if (max(((t + 1) * SPAN_NUM * NM) / (SPAN_DEN * NL) - 1, 0) == ks * NM + q) issue_one(ktn, nxt, t);
                     } else {
 #pragma unroll
                         for (int t = 0; t < NL; ++t)
