@@ -411,3 +411,12 @@ def test_gemm_randomised_sweep_inside_nan_arenas(gpu_device):
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_gemm.py'), '60', '3'], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert '60/60 cases ok' in r.stdout
+
+
+def test_attention_randomised_sweep_with_poisoned_keys(gpu_device):
+    """80 random attention problems (inference spans and training level masks) on arenas whose invisible keys and surroundings
+    are NaN: the MFMA kernel against the exact row-wise kernel of the same library (tools/fuzz_attn.py, 600 cases clean)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_attn.py'), '80', '5'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
