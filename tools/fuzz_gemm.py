@@ -9,6 +9,7 @@ from controlvar_amd import ops
 from controlvar_amd._lib import ACT_GELU_TANH, ACT_NONE
 
 dev = torch.device('cuda:0')
+ops.ensure_splitk_workspace(dev)            # split-K paths (small-M, long-K) are part of the sweep
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 
@@ -51,7 +52,7 @@ def one(case):
     else:
         M = rng.choice([1, 7, 64, 200, 512, 1000, 2048, 4096, 5000, 8192 + 128])
         N = rng.choice([8, 24, 100, 128, 256, 320, 512, 1536, 1920, 5760, 4096 + 256])
-        K = rng.choice([8, 40, 64, 128, 200, 512, 1536, 2048])
+        K = rng.choice([8, 40, 64, 128, 200, 512, 1536, 2048, 8192 + 64])
         a = torch.randn(M, K, generator=g); w = torch.randn(N, K, generator=g) / math.sqrt(K)
         ref = a.to(dtype).float() @ w.to(dtype).float().t()
         A, Wd = arena(a, dtype), arena(w, dtype)
@@ -73,15 +74,30 @@ def one(case):
     if use_res:
         r = torch.randn(M, N, generator=g)
         y = y + r.to(res_dtype).float()
-    out = arena(torch.zeros(M, N), out_dtype)
+    # KV-arena style output row remap (qkv GEMM): row m -> (m // l) * L + off + m % l
+    remap = None
+    if (not conv) and (not use_res) and rng.random() < 0.3:
+        l = rng.choice([1, 2, 8, 50, 128, 200])
+        L = l + rng.choice([0, 7, 100]); off = rng.randint(0, L - l)
+        remap = (l, L, off)
+    rows_out = ((M + remap[0] - 1) // remap[0]) * remap[1] if remap else M
+    out = arena(torch.zeros(rows_out, N), out_dtype)
     ops.gemm(A, Wd, out, M=M, N=N, K=K, bias=arena(bias, torch.float32) if bias is not None else None, act=act,
              gate=arena(gt, torch.float32) if use_gate else None, ldg=N if use_gate else 0, gate_rows=gate_rows,
-             residual=arena(r, res_dtype) if use_res else None, **kw)
+             residual=arena(r, res_dtype) if use_res else None, remap=remap, **kw)
     got = out.float().cpu()
+    if remap:
+        l, L, off = remap
+        m_idx = torch.arange(M)
+        rows = (m_idx // l) * L + off + m_idx % l
+        untouched = torch.ones(rows_out, dtype=torch.bool); untouched[rows] = False
+        if not bool((got[untouched] == 0).all()):
+            return False, f'{desc} remap {remap}: rows outside the remap were written'
+        got = got[rows]
     tol = (3e-2 if out_dtype == torch.bfloat16 or dtype == torch.bfloat16 else 2e-4)
     err = ((got - y).abs() / (y.abs() + 1)).max().item() if torch.isfinite(got).all() else float('nan')
     ok = err == err and err < tol
-    return ok, f'{desc} {str(dtype)[6:]}->{str(out_dtype)[6:]} bias={bias is not None} act={act} gate={gate_rows if use_gate else 0} res={str(res_dtype)[6:] if use_res else 0}: err {err:.3e}'
+    return ok, f'{desc} {str(dtype)[6:]}->{str(out_dtype)[6:]} bias={bias is not None} act={act} gate={gate_rows if use_gate else 0} remap={remap} res={str(res_dtype)[6:] if use_res else 0}: err {err:.3e}'
 
 
 bad = 0
