@@ -367,8 +367,9 @@ class VQVAE(nn.Module):
 class ControlVAR(nn.Module):
     """Joint (control, image) next-scale transformer (reference: models/control_var.py:23-689).
 
-    Only the configuration every shipped yaml uses is built: aln=1 (AdaLNSABlock), shared_aln=False,
-    separator = bidirectional = separate_decoding = type_pos = indep = False; multi_cond as given.
+    Built: aln=1 (AdaLNSABlock), multi_cond as given, and of the non-default variants ``shared_aln``
+    and ``type_pos`` for inference and the teacher-forced forward (both fold into tables at pack time, no extra kernel).
+    separator / bidirectional / separate_decoding / indep / SABlock (aln < 0) raise NotImplementedError.
     """
     _control = True
 
@@ -379,8 +380,10 @@ class ControlVAR(nn.Module):
                  separator=False, type_pos=False, indep=False, multi_cond=False,
                  compute_dtype=None, init_seed: int = 0):
         super().__init__()
-        if aln < 0 or shared_aln or separator or bidirectional or separate_decoding or type_pos or indep:
-            raise NotImplementedError('non-default model variants (SURVEY.md 8f N4) are not built')
+        if aln < 0 or separator or bidirectional or separate_decoding or indep:
+            raise NotImplementedError('separator / bidirectional / separate_decoding / indep / SABlock variants (SURVEY.md 8f N4) are not built')
+        if type_pos and not (self._control and mask_factor == 2):
+            raise NotImplementedError('type_pos needs the joint (control, image) sequence: upstream builds type_1L with 2*sum(pn^2) entries')
         if self._control and mask_factor == 2 and not multi_cond:
             raise NotImplementedError('mask_factor=2 requires multi_cond=True (every shipped config)')
         if embed_dim // num_heads != 64:
@@ -388,7 +391,8 @@ class ControlVAR(nn.Module):
         self.cfg = VarConfig(depth=depth, mask_factor=mask_factor, multi_cond=bool(multi_cond) and self._control and mask_factor == 2,
                              control=self._control, patch_nums=tuple(patch_nums), vocab=vae_local.vocab_size, cvae=vae_local.Cvae,
                              num_classes=num_classes, embed_dim=embed_dim, num_heads=num_heads, norm_eps=norm_eps, tau=float(tau),
-                             cos_attn=bool(cos_attn), mlp_ratio=mlp_ratio, cond_drop_rate=cond_drop_rate)
+                             cos_attn=bool(cos_attn), mlp_ratio=mlp_ratio, cond_drop_rate=cond_drop_rate,
+                             shared_aln=bool(shared_aln), type_pos=bool(type_pos))
         cfg = self.cfg
         self.Cvae, self.V = cfg.cvae, cfg.vocab
         self.depth, self.C, self.D, self.num_heads = depth, cfg.C, cfg.C, cfg.H
@@ -443,14 +447,30 @@ class ControlVAR(nn.Module):
         P['w_fc2'] = torch.stack([blk(i, 'ffn.fc2.weight') for i in range(depth)]).to(T).contiguous()
         P['b_fc2'] = torch.stack([blk(i, 'ffn.fc2.bias') for i in range(depth)]).float().contiguous()
         # every ada_lin of the model in ONE weight: rows [i*6C,(i+1)*6C) = block i, last 2C rows = head_nm
-        P['w_ada'] = torch.cat([blk(i, 'ada_lin.1.weight') for i in range(depth)] + [sd['head_nm.ada_lin.1.weight']]).to(T).contiguous()
-        P['b_ada'] = torch.cat([blk(i, 'ada_lin.1.bias') for i in range(depth)] + [sd['head_nm.ada_lin.1.bias']]).float().contiguous()
+        if cfg.shared_aln:
+            # (ada_gss + SharedAdaLin(cond)) of block i (basic_var.py:204-205) == a Linear whose weight is the shared one and whose
+            # bias is shared bias + ada_gss_i: replicate the weight per block so the one-GEMM layout below serves both forms
+            w_blk = [sd['shared_ada_lin.1.weight']] * depth
+            b_blk = [sd['shared_ada_lin.1.bias'] + blk(i, 'ada_gss').reshape(-1) for i in range(depth)]
+        else:
+            w_blk = [blk(i, 'ada_lin.1.weight') for i in range(depth)]
+            b_blk = [blk(i, 'ada_lin.1.bias') for i in range(depth)]
+        P['w_ada'] = torch.cat(w_blk + [sd['head_nm.ada_lin.1.weight']]).to(T).contiguous()
+        P['b_ada'] = torch.cat(b_blk + [sd['head_nm.ada_lin.1.bias']]).float().contiguous()
         P['n_ada'] = depth * 6 * C + 2 * C
         P['w_head'] = sd['head.weight'].to(T).contiguous()
         P['b_head'] = sd['head.bias'].float().contiguous()
         P['w_we'] = sd['word_embed.weight'].float().contiguous()
         P['b_we'] = sd['word_embed.bias'].float().contiguous()
         P['lvl_pos'] = (sd['lvl_embed.weight'][sd['lvl_1L'][0]] + sd['pos_1LC'][0]).float().contiguous()      # (L, C)
+        # type_pos (control_var.py:99-117): upstream adds type_embed[type_1L] to every row in forward() (:622-624), to the
+        # rows of scales >= 1 in autoregressive_infer_cfg (:423-424,482-483) and nowhere in conditional_infer_cfg
+        P['lvl_pos_fwd'] = P['lvl_pos_gen'] = P['lvl_pos']
+        if cfg.type_pos:
+            ty = sd['type_embed.weight'][sd['type_1L'][0]].float()
+            P['lvl_pos_fwd'] = (P['lvl_pos'] + ty).contiguous()
+            P['lvl_pos_gen'] = P['lvl_pos_fwd'].clone()
+            P['lvl_pos_gen'][:cfg.pyramid.first_l] = P['lvl_pos'][:cfg.pyramid.first_l]
         P['pos_start'] = sd['pos_start'][0].float().contiguous()
         P['class_emb'] = sd['class_emb.weight'].float().contiguous()
         P['cond_embed'] = sd['cond_embed.weight'].float().contiguous() if 'cond_embed.weight' in sd else None
@@ -599,7 +619,8 @@ class ControlVAR(nn.Module):
             tok = vae._next_input(si, idx, f_hat, nb, mf, True)
             if si != nstage - 1:
                 ln = py.l[si + 1]
-                ops.word_embed(tok, P['w_we'], P['b_we'], P['lvl_pos'], x, nb, 1 if four_way else 2, ln, cfg.cvae, C, ln, 0, lvl_off=py.end[si])
+                ops.word_embed(tok, P['w_we'], P['b_we'], P['lvl_pos'] if four_way else P['lvl_pos_gen'], x, nb, 1 if four_way else 2, ln,
+                               cfg.cvae, C, ln, 0, lvl_off=py.end[si])
         if trace:
             tr['f_hat'] = f_hat[:B].clone()
             self.last_trace = tr
@@ -695,9 +716,9 @@ class ControlVAR(nn.Module):
         labels = labels.to(torch.int32).contiguous()
         x = torch.empty(B * py.L, C, device=dev, dtype=torch.float32)
         cond = torch.empty(B, C, device=dev, dtype=torch.float32)
-        ops.first_tokens(P['class_emb'], P['cond_embed'], labels, types, P['pos_start'], P['lvl_pos'], x, cond, B, py.first_l, C, py.L)
+        ops.first_tokens(P['class_emb'], P['cond_embed'], labels, types, P['pos_start'], P['lvl_pos_fwd'], x, cond, B, py.first_l, C, py.L)
         tok = x_BLCv_wo_first_l.to(device=dev, dtype=torch.float32).contiguous()
-        ops.word_embed(tok, P['w_we'], P['b_we'], P['lvl_pos'], x, B, 1, py.L - py.first_l, cfg.cvae, C, py.L, py.first_l, lvl_off=py.first_l)
+        ops.word_embed(tok, P['w_we'], P['b_we'], P['lvl_pos_fwd'], x, B, 1, py.L - py.first_l, cfg.cvae, C, py.L, py.first_l, lvl_off=py.first_l)
         ada = self._ada(cond, B)
         arena = self._get_arena(B, py.L)
         logits = self._blocks_and_head(x, ada, B, py.L, 0, py.L, arena, lvl_end=list(py.end))

@@ -97,6 +97,8 @@ class VarConfig:
     cos_attn: bool = False          # ControlVAR forces True when depth == 30 (control_var.py:35)
     mlp_ratio: float = 4.0
     cond_drop_rate: float = 0.1
+    shared_aln: bool = False        # N4: one SharedAdaLin for all blocks + per-block ada_gss (control_var.py:120, basic_var.py:194-205)
+    type_pos: bool = False          # N4: type_embed added per control / image half (control_var.py:99-117,423,482,623)
 
     @property
     def C(self) -> int:
@@ -127,14 +129,24 @@ def var_state_shapes(cfg: VarConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...],
     sd: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
     sd['pos_start'] = ((1, cfg.pyramid.first_l, C), 'param')
     sd['pos_1LC'] = ((1, L, C), 'param')
+    if cfg.type_pos:                                 # registered before lvl_1L upstream (control_var.py:99-117 vs :160-168)
+        sd['type_1L'] = ((1, L), 'buffer')
+        sd['type_1L_'] = ((1, L), 'buffer')
     sd['lvl_1L'] = ((1, L), 'buffer')
     sd['attn_bias_for_masking'] = ((1, 1, L, L), 'buffer')
     sd['word_embed.weight'] = ((C, cfg.cvae), 'param')
     sd['word_embed.bias'] = ((C,), 'param')
     sd['class_emb.weight'] = ((cfg.num_classes + 1, C), 'param')
     sd['lvl_embed.weight'] = ((len(cfg.patch_nums), C), 'param')
+    if cfg.type_pos:
+        sd['type_embed.weight'] = ((cfg.mask_factor, C), 'param')
+    if cfg.shared_aln:
+        sd['shared_ada_lin.1.weight'] = ((6 * C, C), 'param')
+        sd['shared_ada_lin.1.bias'] = ((6 * C,), 'param')
     for i in range(cfg.depth):
         p = f'blocks.{i}.'
+        if cfg.shared_aln:
+            sd[p + 'ada_gss'] = ((1, 1, 6, C), 'param')
         sd[p + 'attn.q_bias'] = ((C,), 'param')
         sd[p + 'attn.v_bias'] = ((C,), 'param')
         sd[p + 'attn.zero_k_bias'] = ((C,), 'buffer')
@@ -147,8 +159,9 @@ def var_state_shapes(cfg: VarConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...],
         sd[p + 'ffn.fc1.bias'] = ((hid,), 'param')
         sd[p + 'ffn.fc2.weight'] = ((C, hid), 'param')
         sd[p + 'ffn.fc2.bias'] = ((C,), 'param')
-        sd[p + 'ada_lin.1.weight'] = ((6 * C, C), 'param')
-        sd[p + 'ada_lin.1.bias'] = ((6 * C,), 'param')
+        if not cfg.shared_aln:
+            sd[p + 'ada_lin.1.weight'] = ((6 * C, C), 'param')
+            sd[p + 'ada_lin.1.bias'] = ((6 * C,), 'param')
     sd['head_nm.ada_lin.1.weight'] = ((2 * C, C), 'param')
     sd['head_nm.ada_lin.1.bias'] = ((2 * C,), 'param')
     sd['head.weight'] = ((V, C), 'param')

@@ -40,11 +40,21 @@ def synth_var_state(cfg: VarConfig, seed: int = 0, head_gain: float = 4.0) -> Di
             lvl = torch.from_numpy(py.level_of_token())
             d = lvl.view(1, py.L, 1)
             out[key] = torch.where(d >= d.transpose(1, 2), 0.0, -torch.inf).reshape(1, 1, py.L, py.L).contiguous()
+        elif key in ('type_1L', 'type_1L_'):
+            first = 1 if key == 'type_1L' else 0                     # control half id; the image half gets the other one
+            ids = []
+            for pn in py.patch_nums:
+                ids += [first] * (pn * pn) + [1 - first] * (pn * pn)
+            out[key] = torch.tensor(ids, dtype=torch.int64).view(1, -1)
+        elif key.endswith('ada_gss'):
+            b = _randn(shape, g, std=0.1)
+            b[0, 0, :2] += 0.35
+            out[key] = b
         elif key.endswith('zero_k_bias'):
             out[key] = torch.zeros(shape)
         elif key.endswith('scale_mul_1H11'):
             out[key] = _randn(shape, g, std=0.3, mean=math.log(4.0))
-        elif key in ('pos_start', 'pos_1LC', 'lvl_embed.weight', 'cond_embed.weight'):
+        elif key in ('pos_start', 'pos_1LC', 'lvl_embed.weight', 'cond_embed.weight', 'type_embed.weight'):
             out[key] = _randn(shape, g, std=0.5)
         elif key == 'class_emb.weight':
             out[key] = _randn(shape, g, std=1.0)
@@ -52,7 +62,7 @@ def synth_var_state(cfg: VarConfig, seed: int = 0, head_gain: float = 4.0) -> Di
             out[key] = _randn(shape, g, std=0.4 / math.sqrt(C))
         elif key.endswith('ada_lin.1.bias'):
             b = _randn(shape, g, std=0.1)
-            if key.startswith('blocks.'):
+            if key.startswith('blocks.') and not cfg.shared_aln:
                 b[:2 * C] += 0.35            # gamma1, gamma2 rows: residual gates around 0.35
             out[key] = b
         elif key == 'head.weight':

@@ -113,6 +113,8 @@ class TrainEngine:
     def __init__(self, var, drop_path: bool = True, reducer=None):
         self.var = var
         self.cfg = var.cfg
+        if self.cfg.shared_aln or self.cfg.type_pos:
+            raise NotImplementedError('training of the shared_aln / type_pos variants (SURVEY.md 8f N4) is not built: inference and forward only')
         self.drop_path = drop_path
         self.reducer = reducer
         self._B = None

@@ -68,9 +68,10 @@ def make_cvar(vae, cfg: VarConfig, seed=0):
                       multi_cond=cfg.multi_cond, cond_drop_rate=0.0)
         else:
             m = quiet(build_control_var, vae, depth=cfg.depth, patch_nums=PN, mask_type='interleave_append' if cfg.mask_factor == 2 else 'replace',
-                      cond_drop_rate=0.0, multi_cond=cfg.multi_cond, flash_if_available=False, fused_if_available=False)
+                      cond_drop_rate=0.0, multi_cond=cfg.multi_cond, flash_if_available=False, fused_if_available=False,
+                      shared_aln=cfg.shared_aln, type_pos=cfg.type_pos)
     else:
-        m = quiet(build_var, vae, depth=cfg.depth, patch_nums=PN, flash_if_available=False, fused_if_available=False)
+        m = quiet(build_var, vae, depth=cfg.depth, patch_nums=PN, flash_if_available=False, fused_if_available=False, shared_aln=cfg.shared_aln)
         m.cond_drop_rate = 0.0
     m.load_state_dict(synth_var_state(cfg, seed), strict=True)
     return m.eval()
@@ -427,6 +428,37 @@ def case_preprocess():
     save('preprocess', ign_cond=ct, ignore_mask=torch.concat(a), ignore_mask_=torch.concat(b), **out)
 
 
+def case_variants():
+    """shared_aln (SharedAdaLin + per-block ada_gss) and type_pos (type_embed), depth 2, tiny VQVAE.
+    Records the reference's state_dict key order for both models, teacher-forced logits and greedy decode traces - note
+    that upstream adds the type embedding in forward() (all rows) and autoregressive_infer_cfg (scales >= 1) but NOT in
+    conditional_infer_cfg; the fixtures pin exactly that."""
+    vae = make_vae(32)
+    cfg = VarConfig(depth=2, shared_aln=True, type_pos=True)
+    m = make_cvar(vae, cfg, seed=5)
+    keys = list(m.state_dict().keys())
+    B = 2
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(B, cfg.pyramid.L - cfg.pyramid.first_l, 32, generator=g)
+    labels, types = torch.tensor([4, 321]), torch.tensor([2, 0])
+    with torch.no_grad():
+        logits = m(labels, x, types, True)
+    t2 = logits.topk(2, dim=-1).values
+    save('forward_d2v', keys=np.array(keys), labels=labels, types=types, logits_sample=logits[:, ::9, ::31].contiguous(),
+         argmax=logits.argmax(-1).to(torch.int16), margin=(t2[..., 0] - t2[..., 1]), lsum=logits.double().sum(-1).float())
+    r = _run_generate(m, ref_cv, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]))
+    save('gen_d2v_b2', **r)
+    ctrl = synth_images(2, 256, seed=4)
+    with torch.no_grad():
+        c_ids = vae.img_to_idxBl(ctrl, v_patch_nums=PN)
+    r = _run_generate(m, ref_cv, 2, torch.tensor([5, 6]), (4.0, 3.0, 2.0), cond_type=torch.tensor([2, 3]), four=True, c_mask=c_ids)
+    save('gen_d2v_cmask', c_ids=torch.cat(c_ids, dim=1).to(torch.int16), **r)
+    cfgv = VarConfig(depth=2, mask_factor=1, control=False, multi_cond=False, shared_aln=True)
+    mv = make_cvar(vae, cfgv, seed=6)
+    r = _run_generate(mv, ref_v, 2, torch.tensor([3, 7]), 4.0)
+    save('gen_var_d2s_b2', keys=np.array(list(mv.state_dict().keys())), **r)
+
+
 CASES = {
     'interp': case_interp,
     'tok_tiny': lambda: case_tokenizer(32, 3, 'ch32'),
@@ -443,6 +475,7 @@ CASES = {
     'train': case_train_step,
     'checkpoint': case_checkpoint,
     'preprocess': case_preprocess,
+    'variants': case_variants,
 }
 
 if __name__ == '__main__':

@@ -4,6 +4,8 @@ inputs.  Integer outputs (VQ ids, greedy tokens) must be identical - the only to
 difference is an argmin/argmax flip where the reference's own top-1/top-2 margin is below the
 fp32 accumulation-order noise, and that is reported, bounded and asserted per test.
 Floating-point tolerances are written next to each check."""
+import contextlib
+
 import numpy as np
 import pytest
 import torch
@@ -38,12 +40,14 @@ def make_vae(ch, dtype, dev):
     return vae.to(dev)
 
 
-def make_var(vae, cfg: VarConfig, dtype, dev):
+def make_var(vae, cfg: VarConfig, dtype, dev, seed=0):
     if cfg.control:
         m = models.ControlVAR(vae, depth=cfg.depth, embed_dim=cfg.C, num_heads=cfg.H, mask_factor=cfg.mask_factor,
-                              multi_cond=cfg.multi_cond, patch_nums=PN, compute_dtype=dtype)
+                              multi_cond=cfg.multi_cond, patch_nums=PN, compute_dtype=dtype, shared_aln=cfg.shared_aln,
+                              type_pos=cfg.type_pos, init_seed=seed)
     else:
-        m = models.VAR(vae, depth=cfg.depth, embed_dim=cfg.C, num_heads=cfg.H, patch_nums=PN, compute_dtype=dtype)
+        m = models.VAR(vae, depth=cfg.depth, embed_dim=cfg.C, num_heads=cfg.H, patch_nums=PN, compute_dtype=dtype,
+                       shared_aln=cfg.shared_aln, init_seed=seed)
     return m.to(dev).eval()
 
 
@@ -146,6 +150,10 @@ GEN_CASES = {
     'gen_d2_b4none': dict(cfg=VarConfig(depth=2), B=4, labels=[1, 10, 100, 999], scale=4.0, types=None),
     'gen_var_d2_b2': dict(cfg=VarConfig(depth=2, mask_factor=1, control=False, multi_cond=False), B=2, labels=[3, 7], scale=4.0, types=None),
     'gen_d30n_b2': dict(cfg=VarConfig(depth=30, embed_dim=128, num_heads=2), B=2, labels=[3, 7], scale=4.0, types=[3, 0]),
+    # shared_aln + type_pos (type embedding on scales >= 1 of autoregressive_infer_cfg only)
+    'gen_d2v_b2': dict(cfg=VarConfig(depth=2, shared_aln=True, type_pos=True), B=2, labels=[3, 7], scale=4.0, types=[0, 1], seed=5),
+    'gen_var_d2s_b2': dict(cfg=VarConfig(depth=2, mask_factor=1, control=False, multi_cond=False, shared_aln=True), B=2, labels=[3, 7],
+                           scale=4.0, types=None, seed=6),
 }
 
 
@@ -163,7 +171,7 @@ def test_generate_fp32_matches_reference_tokens(gpu_device, name):
     case = GEN_CASES[name]
     g = golden(name)
     vae = make_vae(32, F32, gpu_device)
-    m = make_var(vae, case['cfg'], F32, gpu_device)
+    m = make_var(vae, case['cfg'], F32, gpu_device, seed=case.get('seed', 0))
     img = _run(m, case).cpu()
     tr = m.last_trace
     ids = torch.cat(tr['idx'], dim=1).cpu()
@@ -176,12 +184,15 @@ def test_generate_fp32_matches_reference_tokens(gpu_device, name):
         assert (img.mean(dim=(2, 3)) - t(g['img_mean'])).abs().max() < 2e-4
 
 
-@pytest.mark.parametrize('name,teach,scale', [('gen_d2_cmask', 'c_mask', (4.0, 4.0, 4.0)), ('gen_d2_cimg', 'c_img', (3.0, 2.0, 1.0))])
+@pytest.mark.parametrize('name,teach,scale', [('gen_d2_cmask', 'c_mask', (4.0, 4.0, 4.0)), ('gen_d2_cimg', 'c_img', (3.0, 2.0, 1.0)),
+                                              ('gen_d2v_cmask', 'c_mask', (4.0, 3.0, 2.0))])
 def test_conditional_infer_fp32_matches_reference_tokens(gpu_device, name, teach, scale):
-    """A4: 4-branch CFG + teacher forcing; sampled ids (before the overwrite) equal the reference's."""
+    """A4: 4-branch CFG + teacher forcing; sampled ids (before the overwrite) equal the reference's.
+    gen_d2v_cmask: the shared_aln + type_pos variant (upstream's conditional_infer_cfg ignores the type embedding)."""
     g = golden(name)
     vae = make_vae(32, F32, gpu_device)
-    m = make_var(vae, VarConfig(depth=2), F32, gpu_device)
+    variant = name.startswith('gen_d2v')
+    m = make_var(vae, VarConfig(depth=2, shared_aln=variant, type_pos=variant), F32, gpu_device, seed=5 if variant else 0)
     c_ids = split_ids(g['c_ids'].astype(np.int64))
     img = m.conditional_infer_cfg(2, torch.tensor([5, 6]), g_seed=0, cfg=scale, top_k=1, cond_type=torch.tensor([2, 3]), _trace=True,
                                   **{teach: c_ids}).cpu()
@@ -235,16 +246,21 @@ def test_generate_bf16_against_emulated_oracle(gpu_device):
     print(f'bf16 vs emulated oracle: worst relative logit error {worst:.3e}')
 
 
-@pytest.mark.parametrize('tag,mf', [('d2', 2), ('var_d2', 1)])
+@pytest.mark.parametrize('tag,mf', [('d2', 2), ('var_d2', 1), ('d2v', 2)])
 def test_forward_logits_fp32(gpu_device, tag, mf):
-    """A5: teacher-forced logits (block-causal level mask) against the reference fixture."""
+    """A5: teacher-forced logits (block-causal level mask) against the reference fixture ('d2v': shared_aln + type_pos)."""
     g = golden(f'forward_{tag}')
-    cfg = VarConfig(depth=2, mask_factor=mf, control=(mf == 2), multi_cond=(mf == 2))
+    variant = tag == 'd2v'
+    cfg = VarConfig(depth=2, mask_factor=mf, control=(mf == 2), multi_cond=(mf == 2), shared_aln=variant, type_pos=variant)
     vae = make_vae(32, F32, gpu_device)
-    m = make_var(vae, cfg, F32, gpu_device)
-    gen = torch.Generator().manual_seed(21)
+    m = make_var(vae, cfg, F32, gpu_device, seed=5 if variant else 0)
+    gen = torch.Generator().manual_seed(22 if variant else 21)
     x = torch.randn(2, cfg.pyramid.L - cfg.pyramid.first_l, 32, generator=gen)
-    logits = m(t(g['labels']), x.to(gpu_device), t(g['types'])).cpu()
+    if variant:                                       # training of the variants is not built: grad mode must fail loudly
+        with pytest.raises(NotImplementedError):
+            m(t(g['labels']), x.to(gpu_device), t(g['types']))
+    with torch.no_grad() if variant else contextlib.nullcontext():
+        logits = m(t(g['labels']), x.to(gpu_device), t(g['types'])).detach().cpu()
     assert (logits[:, ::9, ::31] - t(g['logits_sample'])).abs().max() < 2e-3
     assert_ids(logits.argmax(-1), g['argmax'], g['margin'], 2e-3, 'forward argmax')
 

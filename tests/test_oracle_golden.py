@@ -131,11 +131,11 @@ def test_forward_logits(tag, mf):
 
 
 def _gen_check(name, cfg, B, labels, cfg_scale, cond_type=None, four=False, teach=None, top_k=1, top_p=0.0, seed=0,
-               vae_ch=32, img_tol=5e-4):
+               vae_ch=32, img_tol=5e-4, wseed=0):
     g = golden(name)
     sdv = synth_vae_state(VaeConfig(ch=vae_ch))
     msq = MSQuant(sdv, PN, phi_index_map(10))
-    sd = synth_var_state(cfg)
+    sd = synth_var_state(cfg, wseed)
     kw = {}
     if teach is not None:
         kw[teach] = split_ids(g['c_ids'].astype(np.int64))
@@ -205,3 +205,35 @@ def test_sampler_masks():
         assert (kept == g[f'kept_{k}_{p}']).all()
     # greedy == the reference's top_k=1 multinomial
     assert (var_ref.sample(logits.clone(), 1, 0.0, None).numpy() == g['idx_1_0.0']).all()
+
+
+# ------------------------------------------------------------------------------ shared_aln + type_pos
+VARIANT = VarConfig(depth=2, shared_aln=True, type_pos=True)
+VARIANT_VAR = VarConfig(depth=2, mask_factor=1, control=False, multi_cond=False, shared_aln=True)
+
+
+def test_variant_state_tables_match_the_reference_key_order():
+    from controlvar_amd.spec import var_state_shapes
+    assert list(var_state_shapes(VARIANT)) == [str(k) for k in golden('forward_d2v')['keys']]
+    assert list(var_state_shapes(VARIANT_VAR)) == [str(k) for k in golden('gen_var_d2s_b2')['keys']]
+
+
+def test_variant_forward_logits():
+    g = golden('forward_d2v')
+    sd = synth_var_state(VARIANT, 5)
+    gen = torch.Generator().manual_seed(22)
+    x = torch.randn(2, VARIANT.pyramid.L - VARIANT.pyramid.first_l, 32, generator=gen)
+    with torch.no_grad():
+        logits = var_ref.forward_logits(sd, VARIANT, t(g['labels']), x, t(g['types']))
+    assert (logits[:, ::9, ::31] - t(g['logits_sample'])).abs().max() < 1e-4
+    mism = logits.argmax(-1).numpy() != g['argmax'].astype(np.int64)
+    assert mism.sum() == 0 or g['margin'][mism].max() < 1e-4
+    assert (logits.double().sum(-1).float() - t(g['lsum'])).abs().max() < 2e-2
+
+
+def test_variant_generate():
+    """conditional_infer_cfg of the reference ignores type_pos; autoregressive_infer_cfg applies it from scale 1 on"""
+    _gen_check('gen_d2v_b2', VARIANT, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]), wseed=5)
+    _gen_check('gen_d2v_cmask', VARIANT, 2, torch.tensor([5, 6]), (4.0, 3.0, 2.0), cond_type=torch.tensor([2, 3]), four=True,
+               teach='c_mask', wseed=5)
+    _gen_check('gen_var_d2s_b2', VARIANT_VAR, 2, torch.tensor([3, 7]), 4.0, wseed=6)
