@@ -10,7 +10,24 @@ from controlvar_amd import ops
 dev = torch.device('cuda:0'); T = torch.bfloat16
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+only = [int(x) for x in os.environ.get('FUZZ_ONLY', '').split(',') if x]
 bad = 0
+
+
+def torch_ref(qkv, R, H, Lmax, q_off, l, scale, levels):
+    """fp32 softmax(q k^T * scale + mask) v over the visible keys"""
+    q, k, v = qkv.float().view(R, Lmax, 3, H, 64).permute(2, 0, 3, 1, 4).unbind(0)
+    q = q[:, :, q_off:q_off + l]
+    nk = q_off + l
+    s = torch.matmul(q, k[:, :, :nk].transpose(-1, -2)) * scale
+    if levels is not None:
+        lvl = torch.zeros(Lmax, dtype=torch.long, device=qkv.device)
+        for e in levels[:-1]:
+            lvl[e:] += 1
+        s = s.masked_fill(lvl.view(-1, 1) < lvl.view(1, -1), float('-inf'))
+    return torch.matmul(torch.softmax(s, -1), v[:, :, :nk]).transpose(1, 2).reshape(R * l, H * 64)
+
+
 for case in range(n_cases):
     R, H = rng.choice([1, 2, 3, 5]), rng.choice([1, 2, 4, 12])
     levels = None
@@ -26,7 +43,8 @@ for case in range(n_cases):
         Lmax, l, q_off, levels = acc, acc, 0, ends
     C3 = 3 * H * 64
     g = torch.Generator().manual_seed(case)
-    qkv_cpu = (torch.randn(R, Lmax, C3, generator=g) * rng.choice([0.3, 1.0, 2.5])).to(T)
+    amp = rng.choice([0.3, 1.0, 2.5])
+    qkv_cpu = (torch.randn(R, Lmax, C3, generator=g) * amp).to(T)
     pad = 8192
     buf = torch.full((qkv_cpu.numel() + 2 * pad,), float('nan'), device=dev, dtype=T)
     qkv = buf[pad:pad + qkv_cpu.numel()].view(R, Lmax, C3)
@@ -35,15 +53,23 @@ for case in range(n_cases):
     if levels is None and q_off + l < Lmax:
         qkv[:, q_off + l:, H * 64:] = float('nan')
     scale = rng.choice([0.125, 0.03125, 1.0])
+    if only and case not in only:
+        continue
     out = torch.empty(R * l, H * 64, device=dev, dtype=T)
     ref = torch.empty(R * l, H * 64, device=dev, dtype=T)
     ops.attention(qkv, out, R, H, Lmax, q_off, l, scale, levels)
     ops.attention(qkv, ref, R, H, Lmax, q_off, l, scale, levels, rowwise=True)
     a, b = out.float(), ref.float()
-    err = ((a - b).abs() / (b.abs() + 0.05)).max().item() if torch.isfinite(a).all() and torch.isfinite(b).all() else float('nan')
+    err = ((a - b).abs() / (b.abs() + 0.05 * max(1.0, amp))).max().item() if torch.isfinite(a).all() and torch.isfinite(b).all() else float('nan')
     ok = err == err and err < 0.12          # bf16 P vs exact fp32 softmax; near one-hot rows (scale 1.0, large logits) sit at 0.07-0.09
+    # (the floor scales with the value amplitude: at amp 2.5 a one-ulp bf16 flip of an output near 4-8 is 0.031 absolute)
     if not ok:
         bad += 1
-        print('FAIL', case, dict(R=R, H=H, Lmax=Lmax, l=l, q_off=q_off, levels=bool(levels), scale=scale), 'err', err, flush=True)
+        vis = qkv.clone()
+        vis[~torch.isfinite(vis)] = 0
+        t = torch_ref(vis, R, H, Lmax, q_off, l, scale, levels)
+        print('FAIL', case, dict(R=R, H=H, Lmax=Lmax, l=l, q_off=q_off, levels=bool(levels), scale=scale, amp=amp), 'err', err,
+              '| max abs mfma-rowwise', (a - b).abs().max().item(), 'mfma-fp32', (a - t).abs().max().item(), 'rowwise-fp32', (b - t).abs().max().item(),
+              'mean abs mfma-fp32', (a - t).abs().mean().item(), 'rowwise-fp32', (b - t).abs().mean().item(), flush=True)
 print(f'{n_cases - bad}/{n_cases} cases ok')
 sys.exit(1 if bad else 0)
