@@ -368,7 +368,7 @@ class ControlVAR(nn.Module):
     """Joint (control, image) next-scale transformer (reference: models/control_var.py:23-689).
 
     Built: aln=1 (AdaLNSABlock), multi_cond as given, and of the non-default variants ``shared_aln``
-    and ``type_pos`` for inference and the teacher-forced forward (both fold into tables at pack time, no extra kernel).
+    and ``type_pos`` for inference, forward and training (both fold into tables at pack time, no extra kernel).
     separator / bidirectional / separate_decoding / indep / SABlock (aln < 0) raise NotImplementedError.
     """
     _control = True

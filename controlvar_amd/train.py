@@ -113,8 +113,6 @@ class TrainEngine:
     def __init__(self, var, drop_path: bool = True, reducer=None):
         self.var = var
         self.cfg = var.cfg
-        if self.cfg.shared_aln or self.cfg.type_pos:
-            raise NotImplementedError('training of the shared_aln / type_pos variants (SURVEY.md 8f N4) is not built: inference and forward only')
         self.drop_path = drop_path
         self.reducer = reducer
         self._B = None
@@ -158,7 +156,8 @@ class TrainEngine:
         self.TA32 = torch.zeros(C * _pad8(B * (L - cfg.pyramid.first_l)), **f32)
         self.TB32 = torch.zeros(cfg.cvae * _pad8(B * (L - cfg.pyramid.first_l)), **f32)
         self.dada = torch.zeros(B, n_ada, **f32)
-        self.ws = torch.empty(max(2 * M + 16 * B * C, 64 * max(hid, 3 * C, V, n_ada), L * C, B * cfg.H * L) + 16, **f32)
+        self.ws = torch.empty(max(2 * M + 16 * B * C, 64 * max(hid, 3 * C, V, n_ada), L * C, B * cfg.H * L,
+                                  6 * C * C if cfg.shared_aln else 0) + 16, **f32)
         # gradient slabs: [layer][w_qkv | w_proj | w_fc1 | w_fc2 | b_qkv | b_proj | b_fc1 | b_fc2]
         self.slab_off = {}
         o = 0
@@ -171,6 +170,10 @@ class TrainEngine:
         self.G_ada = torch.zeros(n_ada * C + n_ada, **f32)                       # [w_ada | b_ada]
         misc = [('w_head', V * C), ('b_head', V), ('w_we', C * cfg.cvae), ('b_we', C), ('pos', L * C), ('lvl', len(cfg.patch_nums) * C),
                 ('pos_start', cfg.pyramid.first_l * C), ('class_emb', (cfg.num_classes + 1) * C), ('cond_embed', 5 * C)]
+        if cfg.shared_aln:      # the shared generator's gradient = sum over blocks of the per-block (folded) ones
+            misc += [('w_shared', 6 * C * C), ('b_shared', 6 * C)]
+        if cfg.type_pos:
+            misc += [('type', cfg.mask_factor * C)]
         self.misc_off = {}
         o = 0
         for name, n in misc:
@@ -219,8 +222,11 @@ class TrainEngine:
             if cfg.uses_cos_attn:
                 g[p + 'attn.scale_mul_1H11'] = s[so['scale_mul']:so['scale_mul'] + cfg.H].view(1, cfg.H, 1, 1)
             n_ada = depth * 6 * C + 2 * C
-            g[p + 'ada_lin.1.weight'] = self.G_ada[:n_ada * C].view(n_ada, C)[i * 6 * C:(i + 1) * 6 * C]
-            g[p + 'ada_lin.1.bias'] = self.G_ada[n_ada * C:][i * 6 * C:(i + 1) * 6 * C]
+            if cfg.shared_aln:      # folded bias_i = shared bias + ada_gss_i (models._pack): d ada_gss_i = d bias_i
+                g[p + 'ada_gss'] = self.G_ada[n_ada * C:][i * 6 * C:(i + 1) * 6 * C].view(1, 1, 6, C)
+            else:
+                g[p + 'ada_lin.1.weight'] = self.G_ada[:n_ada * C].view(n_ada, C)[i * 6 * C:(i + 1) * 6 * C]
+                g[p + 'ada_lin.1.bias'] = self.G_ada[n_ada * C:][i * 6 * C:(i + 1) * 6 * C]
         n_ada = depth * 6 * C + 2 * C
         g['head_nm.ada_lin.1.weight'] = self.G_ada[:n_ada * C].view(n_ada, C)[depth * 6 * C:]
         g['head_nm.ada_lin.1.bias'] = self.G_ada[n_ada * C:][depth * 6 * C:]
@@ -233,6 +239,10 @@ class TrainEngine:
         g['class_emb.weight'] = mo('class_emb').view(cfg.num_classes + 1, C)
         if cfg.mask_factor == 2:
             g['cond_embed.weight'] = mo('cond_embed').view(5, C)
+        if cfg.shared_aln:
+            g['shared_ada_lin.1.weight'] = mo('w_shared').view(6 * C, C); g['shared_ada_lin.1.bias'] = mo('b_shared')
+        if cfg.type_pos:
+            g['type_embed.weight'] = mo('type').view(cfg.mask_factor, C)
         return g
 
     # ---------------------------------------------------------------- forward + backward
@@ -291,9 +301,9 @@ class TrainEngine:
         # ---- forward
         x0 = self.Xs[0]
         cond = torch.empty(B, C, device=dev, dtype=torch.float32)
-        ops.first_tokens(P['class_emb'], P['cond_embed'], labels, types, P['pos_start'], P['lvl_pos'], x0, cond, B, fl, C, L)
+        ops.first_tokens(P['class_emb'], P['cond_embed'], labels, types, P['pos_start'], P['lvl_pos_fwd'], x0, cond, B, fl, C, L)
         tok = x_wo_first.to(device=dev, dtype=torch.float32).contiguous()
-        ops.word_embed(tok, P['w_we'], P['b_we'], P['lvl_pos'], x0, B, 1, L - fl, cfg.cvae, C, L, fl, lvl_off=fl)
+        ops.word_embed(tok, P['w_we'], P['b_we'], P['lvl_pos_fwd'], x0, B, 1, L - fl, cfg.cvae, C, L, fl, lvl_off=fl)
         cs = torch.empty(B, C, device=dev, dtype=T)
         ops.silu_cast(cond, cs)
         ada = torch.empty(B, n_ada, device=dev, dtype=torch.float32)
@@ -398,6 +408,9 @@ class TrainEngine:
         ops.transpose(cs, tB, 1, B, C, C, ld_out=Bp)
         ops.gemm(tA, tB, self.G_ada, M=n_ada, N=C, K=Bp)
         ops.colsum(self.dada, n_ada, self.G_ada, B, n_ada, ws, out_off=n_ada * C)
+        if cfg.shared_aln:          # rows = blocks: column sums over the depth axis of the folded per-block gradients
+            ops.colsum(self.G_ada, 6 * C * C, self.G_misc, depth, 6 * C * C, ws, out_off=mo['w_shared'][0])
+            ops.colsum(self.G_ada, 6 * C, self.G_misc, depth, 6 * C, ws, a_off=n_ada * C, out_off=mo['b_shared'][0])
         dcond = torch.empty(B, C, device=dev, dtype=torch.float32)
         ops.silu_bwd(cond, dsilu, dcond)
         if self.reducer is not None:
@@ -407,6 +420,11 @@ class TrainEngine:
         ops.colsum(self.dX, L * C, Gm, B, L * C, ws, out_off=mo['pos'][0])
         for k, (b0, e0) in enumerate(zip(py.begin, py.end)):
             ops.colsum(Gm, C, Gm, e0 - b0, C, ws, a_off=mo['pos'][0] + b0 * C, out_off=mo['lvl'][0] + k * C)
+        if cfg.type_pos:            # type_1L: first (control) half of every scale has id 1, the image half id 0 (control_var.py:103-108)
+            for k, (b0, e0) in enumerate(zip(py.begin, py.end)):
+                half = (e0 - b0) // 2
+                for tid, r0 in ((1, b0), (0, b0 + half)):
+                    ops.colsum(Gm, C, Gm, half, C, ws, accumulate=(k > 0), a_off=mo['pos'][0] + r0 * C, out_off=mo['type'][0] + tid * C)
         Gm[mo['pos_start'][0]:mo['pos_start'][0] + fl * C].copy_(Gm[mo['pos'][0]:mo['pos'][0] + fl * C])
         Mt = B * (L - fl)
         Mtp = _pad8(Mt)

@@ -294,7 +294,7 @@ def case_lr():
     save('lr_lin0', table=np.array(rows, dtype=np.float64), peak_lr=4e-5, wd=0.08, wd_end=0.08, wp_it=wp_it, max_it=max_it, wp0=0.005, wpe=0.01)
 
 
-def case_train_step():
+def case_train_step(cfg=None, tag='d2', wseed=0):
     """A20: one training step of the reference on a depth-2 ControlVAR + tiny VQVAE (train_control_var_hpu.py:157-250):
     tokenise control + image, interleave (mask first), teacher-forced forward, CE mean, backward, clip 2.0, AdamW with
     filter_params groups and lr_wd_annealing('lin0').  Dropouts off (cond_drop_rate=0, eval-mode DropPath)."""
@@ -303,8 +303,8 @@ def case_train_step():
     spec = importlib.util.spec_from_file_location('ref_lr_control', '/root/reference/utils/lr_control.py')
     lrc = importlib.util.module_from_spec(spec); spec.loader.exec_module(lrc)
     vae = make_vae(32)
-    cfg = VarConfig(depth=2)
-    m = make_cvar(vae, cfg)            # eval(): DropPath is identity; cond_drop_rate = 0
+    cfg = cfg or VarConfig(depth=2)
+    m = make_cvar(vae, cfg, seed=wseed)  # eval(): DropPath is identity; cond_drop_rate = 0
     for p_ in m.parameters():
         p_.requires_grad_(True)
     images, masks = synth_images(2, 256, seed=6), synth_images(2, 256, seed=7)
@@ -336,7 +336,7 @@ def case_train_step():
     after = {}
     for n, p_ in m.named_parameters():
         after['p:' + n] = p_.detach().reshape(-1)[:: max(1, p_.numel() // 64)][:64].clone()
-    save('train_step_d2', loss=loss.detach(), loss_tok=loss_tok.detach()[::17].clone(), labels=labels.to(torch.int16), x_sample=x[:, ::7].clone(),
+    save(f'train_step_{tag}', loss=loss.detach(), loss_tok=loss_tok.detach()[::17].clone(), labels=labels.to(torch.int16), x_sample=x[:, ::7].clone(),
          names=np.array(names), nd_names=np.array(nd_names), gnorms=gnorms, total_norm=total_norm, lrs=np.array(lrs, dtype=np.float64), **sl, **after)
 
 
@@ -476,6 +476,7 @@ CASES = {
     'checkpoint': case_checkpoint,
     'preprocess': case_preprocess,
     'variants': case_variants,
+    'train_variants': lambda: case_train_step(VarConfig(depth=2, shared_aln=True, type_pos=True), 'd2v', 5),
 }
 
 if __name__ == '__main__':

@@ -256,10 +256,7 @@ def test_forward_logits_fp32(gpu_device, tag, mf):
     m = make_var(vae, cfg, F32, gpu_device, seed=5 if variant else 0)
     gen = torch.Generator().manual_seed(22 if variant else 21)
     x = torch.randn(2, cfg.pyramid.L - cfg.pyramid.first_l, 32, generator=gen)
-    if variant:                                       # training of the variants is not built: grad mode must fail loudly
-        with pytest.raises(NotImplementedError):
-            m(t(g['labels']), x.to(gpu_device), t(g['types']))
-    with torch.no_grad() if variant else contextlib.nullcontext():
+    with torch.no_grad() if variant else contextlib.nullcontext():      # both routes: the inference-only pass and the autograd bridge
         logits = m(t(g['labels']), x.to(gpu_device), t(g['types'])).detach().cpu()
     assert (logits[:, ::9, ::31] - t(g['logits_sample'])).abs().max() < 2e-3
     assert_ids(logits.argmax(-1), g['argmax'], g['margin'], 2e-3, 'forward argmax')

@@ -38,10 +38,12 @@ def build_inputs():
     return x, labels
 
 
-def test_training_step_oracle_matches_reference():
-    g = golden('train_step_d2')
-    cfg = VarConfig(depth=2)
-    sd = synth_var_state(cfg)
+@pytest.mark.parametrize('tag', ['d2', 'd2v'])
+def test_training_step_oracle_matches_reference(tag):
+    """'d2v': the shared_aln + type_pos variant, weights seed 5"""
+    g = golden(f'train_step_{tag}')
+    cfg = VarConfig(depth=2) if tag == 'd2' else VarConfig(depth=2, shared_aln=True, type_pos=True)
+    sd = synth_var_state(cfg, 0 if tag == 'd2' else 5)
     x, labels = build_inputs()
     assert np.array_equal(labels.numpy(), g['labels'].astype(np.int64))
     assert (x[:, ::7] - t(g['x_sample'])).abs().max() < 2e-5
