@@ -369,7 +369,8 @@ class ControlVAR(nn.Module):
 
     Built: aln=1 (AdaLNSABlock), multi_cond as given, and of the non-default variants ``shared_aln``
     and ``type_pos`` for inference, forward and training (both fold into tables at pack time, no extra kernel).
-    separator / bidirectional / separate_decoding / indep / SABlock (aln < 0) raise NotImplementedError.
+    ``aln < 0`` (SABlock: affine LayerNorms + layer scale, basic_var.py:128-176) is likewise folded into the adaLN layout.
+    separator / bidirectional / separate_decoding / indep raise NotImplementedError.
     """
     _control = True
 
@@ -380,8 +381,9 @@ class ControlVAR(nn.Module):
                  separator=False, type_pos=False, indep=False, multi_cond=False,
                  compute_dtype=None, init_seed: int = 0):
         super().__init__()
-        if aln < 0 or separator or bidirectional or separate_decoding or indep:
-            raise NotImplementedError('separator / bidirectional / separate_decoding / indep / SABlock variants (SURVEY.md 8f N4) are not built')
+        if separator or bidirectional or separate_decoding or indep:
+            raise NotImplementedError('separator / bidirectional / separate_decoding / indep variants (SURVEY.md 8f N4) are not built')
+        sa_block = aln < 0                                           # control_var.py:41: using_aln = aln >= 0
         if type_pos and not (self._control and mask_factor == 2):
             raise NotImplementedError('type_pos needs the joint (control, image) sequence: upstream builds type_1L with 2*sum(pn^2) entries')
         if self._control and mask_factor == 2 and not multi_cond:
@@ -392,7 +394,8 @@ class ControlVAR(nn.Module):
                              control=self._control, patch_nums=tuple(patch_nums), vocab=vae_local.vocab_size, cvae=vae_local.Cvae,
                              num_classes=num_classes, embed_dim=embed_dim, num_heads=num_heads, norm_eps=norm_eps, tau=float(tau),
                              cos_attn=bool(cos_attn), mlp_ratio=mlp_ratio, cond_drop_rate=cond_drop_rate,
-                             shared_aln=bool(shared_aln), type_pos=bool(type_pos))
+                             shared_aln=bool(shared_aln) and not sa_block, type_pos=bool(type_pos), sa_block=sa_block,
+                             layer_scale=float(layer_scale) if sa_block else -1.0)
         cfg = self.cfg
         self.Cvae, self.V = cfg.cvae, cfg.vocab
         self.depth, self.C, self.D, self.num_heads = depth, cfg.C, cfg.C, cfg.H
@@ -447,7 +450,18 @@ class ControlVAR(nn.Module):
         P['w_fc2'] = torch.stack([blk(i, 'ffn.fc2.weight') for i in range(depth)]).to(T).contiguous()
         P['b_fc2'] = torch.stack([blk(i, 'ffn.fc2.bias') for i in range(depth)]).float().contiguous()
         # every ada_lin of the model in ONE weight: rows [i*6C,(i+1)*6C) = block i, last 2C rows = head_nm
-        if cfg.shared_aln:
+        head_w, head_b = ('head.1.weight', 'head.1.bias') if cfg.sa_block else ('head.weight', 'head.bias')
+        if cfg.sa_block:
+            # SABlock (basic_var.py:128-160) in the adaLN layout: LayerNorm(x) * w + b == LN0(x) * (1 + (w - 1)) + b and the
+            # residual gates are the layer-scale gammas (or 1).  The generator weight is zero, its bias holds the constants,
+            # so every kernel (and the backward: d bias = column sum of d ada) is shared with the adaLN form.
+            one = torch.ones(C, device=dev)
+            gam = (lambda i, k: blk(i, k)) if cfg.layer_scale >= 0 else (lambda i, k: one)
+            b_blk = [torch.cat([gam(i, 'gamma1'), gam(i, 'gamma2'), blk(i, 'norm1.weight') - 1, blk(i, 'norm2.weight') - 1,
+                                blk(i, 'norm1.bias'), blk(i, 'norm2.bias')]) for i in range(depth)]
+            w_all = torch.zeros(depth * 6 * C + 2 * C, C, device=dev)
+            b_all = torch.cat(b_blk + [sd['head.0.weight'] - 1, sd['head.0.bias']])
+        elif cfg.shared_aln:
             # (ada_gss + SharedAdaLin(cond)) of block i (basic_var.py:204-205) == a Linear whose weight is the shared one and whose
             # bias is shared bias + ada_gss_i: replicate the weight per block so the one-GEMM layout below serves both forms
             w_blk = [sd['shared_ada_lin.1.weight']] * depth
@@ -455,11 +469,14 @@ class ControlVAR(nn.Module):
         else:
             w_blk = [blk(i, 'ada_lin.1.weight') for i in range(depth)]
             b_blk = [blk(i, 'ada_lin.1.bias') for i in range(depth)]
-        P['w_ada'] = torch.cat(w_blk + [sd['head_nm.ada_lin.1.weight']]).to(T).contiguous()
-        P['b_ada'] = torch.cat(b_blk + [sd['head_nm.ada_lin.1.bias']]).float().contiguous()
+        if not cfg.sa_block:
+            w_all = torch.cat(w_blk + [sd['head_nm.ada_lin.1.weight']])
+            b_all = torch.cat(b_blk + [sd['head_nm.ada_lin.1.bias']])
+        P['w_ada'] = w_all.to(T).contiguous()
+        P['b_ada'] = b_all.float().contiguous()
         P['n_ada'] = depth * 6 * C + 2 * C
-        P['w_head'] = sd['head.weight'].to(T).contiguous()
-        P['b_head'] = sd['head.bias'].float().contiguous()
+        P['w_head'] = sd[head_w].to(T).contiguous()
+        P['b_head'] = sd[head_b].float().contiguous()
         P['w_we'] = sd['word_embed.weight'].float().contiguous()
         P['b_we'] = sd['word_embed.bias'].float().contiguous()
         P['lvl_pos'] = (sd['lvl_embed.weight'][sd['lvl_1L'][0]] + sd['pos_1LC'][0]).float().contiguous()      # (L, C)

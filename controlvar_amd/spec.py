@@ -99,6 +99,8 @@ class VarConfig:
     cond_drop_rate: float = 0.1
     shared_aln: bool = False        # N4: one SharedAdaLin for all blocks + per-block ada_gss (control_var.py:120, basic_var.py:194-205)
     type_pos: bool = False          # N4: type_embed added per control / image half (control_var.py:99-117,423,482,623)
+    sa_block: bool = False          # N4: aln < 0 -> SABlock (affine LayerNorms, no adaLN; basic_var.py:128-176) + head = Sequential(LN, Linear)
+    layer_scale: float = -1.0       # SABlock only: >= 0 -> learned per-channel gamma1 / gamma2 (basic_var.py:145-149)
 
     @property
     def C(self) -> int:
@@ -140,12 +142,18 @@ def var_state_shapes(cfg: VarConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...],
     sd['lvl_embed.weight'] = ((len(cfg.patch_nums), C), 'param')
     if cfg.type_pos:
         sd['type_embed.weight'] = ((cfg.mask_factor, C), 'param')
-    if cfg.shared_aln:
+    if cfg.shared_aln and not cfg.sa_block:
         sd['shared_ada_lin.1.weight'] = ((6 * C, C), 'param')
         sd['shared_ada_lin.1.bias'] = ((6 * C,), 'param')
     for i in range(cfg.depth):
         p = f'blocks.{i}.'
-        if cfg.shared_aln:
+        if cfg.sa_block:
+            if cfg.layer_scale >= 0:
+                sd[p + 'gamma1'] = ((C,), 'param')
+                sd[p + 'gamma2'] = ((C,), 'param')
+            sd[p + 'norm1.weight'] = ((C,), 'param')
+            sd[p + 'norm1.bias'] = ((C,), 'param')
+        elif cfg.shared_aln:
             sd[p + 'ada_gss'] = ((1, 1, 6, C), 'param')
         sd[p + 'attn.q_bias'] = ((C,), 'param')
         sd[p + 'attn.v_bias'] = ((C,), 'param')
@@ -155,17 +163,26 @@ def var_state_shapes(cfg: VarConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...],
         sd[p + 'attn.mat_qkv.weight'] = ((3 * C, C), 'param')
         sd[p + 'attn.proj.weight'] = ((C, C), 'param')
         sd[p + 'attn.proj.bias'] = ((C,), 'param')
+        if cfg.sa_block:
+            sd[p + 'norm2.weight'] = ((C,), 'param')
+            sd[p + 'norm2.bias'] = ((C,), 'param')
         sd[p + 'ffn.fc1.weight'] = ((hid, C), 'param')
         sd[p + 'ffn.fc1.bias'] = ((hid,), 'param')
         sd[p + 'ffn.fc2.weight'] = ((C, hid), 'param')
         sd[p + 'ffn.fc2.bias'] = ((C,), 'param')
-        if not cfg.shared_aln:
+        if not (cfg.shared_aln or cfg.sa_block):
             sd[p + 'ada_lin.1.weight'] = ((6 * C, C), 'param')
             sd[p + 'ada_lin.1.bias'] = ((6 * C,), 'param')
-    sd['head_nm.ada_lin.1.weight'] = ((2 * C, C), 'param')
-    sd['head_nm.ada_lin.1.bias'] = ((2 * C,), 'param')
-    sd['head.weight'] = ((V, C), 'param')
-    sd['head.bias'] = ((V,), 'param')
+    if cfg.sa_block:                                 # control_var.py:205-207: MultiInpIdentity + Sequential(norm, Linear)
+        sd['head.0.weight'] = ((C,), 'param')
+        sd['head.0.bias'] = ((C,), 'param')
+        sd['head.1.weight'] = ((V, C), 'param')
+        sd['head.1.bias'] = ((V,), 'param')
+    else:
+        sd['head_nm.ada_lin.1.weight'] = ((2 * C, C), 'param')
+        sd['head_nm.ada_lin.1.bias'] = ((2 * C,), 'param')
+        sd['head.weight'] = ((V, C), 'param')
+        sd['head.bias'] = ((V,), 'param')
     if cfg.control and cfg.multi_cond:
         sd['cond_embed.weight'] = ((NUM_COND_TYPES + 1, C), 'param')
     return sd

@@ -46,6 +46,10 @@ def synth_var_state(cfg: VarConfig, seed: int = 0, head_gain: float = 4.0) -> Di
             for pn in py.patch_nums:
                 ids += [first] * (pn * pn) + [1 - first] * (pn * pn)
             out[key] = torch.tensor(ids, dtype=torch.int64).view(1, -1)
+        elif key.endswith('gamma1') or key.endswith('gamma2'):
+            out[key] = _randn(shape, g, std=0.1, mean=0.35)
+        elif len(shape) == 1 and key.endswith('.weight'):            # LayerNorm weights of the SABlock variant
+            out[key] = _randn(shape, g, std=0.1, mean=1.0)
         elif key.endswith('ada_gss'):
             b = _randn(shape, g, std=0.1)
             b[0, 0, :2] += 0.35
@@ -65,7 +69,7 @@ def synth_var_state(cfg: VarConfig, seed: int = 0, head_gain: float = 4.0) -> Di
             if key.startswith('blocks.') and not cfg.shared_aln:
                 b[:2 * C] += 0.35            # gamma1, gamma2 rows: residual gates around 0.35
             out[key] = b
-        elif key == 'head.weight':
+        elif key in ('head.weight', 'head.1.weight'):
             out[key] = _randn(shape, g, std=head_gain / math.sqrt(C))
         elif key.endswith('.weight') and len(shape) == 2:
             out[key] = _randn(shape, g, std=1.0 / math.sqrt(shape[1]))

@@ -222,17 +222,28 @@ class TrainEngine:
             if cfg.uses_cos_attn:
                 g[p + 'attn.scale_mul_1H11'] = s[so['scale_mul']:so['scale_mul'] + cfg.H].view(1, cfg.H, 1, 1)
             n_ada = depth * 6 * C + 2 * C
-            if cfg.shared_aln:      # folded bias_i = shared bias + ada_gss_i (models._pack): d ada_gss_i = d bias_i
+            if cfg.sa_block:        # constants in the folded bias (models._pack): [gamma1, gamma2, w1 - 1, w2 - 1, b1, b2]
+                gb = self.G_ada[n_ada * C:][i * 6 * C:(i + 1) * 6 * C]
+                if cfg.layer_scale >= 0:
+                    g[p + 'gamma1'], g[p + 'gamma2'] = gb[0:C], gb[C:2 * C]
+                g[p + 'norm1.weight'], g[p + 'norm2.weight'] = gb[2 * C:3 * C], gb[3 * C:4 * C]
+                g[p + 'norm1.bias'], g[p + 'norm2.bias'] = gb[4 * C:5 * C], gb[5 * C:6 * C]
+            elif cfg.shared_aln:    # folded bias_i = shared bias + ada_gss_i (models._pack): d ada_gss_i = d bias_i
                 g[p + 'ada_gss'] = self.G_ada[n_ada * C:][i * 6 * C:(i + 1) * 6 * C].view(1, 1, 6, C)
             else:
                 g[p + 'ada_lin.1.weight'] = self.G_ada[:n_ada * C].view(n_ada, C)[i * 6 * C:(i + 1) * 6 * C]
                 g[p + 'ada_lin.1.bias'] = self.G_ada[n_ada * C:][i * 6 * C:(i + 1) * 6 * C]
         n_ada = depth * 6 * C + 2 * C
-        g['head_nm.ada_lin.1.weight'] = self.G_ada[:n_ada * C].view(n_ada, C)[depth * 6 * C:]
-        g['head_nm.ada_lin.1.bias'] = self.G_ada[n_ada * C:][depth * 6 * C:]
         mo = lambda k: self.G_misc[self.misc_off[k][0]:self.misc_off[k][0] + self.misc_off[k][1]]
         py = cfg.pyramid
-        g['head.weight'] = mo('w_head').view(V, C); g['head.bias'] = mo('b_head')
+        if cfg.sa_block:            # head = Sequential(LayerNorm, Linear) (control_var.py:205-207)
+            hb = self.G_ada[n_ada * C:][depth * 6 * C:]
+            g['head.0.weight'], g['head.0.bias'] = hb[:C], hb[C:]
+            g['head.1.weight'] = mo('w_head').view(V, C); g['head.1.bias'] = mo('b_head')
+        else:
+            g['head_nm.ada_lin.1.weight'] = self.G_ada[:n_ada * C].view(n_ada, C)[depth * 6 * C:]
+            g['head_nm.ada_lin.1.bias'] = self.G_ada[n_ada * C:][depth * 6 * C:]
+            g['head.weight'] = mo('w_head').view(V, C); g['head.bias'] = mo('b_head')
         g['word_embed.weight'] = mo('w_we').view(C, cfg.cvae); g['word_embed.bias'] = mo('b_we')
         g['pos_1LC'] = mo('pos').view(1, py.L, C); g['lvl_embed.weight'] = mo('lvl').view(len(cfg.patch_nums), C)
         g['pos_start'] = mo('pos_start').view(1, py.first_l, C)

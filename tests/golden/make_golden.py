@@ -69,7 +69,7 @@ def make_cvar(vae, cfg: VarConfig, seed=0):
         else:
             m = quiet(build_control_var, vae, depth=cfg.depth, patch_nums=PN, mask_type='interleave_append' if cfg.mask_factor == 2 else 'replace',
                       cond_drop_rate=0.0, multi_cond=cfg.multi_cond, flash_if_available=False, fused_if_available=False,
-                      shared_aln=cfg.shared_aln, type_pos=cfg.type_pos)
+                      shared_aln=cfg.shared_aln, type_pos=cfg.type_pos, aln=-1 if cfg.sa_block else 1, layer_scale=cfg.layer_scale)
     else:
         m = quiet(build_var, vae, depth=cfg.depth, patch_nums=PN, flash_if_available=False, fused_if_available=False, shared_aln=cfg.shared_aln)
         m.cond_drop_rate = 0.0
@@ -428,6 +428,24 @@ def case_preprocess():
     save('preprocess', ign_cond=ct, ignore_mask=torch.concat(a), ignore_mask_=torch.concat(b), **out)
 
 
+def case_sa_block():
+    """aln < 0 -> SABlock (affine LayerNorms, layer-scale gammas) + Sequential(LN, Linear) head; depth 2."""
+    vae = make_vae(32)
+    for tag, cfg, seed in (('d2sa', VarConfig(depth=2, sa_block=True, layer_scale=0.1), 7), ('d2sa0', VarConfig(depth=2, sa_block=True), 8)):
+        m = make_cvar(vae, cfg, seed=seed)
+        g = torch.Generator().manual_seed(23)
+        x = torch.randn(2, cfg.pyramid.L - cfg.pyramid.first_l, 32, generator=g)
+        labels, types = torch.tensor([9, 500]), torch.tensor([3, 1])
+        with torch.no_grad():
+            logits = m(labels, x, types, True)
+        t2 = logits.topk(2, dim=-1).values
+        save(f'forward_{tag}', keys=np.array(list(m.state_dict().keys())), labels=labels, types=types, logits_sample=logits[:, ::9, ::31].contiguous(),
+             argmax=logits.argmax(-1).to(torch.int16), margin=(t2[..., 0] - t2[..., 1]), lsum=logits.double().sum(-1).float())
+        if tag == 'd2sa':
+            r = _run_generate(m, ref_cv, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]))
+            save('gen_d2sa_b2', **r)
+
+
 def case_variants():
     """shared_aln (SharedAdaLin + per-block ada_gss) and type_pos (type_embed), depth 2, tiny VQVAE.
     Records the reference's state_dict key order for both models, teacher-forced logits and greedy decode traces - note
@@ -476,6 +494,8 @@ CASES = {
     'checkpoint': case_checkpoint,
     'preprocess': case_preprocess,
     'variants': case_variants,
+    'sa_block': case_sa_block,
+    'train_sa_block': lambda: case_train_step(VarConfig(depth=2, sa_block=True, layer_scale=0.1), 'd2sa', 7),
     'train_variants': lambda: case_train_step(VarConfig(depth=2, shared_aln=True, type_pos=True), 'd2v', 5),
 }
 

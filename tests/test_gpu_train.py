@@ -22,7 +22,8 @@ def make(cfg, dtype, dev, seed=0):
     vae = models.build_vae(ch=32, compute_dtype=dtype).to(dev)
     if cfg.control:
         m = models.ControlVAR(vae, depth=cfg.depth, embed_dim=cfg.C, num_heads=cfg.H, mask_factor=2, multi_cond=True, patch_nums=PN,
-                              compute_dtype=dtype, cond_drop_rate=0.0, shared_aln=cfg.shared_aln, type_pos=cfg.type_pos, init_seed=seed)
+                              compute_dtype=dtype, cond_drop_rate=0.0, shared_aln=cfg.shared_aln, type_pos=cfg.type_pos,
+                              aln=-1 if cfg.sa_block else 1, layer_scale=cfg.layer_scale, init_seed=seed)
     else:
         m = models.VAR(vae, depth=cfg.depth, embed_dim=cfg.C, num_heads=cfg.H, patch_nums=PN, compute_dtype=dtype, cond_drop_rate=0.0,
                        shared_aln=cfg.shared_aln, init_seed=seed)
@@ -38,13 +39,17 @@ def tokenize(vae, dev):
     return x, labels
 
 
-@pytest.mark.parametrize('tag', ['d2', 'd2v'])
+FIXTURE_CASES = {'d2': (VarConfig(depth=2), 0), 'd2v': (VarConfig(depth=2, shared_aln=True, type_pos=True), 5),
+                 'd2sa': (VarConfig(depth=2, sa_block=True, layer_scale=0.1), 7)}
+
+
+@pytest.mark.parametrize('tag', list(FIXTURE_CASES))
 def test_training_step_fp32_matches_reference_fixture(gpu_device, tag):
     """tokenise (HIP) -> interleave -> forward -> CE -> backward, fp32 mode, against train_step_<tag>.npz (the reference);
     'd2v' = the shared_aln + type_pos variant."""
     g = golden(f'train_step_{tag}')
-    cfg = VarConfig(depth=2) if tag == 'd2' else VarConfig(depth=2, shared_aln=True, type_pos=True)
-    vae, m = make(cfg, torch.float32, gpu_device, seed=0 if tag == 'd2' else 5)
+    cfg, wseed = FIXTURE_CASES[tag]
+    vae, m = make(cfg, torch.float32, gpu_device, seed=wseed)
     x, labels = tokenize(vae, gpu_device)
     assert np.array_equal(labels.cpu().numpy(), g['labels'].astype(np.int64))
     eng = T.TrainEngine(m, drop_path=False)
@@ -67,14 +72,15 @@ def test_training_step_fp32_matches_reference_fixture(gpu_device, tag):
     print(f'worst relative gradient-slice error vs the reference: {worst:.2e}')
 
 
-@pytest.mark.parametrize('kind', ['control', 'var', 'cos', 'variant', 'var_shared'])
+@pytest.mark.parametrize('kind', ['control', 'var', 'cos', 'variant', 'var_shared', 'sa', 'sa_no_scale'])
 def test_all_gradients_against_oracle_fp32(gpu_device, kind):
     """full tensors of every gradient vs autograd over the oracle (d2 ControlVAR, plain VAR, and the depth-30 cos-attention
     variant at narrow width incl. its learned temperature), with an ignore mask"""
     cfg = {'control': VarConfig(depth=2), 'var': VarConfig(depth=2, mask_factor=1, control=False, multi_cond=False),
            'cos': VarConfig(depth=30, embed_dim=128, num_heads=2),
            'variant': VarConfig(depth=3, shared_aln=True, type_pos=True),
-           'var_shared': VarConfig(depth=2, mask_factor=1, control=False, multi_cond=False, shared_aln=True)}[kind]
+           'var_shared': VarConfig(depth=2, mask_factor=1, control=False, multi_cond=False, shared_aln=True),
+           'sa': VarConfig(depth=3, sa_block=True, layer_scale=0.1), 'sa_no_scale': VarConfig(depth=2, sa_block=True)}[kind]
     vae, m = make(cfg, torch.float32, gpu_device)
     sd = synth_var_state(cfg)
     B, L, fl = 2, cfg.pyramid.L, cfg.pyramid.first_l
@@ -116,13 +122,13 @@ def test_training_step_bf16_close_to_fp32_oracle(gpu_device):
         assert cos > 0.99, (n, float(cos))
 
 
-@pytest.mark.parametrize('tag', ['d2', 'd2v'])
+@pytest.mark.parametrize('tag', list(FIXTURE_CASES))
 def test_trainer_step_matches_reference_adamw(gpu_device, tag):
     """A20 end to end in fp32 mode: lr/wd schedule -> tokenise -> forward/backward -> clip 2.0 -> AdamW, parameters after the
     step against the reference's (train_step_<tag>.npz 'p:*' slices; 'd2v' = shared_aln + type_pos)."""
     g = golden(f'train_step_{tag}')
-    cfg = VarConfig(depth=2) if tag == 'd2' else VarConfig(depth=2, shared_aln=True, type_pos=True)
-    vae, m = make(cfg, torch.float32, gpu_device, seed=0 if tag == 'd2' else 5)
+    cfg, wseed = FIXTURE_CASES[tag]
+    vae, m = make(cfg, torch.float32, gpu_device, seed=wseed)
     m.eval()                                   # DropPath / label dropout off, as in the recorded reference step
     tr = T.Trainer(m, vae, peak_lr=2e-3, weight_decay=0.05, weight_decay_end=0.01, sche='lin0', warmup_it=20, max_it=1000, clip=2.0,
                    wp0=0.005, wpe=0.01, drop_path=False)

@@ -237,3 +237,27 @@ def test_variant_generate():
     _gen_check('gen_d2v_cmask', VARIANT, 2, torch.tensor([5, 6]), (4.0, 3.0, 2.0), cond_type=torch.tensor([2, 3]), four=True,
                teach='c_mask', wseed=5)
     _gen_check('gen_var_d2s_b2', VARIANT_VAR, 2, torch.tensor([3, 7]), 4.0, wseed=6)
+
+
+# ------------------------------------------------------------------------------ SABlock (aln < 0)
+SA = VarConfig(depth=2, sa_block=True, layer_scale=0.1)
+SA0 = VarConfig(depth=2, sa_block=True)
+
+
+@pytest.mark.parametrize('tag,cfg,seed', [('d2sa', SA, 7), ('d2sa0', SA0, 8)])
+def test_sa_block_forward_logits_and_key_order(tag, cfg, seed):
+    from controlvar_amd.spec import var_state_shapes
+    g = golden(f'forward_{tag}')
+    assert list(var_state_shapes(cfg)) == [str(k) for k in g['keys']]
+    sd = synth_var_state(cfg, seed)
+    gen = torch.Generator().manual_seed(23)
+    x = torch.randn(2, cfg.pyramid.L - cfg.pyramid.first_l, 32, generator=gen)
+    with torch.no_grad():
+        logits = var_ref.forward_logits(sd, cfg, t(g['labels']), x, t(g['types']))
+    assert (logits[:, ::9, ::31] - t(g['logits_sample'])).abs().max() < 1e-4
+    mism = logits.argmax(-1).numpy() != g['argmax'].astype(np.int64)
+    assert mism.sum() == 0 or g['margin'][mism].max() < 1e-4
+
+
+def test_sa_block_generate():
+    _gen_check('gen_d2sa_b2', SA, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]), wseed=7)

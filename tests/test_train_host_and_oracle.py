@@ -38,12 +38,16 @@ def build_inputs():
     return x, labels
 
 
-@pytest.mark.parametrize('tag', ['d2', 'd2v'])
+TRAIN_CASES = {'d2': (VarConfig(depth=2), 0), 'd2v': (VarConfig(depth=2, shared_aln=True, type_pos=True), 5),
+               'd2sa': (VarConfig(depth=2, sa_block=True, layer_scale=0.1), 7)}
+
+
+@pytest.mark.parametrize('tag', list(TRAIN_CASES))
 def test_training_step_oracle_matches_reference(tag):
-    """'d2v': the shared_aln + type_pos variant, weights seed 5"""
+    """'d2v': the shared_aln + type_pos variant, 'd2sa': the SABlock variant"""
     g = golden(f'train_step_{tag}')
-    cfg = VarConfig(depth=2) if tag == 'd2' else VarConfig(depth=2, shared_aln=True, type_pos=True)
-    sd = synth_var_state(cfg, 0 if tag == 'd2' else 5)
+    cfg, wseed = TRAIN_CASES[tag]
+    sd = synth_var_state(cfg, wseed)
     x, labels = build_inputs()
     assert np.array_equal(labels.numpy(), g['labels'].astype(np.int64))
     assert (x[:, ::7] - t(g['x_sample'])).abs().max() < 2e-5
