@@ -370,7 +370,8 @@ class ControlVAR(nn.Module):
     Built: aln=1 (AdaLNSABlock), multi_cond as given, and of the non-default variants ``shared_aln``
     and ``type_pos`` for inference, forward and training (both fold into tables at pack time, no extra kernel).
     ``aln < 0`` (SABlock: affine LayerNorms + layer scale, basic_var.py:128-176) is likewise folded into the adaLN layout.
-    separator / bidirectional / separate_decoding / indep raise NotImplementedError.
+    ``bidirectional`` (image-first order, mask_first=False) swaps the first two tokens and the type ids.
+    separator / separate_decoding / indep raise NotImplementedError.
     """
     _control = True
 
@@ -381,8 +382,10 @@ class ControlVAR(nn.Module):
                  separator=False, type_pos=False, indep=False, multi_cond=False,
                  compute_dtype=None, init_seed: int = 0):
         super().__init__()
-        if separator or bidirectional or separate_decoding or indep:
-            raise NotImplementedError('separator / bidirectional / separate_decoding / indep variants (SURVEY.md 8f N4) are not built')
+        if separator or separate_decoding or indep:
+            raise NotImplementedError('separator / separate_decoding / indep variants (SURVEY.md 8f N4) are not built')
+        if bidirectional and not (self._control and mask_factor == 2):
+            raise NotImplementedError('bidirectional needs the joint (control, image) sequence')
         sa_block = aln < 0                                           # control_var.py:41: using_aln = aln >= 0
         if type_pos and not (self._control and mask_factor == 2):
             raise NotImplementedError('type_pos needs the joint (control, image) sequence: upstream builds type_1L with 2*sum(pn^2) entries')
@@ -395,8 +398,9 @@ class ControlVAR(nn.Module):
                              num_classes=num_classes, embed_dim=embed_dim, num_heads=num_heads, norm_eps=norm_eps, tau=float(tau),
                              cos_attn=bool(cos_attn), mlp_ratio=mlp_ratio, cond_drop_rate=cond_drop_rate,
                              shared_aln=bool(shared_aln) and not sa_block, type_pos=bool(type_pos), sa_block=sa_block,
-                             layer_scale=float(layer_scale) if sa_block else -1.0)
+                             layer_scale=float(layer_scale) if sa_block else -1.0, bidirectional=bool(bidirectional))
         cfg = self.cfg
+        self.bidirectional = cfg.bidirectional
         self.Cvae, self.V = cfg.cvae, cfg.vocab
         self.depth, self.C, self.D, self.num_heads = depth, cfg.C, cfg.C, cfg.H
         self.patch_nums, self.mask_factor, self.multi_cond = tuple(patch_nums), mask_factor, cfg.multi_cond
@@ -482,19 +486,34 @@ class ControlVAR(nn.Module):
         P['lvl_pos'] = (sd['lvl_embed.weight'][sd['lvl_1L'][0]] + sd['pos_1LC'][0]).float().contiguous()      # (L, C)
         # type_pos (control_var.py:99-117): upstream adds type_embed[type_1L] to every row in forward() (:622-624), to the
         # rows of scales >= 1 in autoregressive_infer_cfg (:423-424,482-483) and nowhere in conditional_infer_cfg
-        P['lvl_pos_fwd'] = P['lvl_pos_gen'] = P['lvl_pos']
+        # the '_' tables are the image-first order (mask_first=False, bidirectional): type ids from type_1L_ (:424,624)
+        P['lvl_pos_fwd'] = P['lvl_pos_gen'] = P['lvl_pos_fwd_'] = P['lvl_pos_gen_'] = P['lvl_pos']
         if cfg.type_pos:
-            ty = sd['type_embed.weight'][sd['type_1L'][0]].float()
-            P['lvl_pos_fwd'] = (P['lvl_pos'] + ty).contiguous()
-            P['lvl_pos_gen'] = P['lvl_pos_fwd'].clone()
-            P['lvl_pos_gen'][:cfg.pyramid.first_l] = P['lvl_pos'][:cfg.pyramid.first_l]
+            for suf, buf in (('', 'type_1L'), ('_', 'type_1L_')):
+                ty = sd['type_embed.weight'][sd[buf][0]].float()
+                P['lvl_pos_fwd' + suf] = (P['lvl_pos'] + ty).contiguous()
+                P['lvl_pos_gen' + suf] = P['lvl_pos_fwd' + suf].clone()
+                P['lvl_pos_gen' + suf][:cfg.pyramid.first_l] = P['lvl_pos'][:cfg.pyramid.first_l]
         P['pos_start'] = sd['pos_start'][0].float().contiguous()
+        P['pos_start_sw'] = P['pos_start'].flip(0).contiguous()
         P['class_emb'] = sd['class_emb.weight'].float().contiguous()
         P['cond_embed'] = sd['cond_embed.weight'].float().contiguous() if 'cond_embed.weight' in sd else None
         if cfg.uses_cos_attn:
             P['scale_mul'] = torch.stack([blk(i, 'attn.scale_mul_1H11').reshape(-1) for i in range(depth)]).float().contiguous()
         self._packed = P
         return P
+
+    def _first_tokens(self, P, labels, types, x, cond, R: int, x_rows: int, table, mask_first: bool = True):
+        """first-scale tokens [cond_token, sos] (+ pos_start + table rows); image first (mask_first=False, control_var.py:404-407,
+        587) is [sos, cond_token]: the kernel runs with the two position rows exchanged, then the two token rows are exchanged."""
+        py, C = self.cfg.pyramid, self.cfg.C
+        if mask_first or py.first_l != 2:
+            ops.first_tokens(P['class_emb'], P['cond_embed'], labels, types, P['pos_start'], table, x, cond, R, py.first_l, C, x_rows)
+            return
+        ops.first_tokens(P['class_emb'], P['cond_embed'], labels, types, P['pos_start_sw'], table[:2].flip(0).contiguous(), x, cond, R,
+                         py.first_l, C, x_rows)
+        xv = x[:R * x_rows].view(R, x_rows, C)
+        xv[:, :2] = xv[:, :2].flip(1)
 
     def _get_arena(self, R: int, Lmax: int):
         key = (R, Lmax, self.compute_dtype)
@@ -587,11 +606,18 @@ class ControlVAR(nn.Module):
             raise NotImplementedError('more_smooth (Gumbel visualisation path) is not built (SURVEY.md 8f N4)')
         seed = int(g_seed) if g_seed is not None else int(torch.empty((), dtype=torch.int64).random_().item())
         labels_all, types_all = self._prepare_rows(B, label_B, cond_type, four_way, seed)
-        return self._generate_core(B, labels_all, types_all, seed, None, cfg_scale, top_k, top_p, four_way, c_mask, c_img, force_idx, trace)
+        mask_first = True
+        if self.cfg.mask_factor == 2 and not four_way:
+            # control_var.py:403: python's global `random`, drawn on every call (before the `or`), exactly as upstream -
+            # random.seed(k) before the call reproduces the reference's choice of order
+            import random
+            mask_first = True if (random.random() < 0.5 or not self.bidirectional) else False
+        return self._generate_core(B, labels_all, types_all, seed, None, cfg_scale, top_k, top_p, four_way, c_mask, c_img, force_idx, trace,
+                                   mask_first=mask_first)
 
     @torch.no_grad()
     def _generate_core(self, B, labels_all, types_all, seed, seed_dev, cfg_scale, top_k, top_p, four_way, c_mask=None, c_img=None,
-                       force_idx=None, trace: bool = False):
+                       force_idx=None, trace: bool = False, mask_first: bool = True):
         """the 10-scale loop on device-resident inputs only (capturable in a HIP graph: no host sync, static shapes)"""
         cfg, P = self.cfg, self._pack()
         vae: VQVAE = self.vae_proxy[0]
@@ -602,7 +628,8 @@ class ControlVAR(nn.Module):
         nb = R if four_way else B
         x = torch.empty(R * py.l[-1], C, device=dev, dtype=torch.float32)
         cond = torch.empty(R, C, device=dev, dtype=torch.float32)
-        ops.first_tokens(P['class_emb'], P['cond_embed'], labels_all, types_all, P['pos_start'], P['lvl_pos'], x, cond, R, py.first_l, C, py.first_l)
+        self._first_tokens(P, labels_all, types_all, x, cond, R, py.first_l, P['lvl_pos'], mask_first)
+        gen_table = P['lvl_pos'] if four_way else (P['lvl_pos_gen'] if mask_first else P['lvl_pos_gen_'])
         ada = self._ada(cond, R)
         arena = self._get_arena(R, py.L)
         S = py.patch_nums[-1]
@@ -636,7 +663,7 @@ class ControlVAR(nn.Module):
             tok = vae._next_input(si, idx, f_hat, nb, mf, True)
             if si != nstage - 1:
                 ln = py.l[si + 1]
-                ops.word_embed(tok, P['w_we'], P['b_we'], P['lvl_pos'] if four_way else P['lvl_pos_gen'], x, nb, 1 if four_way else 2, ln,
+                ops.word_embed(tok, P['w_we'], P['b_we'], gen_table, x, nb, 1 if four_way else 2, ln,
                                cfg.cvae, C, ln, 0, lvl_off=py.end[si])
         if trace:
             tr['f_hat'] = f_hat[:B].clone()
@@ -651,6 +678,8 @@ class ControlVAR(nn.Module):
         Removes the host launch cost that dominates small batches (the reference's loop is host-launched op by op)."""
         dev = self.device
         four_way = False
+        if self.bidirectional:
+            raise NotImplementedError('the captured generator fixes the (control, image) order; bidirectional models draw it per call')
         lab0 = torch.zeros(B, dtype=torch.int64)
         ty0 = torch.zeros(B, dtype=torch.int64) if self.cfg.mask_factor == 2 else None
         labels_all, types_all = self._prepare_rows(B, lab0, ty0, four_way, 0)
@@ -708,9 +737,7 @@ class ControlVAR(nn.Module):
         ``self.training`` (torch.rand, as the reference)."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from .train import teacher_forced_with_grad
-            if not mask_first:
-                raise NotImplementedError('mask_first=False only occurs with bidirectional=True')
-            return teacher_forced_with_grad(self, label_B, x_BLCv_wo_first_l, cond_type)
+            return teacher_forced_with_grad(self, label_B, x_BLCv_wo_first_l, cond_type, bool(mask_first))
         with torch.no_grad():
             return self._forward_nograd(label_B, x_BLCv_wo_first_l, cond_type, mask_first)
 
@@ -718,8 +745,7 @@ class ControlVAR(nn.Module):
         cfg, P = self.cfg, self._pack()
         py, C = cfg.pyramid, cfg.C
         dev = self.device
-        if not mask_first:
-            raise NotImplementedError('mask_first=False only occurs with bidirectional=True')
+        mask_first = bool(mask_first) or cfg.mask_factor != 2
         B = x_BLCv_wo_first_l.shape[0]
         labels = label_B.to(dev)
         if self.training and cfg.cond_drop_rate > 0:
@@ -733,9 +759,10 @@ class ControlVAR(nn.Module):
         labels = labels.to(torch.int32).contiguous()
         x = torch.empty(B * py.L, C, device=dev, dtype=torch.float32)
         cond = torch.empty(B, C, device=dev, dtype=torch.float32)
-        ops.first_tokens(P['class_emb'], P['cond_embed'], labels, types, P['pos_start'], P['lvl_pos_fwd'], x, cond, B, py.first_l, C, py.L)
+        table = P['lvl_pos_fwd'] if mask_first else P['lvl_pos_fwd_']
+        self._first_tokens(P, labels, types, x, cond, B, py.L, table, mask_first)
         tok = x_BLCv_wo_first_l.to(device=dev, dtype=torch.float32).contiguous()
-        ops.word_embed(tok, P['w_we'], P['b_we'], P['lvl_pos_fwd'], x, B, 1, py.L - py.first_l, cfg.cvae, C, py.L, py.first_l, lvl_off=py.first_l)
+        ops.word_embed(tok, P['w_we'], P['b_we'], table, x, B, 1, py.L - py.first_l, cfg.cvae, C, py.L, py.first_l, lvl_off=py.first_l)
         ada = self._ada(cond, B)
         arena = self._get_arena(B, py.L)
         logits = self._blocks_and_head(x, ada, B, py.L, 0, py.L, arena, lvl_end=list(py.end))

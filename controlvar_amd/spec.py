@@ -99,6 +99,7 @@ class VarConfig:
     cond_drop_rate: float = 0.1
     shared_aln: bool = False        # N4: one SharedAdaLin for all blocks + per-block ada_gss (control_var.py:120, basic_var.py:194-205)
     type_pos: bool = False          # N4: type_embed added per control / image half (control_var.py:99-117,423,482,623)
+    bidirectional: bool = False     # N4: image-first order allowed (mask_first=False: first two tokens and type ids swapped; control_var.py:403-407,587,624)
     sa_block: bool = False          # N4: aln < 0 -> SABlock (affine LayerNorms, no adaLN; basic_var.py:128-176) + head = Sequential(LN, Linear)
     layer_scale: float = -1.0       # SABlock only: >= 0 -> learned per-channel gamma1 / gamma2 (basic_var.py:145-149)
 

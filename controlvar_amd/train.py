@@ -259,9 +259,9 @@ class TrainEngine:
     # ---------------------------------------------------------------- forward + backward
     @torch.no_grad()
     def forward_backward(self, label_B: torch.Tensor, x_wo_first: torch.Tensor, cond_type: Optional[torch.Tensor], targets: torch.Tensor,
-                         ignore_mask: Optional[torch.Tensor] = None, drop_seed: Optional[int] = None):
+                         ignore_mask: Optional[torch.Tensor] = None, drop_seed: Optional[int] = None, mask_first: bool = True):
         """-> (loss scalar tensor, per-token loss (B*L,)); gradients land in self.grads() (overwritten, not accumulated)."""
-        self.forward_train(label_B, x_wo_first, cond_type, drop_seed)
+        self.forward_train(label_B, x_wo_first, cond_type, drop_seed, mask_first)
         dev = self.var.device
         M, V = self.M, self.cfg.vocab
         tg = targets.to(device=dev, dtype=torch.int32).contiguous().view(-1)
@@ -276,7 +276,8 @@ class TrainEngine:
         return loss, self.loss_tok
 
     @torch.no_grad()
-    def forward_train(self, label_B: torch.Tensor, x_wo_first: torch.Tensor, cond_type: Optional[torch.Tensor], drop_seed: Optional[int] = None):
+    def forward_train(self, label_B: torch.Tensor, x_wo_first: torch.Tensor, cond_type: Optional[torch.Tensor], drop_seed: Optional[int] = None,
+                      mask_first: bool = True):
         """teacher-forced forward that keeps every block's activations; returns logits (B*L, V) fp32"""
         cfg, var = self.cfg, self.var
         P = var._pack()
@@ -312,9 +313,11 @@ class TrainEngine:
         # ---- forward
         x0 = self.Xs[0]
         cond = torch.empty(B, C, device=dev, dtype=torch.float32)
-        ops.first_tokens(P['class_emb'], P['cond_embed'], labels, types, P['pos_start'], P['lvl_pos_fwd'], x0, cond, B, fl, C, L)
+        mask_first = self._mask_first = bool(mask_first) or cfg.mask_factor != 2
+        table = P['lvl_pos_fwd'] if mask_first else P['lvl_pos_fwd_']
+        var._first_tokens(P, labels, types, x0, cond, B, L, table, mask_first)
         tok = x_wo_first.to(device=dev, dtype=torch.float32).contiguous()
-        ops.word_embed(tok, P['w_we'], P['b_we'], P['lvl_pos_fwd'], x0, B, 1, L - fl, cfg.cvae, C, L, fl, lvl_off=fl)
+        ops.word_embed(tok, P['w_we'], P['b_we'], table, x0, B, 1, L - fl, cfg.cvae, C, L, fl, lvl_off=fl)
         cs = torch.empty(B, C, device=dev, dtype=T)
         ops.silu_cast(cond, cs)
         ada = torch.empty(B, n_ada, device=dev, dtype=torch.float32)
@@ -434,7 +437,7 @@ class TrainEngine:
         if cfg.type_pos:            # type_1L: first (control) half of every scale has id 1, the image half id 0 (control_var.py:103-108)
             for k, (b0, e0) in enumerate(zip(py.begin, py.end)):
                 half = (e0 - b0) // 2
-                for tid, r0 in ((1, b0), (0, b0 + half)):
+                for tid, r0 in (((1, b0), (0, b0 + half)) if self._mask_first else ((0, b0), (1, b0 + half))):
                     ops.colsum(Gm, C, Gm, half, C, ws, accumulate=(k > 0), a_off=mo['pos'][0] + r0 * C, out_off=mo['type'][0] + tid * C)
         Gm[mo['pos_start'][0]:mo['pos_start'][0] + fl * C].copy_(Gm[mo['pos'][0]:mo['pos'][0] + fl * C])
         Mt = B * (L - fl)
@@ -444,10 +447,11 @@ class TrainEngine:
         Gm[cls_o:cls_o + mo['class_emb'][1]].zero_()
         Gm[cnd_o:cnd_o + mo['cond_embed'][1]].zero_()
         g_class = Gm[cls_o:cls_o + mo['class_emb'][1]]
-        ops.scatter_add_rows(self.dX, L * C, labels, g_class, B, C, src_off=(fl - 1) * C)     # sos row (position first_l-1 holds the class token)
+        sos_row = (fl - 1) if self._mask_first else 0                 # position of the class token; image first: [sos, cond_token]
+        ops.scatter_add_rows(self.dX, L * C, labels, g_class, B, C, src_off=sos_row * C)
         ops.scatter_add_rows(dcond, C, labels, g_class, B, C)
         if cfg.mask_factor == 2:
-            ops.scatter_add_rows(self.dX, L * C, types, Gm[cnd_o:cnd_o + mo['cond_embed'][1]], B, C, src_off=0)
+            ops.scatter_add_rows(self.dX, L * C, types, Gm[cnd_o:cnd_o + mo['cond_embed'][1]], B, C, src_off=(1 - sos_row) * C)
         if self.reducer is not None:
             self.reducer.ready(depth + 1)
 
@@ -610,30 +614,37 @@ class Trainer:
         self._reducer_for = None
 
     @torch.no_grad()
-    def tokenize(self, images: torch.Tensor, masks: torch.Tensor):
-        """frozen tokenizer + 'interleave_append' (mask first): train_control_var_hpu.py:157-204"""
+    def tokenize(self, images: torch.Tensor, masks: torch.Tensor, mask_first: bool = True):
+        """frozen tokenizer + 'interleave_append' (mask first unless bidirectional drew image first): train_control_var_hpu.py:157-204"""
         mi = self.vae.img_to_idxBl(masks); mh = self.vae.idxBl_to_h(mi)
         ii = self.vae.img_to_idxBl(images); ih = self.vae.idxBl_to_h(ii)
+        if not mask_first:
+            mi, ii, mh, ih = ii, mi, ih, mh
         labels = torch.cat([torch.cat((a, b), 1) for a, b in zip(mi, ii)], dim=1)
         x = torch.cat([torch.cat((a, b), 1) for a, b in zip(mh, ih)], dim=1)
         return x, labels
 
     @torch.no_grad()
-    def step(self, images, masks, cls, types, ignore_mask=None, drop_seed=None) -> Dict[str, object]:
+    def step(self, images, masks, cls, types, ignore_mask=None, drop_seed=None, mask_first: Optional[bool] = None) -> Dict[str, object]:
+        """mask_first=None draws the order as the reference does (image first with probability 1/2 when the model is bidirectional,
+        python `random`, train_control_var_hpu.py:192-199); pass the matching ``ignore_mask`` / ``ignore_mask_`` (:234)."""
+        if mask_first is None:
+            import random
+            mask_first = not (getattr(self.var, 'bidirectional', False) and random.random() < 0.5)
         s = self.sched
         _, max_lr, _, max_wd = lr_wd_annealing(s['sche'], self.opt, s['peak_lr'], s['wd'], s['wd_end'], self.it, s['wp_it'], s['max_it'], wp0=s['wp0'], wpe=s['wpe'])
-        x, labels = self.tokenize(images, masks)
+        x, labels = self.tokenize(images, masks, mask_first)
         self.engine._setup(x.shape[0])
         if self.world > 1 and self._reducer_for is not self.engine.buckets:
             self.engine.reducer = BucketReducer(self.engine.buckets)
             self._reducer_for = self.engine.buckets
-        loss, _ = self.engine.forward_backward(cls, x, types, labels, ignore_mask, drop_seed)
+        loss, _ = self.engine.forward_backward(cls, x, types, labels, ignore_mask, drop_seed, mask_first)
         if self.engine.reducer is not None:
             self.engine.reducer.wait()
         norm_coef = self.opt.step(self.engine.grads(), self.clip, self.world)
         self.engine._transposed_weights()
         self.it += 1
-        return dict(loss=loss, grad_norm=norm_coef[0], clip_coef=norm_coef[1], lr=max_lr, wd=max_wd)
+        return dict(loss=loss, grad_norm=norm_coef[0], clip_coef=norm_coef[1], lr=max_lr, wd=max_wd, mask_first=mask_first)
 
 
 class _TeacherForcedFn(torch.autograd.Function):
@@ -642,8 +653,8 @@ class _TeacherForcedFn(torch.autograd.Function):
     hand-written kernels and hands one gradient per parameter back to autograd."""
 
     @staticmethod
-    def forward(ctx, engine, label_B, x, cond_type, *params):
-        logits = engine.forward_train(label_B, x, cond_type)
+    def forward(ctx, engine, label_B, x, cond_type, mask_first, *params):
+        logits = engine.forward_train(label_B, x, cond_type, None, mask_first)
         ctx.engine = engine
         B = x.shape[0]
         return logits.view(B, -1, logits.shape[-1]).clone()
@@ -654,11 +665,11 @@ class _TeacherForcedFn(torch.autograd.Function):
         eng.dlogits.copy_(dlogits.reshape(eng.M, -1))
         eng.backward()
         g = eng.grads()
-        return (None, None, None, None) + tuple(g[n].clone() for n, _ in eng.var.named_parameters())
+        return (None, None, None, None, None) + tuple(g[n].clone() for n, _ in eng.var.named_parameters())
 
 
-def teacher_forced_with_grad(var, label_B, x, cond_type):
+def teacher_forced_with_grad(var, label_B, x, cond_type, mask_first: bool = True):
     eng = getattr(var, '_train_engine', None)
     if eng is None:
         eng = var._train_engine = TrainEngine(var, drop_path=True)
-    return _TeacherForcedFn.apply(eng, label_B, x, cond_type, *[p for _, p in var.named_parameters()])
+    return _TeacherForcedFn.apply(eng, label_B, x, cond_type, mask_first, *[p for _, p in var.named_parameters()])

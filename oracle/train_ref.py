@@ -22,10 +22,10 @@ def trainable_keys(cfg: VarConfig) -> List[str]:
 
 
 def loss_and_grads(sd: SD, cfg: VarConfig, cls: torch.Tensor, x_wo_first: torch.Tensor, cond_type: Optional[torch.Tensor],
-                   targets: torch.Tensor, ignore_mask: Optional[torch.Tensor] = None, prec=var_ref.FP32):
+                   targets: torch.Tensor, ignore_mask: Optional[torch.Tensor] = None, prec=var_ref.FP32, mask_first: bool = True):
     """-> (loss, per-token loss (B*L,), {key: grad}) with the reduction of train_control_var_hpu.py:228-239."""
     leaf = {k: (v.detach().clone().requires_grad_(True) if k in set(trainable_keys(cfg)) else v) for k, v in sd.items()}
-    logits = var_ref.forward_logits(leaf, cfg, cls, x_wo_first, cond_type, prec)
+    logits = var_ref.forward_logits(leaf, cfg, cls, x_wo_first, cond_type, prec, mask_first)
     loss_tok = F.cross_entropy(logits.view(-1, logits.size(-1)), targets.view(-1), reduction='none')
     if ignore_mask is not None:
         m = ignore_mask.view(-1).float()

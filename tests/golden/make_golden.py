@@ -69,7 +69,8 @@ def make_cvar(vae, cfg: VarConfig, seed=0):
         else:
             m = quiet(build_control_var, vae, depth=cfg.depth, patch_nums=PN, mask_type='interleave_append' if cfg.mask_factor == 2 else 'replace',
                       cond_drop_rate=0.0, multi_cond=cfg.multi_cond, flash_if_available=False, fused_if_available=False,
-                      shared_aln=cfg.shared_aln, type_pos=cfg.type_pos, aln=-1 if cfg.sa_block else 1, layer_scale=cfg.layer_scale)
+                      shared_aln=cfg.shared_aln, type_pos=cfg.type_pos, aln=-1 if cfg.sa_block else 1, layer_scale=cfg.layer_scale,
+                      bidirectional=cfg.bidirectional)
     else:
         m = quiet(build_var, vae, depth=cfg.depth, patch_nums=PN, flash_if_available=False, fused_if_available=False, shared_aln=cfg.shared_aln)
         m.cond_drop_rate = 0.0
@@ -294,7 +295,27 @@ def case_lr():
     save('lr_lin0', table=np.array(rows, dtype=np.float64), peak_lr=4e-5, wd=0.08, wd_end=0.08, wp_it=wp_it, max_it=max_it, wp0=0.005, wpe=0.01)
 
 
-def case_train_step(cfg=None, tag='d2', wseed=0):
+def case_bidirectional():
+    """bidirectional=True (+ type_pos so that type_1L_ is exercised).  forward(mask_first=False) and one
+    autoregressive_infer_cfg whose python-`random` draw (random.seed(2) -> 0.956 >= 0.5) selects the image-first order."""
+    import random
+    vae = make_vae(32)
+    cfg = VarConfig(depth=2, bidirectional=True, type_pos=True)
+    m = make_cvar(vae, cfg, seed=9)
+    g = torch.Generator().manual_seed(24)
+    x = torch.randn(2, cfg.pyramid.L - cfg.pyramid.first_l, 32, generator=g)
+    labels, types = torch.tensor([11, 640]), torch.tensor([1, 2])
+    with torch.no_grad():
+        logits = m(labels, x, types, False)
+    t2 = logits.topk(2, dim=-1).values
+    save('forward_d2b', keys=np.array(list(m.state_dict().keys())), labels=labels, types=types, logits_sample=logits[:, ::9, ::31].contiguous(),
+         argmax=logits.argmax(-1).to(torch.int16), margin=(t2[..., 0] - t2[..., 1]), lsum=logits.double().sum(-1).float())
+    random.seed(2)
+    r = _run_generate(m, ref_cv, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]))
+    save('gen_d2b_b2', **r)
+
+
+def case_train_step(cfg=None, tag='d2', wseed=0, mask_first=True):
     """A20: one training step of the reference on a depth-2 ControlVAR + tiny VQVAE (train_control_var_hpu.py:157-250):
     tokenise control + image, interleave (mask first), teacher-forced forward, CE mean, backward, clip 2.0, AdamW with
     filter_params groups and lr_wd_annealing('lin0').  Dropouts off (cond_drop_rate=0, eval-mode DropPath)."""
@@ -312,11 +333,15 @@ def case_train_step(cfg=None, tag='d2', wseed=0):
     with torch.no_grad():
         mask_ids = vae.img_to_idxBl(masks, v_patch_nums=PN); mask_h = vae.idxBl_to_h(mask_ids)
         img_ids = vae.img_to_idxBl(images, v_patch_nums=PN); img_h = vae.idxBl_to_h(img_ids)
-    labels_list = list(chain.from_iterable(zip(mask_ids, img_ids)))
-    h_list = list(chain.from_iterable(zip(mask_h, img_h)))
+    if mask_first:
+        labels_list = list(chain.from_iterable(zip(mask_ids, img_ids)))
+        h_list = list(chain.from_iterable(zip(mask_h, img_h)))
+    else:                                             # train_control_var_hpu.py:192-195 (bidirectional, image first)
+        labels_list = list(chain.from_iterable(zip(img_ids, mask_ids)))
+        h_list = list(chain.from_iterable(zip(img_h, mask_h)))
     x = torch.cat(h_list, dim=1)
     labels = torch.cat(labels_list, dim=1)
-    logits = m(cls, x, types, True)
+    logits = m(cls, x, types, mask_first)
     loss_tok = torch.nn.CrossEntropyLoss(reduction='none')(logits.view(-1, logits.size(-1)), labels.view(-1))
     loss = loss_tok.mean()
     loss.backward()
@@ -494,6 +519,8 @@ CASES = {
     'checkpoint': case_checkpoint,
     'preprocess': case_preprocess,
     'variants': case_variants,
+    'bidirectional': case_bidirectional,
+    'train_bidirectional': lambda: case_train_step(VarConfig(depth=2, bidirectional=True, type_pos=True), 'd2b', 9, mask_first=False),
     'sa_block': case_sa_block,
     'train_sa_block': lambda: case_train_step(VarConfig(depth=2, sa_block=True, layer_scale=0.1), 'd2sa', 7),
     'train_variants': lambda: case_train_step(VarConfig(depth=2, shared_aln=True, type_pos=True), 'd2v', 5),

@@ -23,24 +23,27 @@ def make(cfg, dtype, dev, seed=0):
     if cfg.control:
         m = models.ControlVAR(vae, depth=cfg.depth, embed_dim=cfg.C, num_heads=cfg.H, mask_factor=2, multi_cond=True, patch_nums=PN,
                               compute_dtype=dtype, cond_drop_rate=0.0, shared_aln=cfg.shared_aln, type_pos=cfg.type_pos,
-                              aln=-1 if cfg.sa_block else 1, layer_scale=cfg.layer_scale, init_seed=seed)
+                              aln=-1 if cfg.sa_block else 1, layer_scale=cfg.layer_scale, bidirectional=cfg.bidirectional, init_seed=seed)
     else:
         m = models.VAR(vae, depth=cfg.depth, embed_dim=cfg.C, num_heads=cfg.H, patch_nums=PN, compute_dtype=dtype, cond_drop_rate=0.0,
                        shared_aln=cfg.shared_aln, init_seed=seed)
     return vae, m.to(dev)
 
 
-def tokenize(vae, dev):
+def tokenize(vae, dev, mask_first=True):
     images, masks = synth_images(2, 256, seed=6).to(dev), synth_images(2, 256, seed=7).to(dev)
     mi = vae.img_to_idxBl(masks); mh = vae.idxBl_to_h(mi)
     ii = vae.img_to_idxBl(images); ih = vae.idxBl_to_h(ii)
+    if not mask_first:
+        mi, ii, mh, ih = ii, mi, ih, mh
     labels = torch.cat([torch.cat((a, b), 1) for a, b in zip(mi, ii)], dim=1)
     x = torch.cat([torch.cat((a, b), 1) for a, b in zip(mh, ih)], dim=1)
     return x, labels
 
 
 FIXTURE_CASES = {'d2': (VarConfig(depth=2), 0), 'd2v': (VarConfig(depth=2, shared_aln=True, type_pos=True), 5),
-                 'd2sa': (VarConfig(depth=2, sa_block=True, layer_scale=0.1), 7)}
+                 'd2sa': (VarConfig(depth=2, sa_block=True, layer_scale=0.1), 7),
+                 'd2b': (VarConfig(depth=2, bidirectional=True, type_pos=True), 9)}        # recorded image first (mask_first=False)
 
 
 @pytest.mark.parametrize('tag', list(FIXTURE_CASES))
@@ -50,10 +53,10 @@ def test_training_step_fp32_matches_reference_fixture(gpu_device, tag):
     g = golden(f'train_step_{tag}')
     cfg, wseed = FIXTURE_CASES[tag]
     vae, m = make(cfg, torch.float32, gpu_device, seed=wseed)
-    x, labels = tokenize(vae, gpu_device)
+    x, labels = tokenize(vae, gpu_device, tag != 'd2b')
     assert np.array_equal(labels.cpu().numpy(), g['labels'].astype(np.int64))
     eng = T.TrainEngine(m, drop_path=False)
-    loss, loss_tok = eng.forward_backward(torch.tensor([17, 403]), x, torch.tensor([2, 0]), labels)
+    loss, loss_tok = eng.forward_backward(torch.tensor([17, 403]), x, torch.tensor([2, 0]), labels, mask_first=tag != 'd2b')
     assert abs(loss.item() - float(g['loss'])) < 2e-5
     assert (loss_tok.cpu()[::17] - t(g['loss_tok'])).abs().max() < 2e-4
     grads = eng.grads()
@@ -134,7 +137,7 @@ def test_trainer_step_matches_reference_adamw(gpu_device, tag):
                    wp0=0.005, wpe=0.01, drop_path=False)
     tr.it = 7
     images, masks = synth_images(2, 256, seed=6).to(gpu_device), synth_images(2, 256, seed=7).to(gpu_device)
-    out = tr.step(images, masks, torch.tensor([17, 403]), torch.tensor([2, 0]))
+    out = tr.step(images, masks, torch.tensor([17, 403]), torch.tensor([2, 0]), mask_first=tag != 'd2b')
     assert abs(out['loss'].item() - float(g['loss'])) < 2e-5
     assert abs(out['grad_norm'].item() - float(g['total_norm'])) < 1e-3 * float(g['total_norm'])
     assert abs(out['lr'] - g['lrs'][1]) < 1e-12 and abs(out['wd'] - g['lrs'][3]) < 1e-12

@@ -131,12 +131,12 @@ def test_forward_logits(tag, mf):
 
 
 def _gen_check(name, cfg, B, labels, cfg_scale, cond_type=None, four=False, teach=None, top_k=1, top_p=0.0, seed=0,
-               vae_ch=32, img_tol=5e-4, wseed=0):
+               vae_ch=32, img_tol=5e-4, wseed=0, **kw0):
     g = golden(name)
     sdv = synth_vae_state(VaeConfig(ch=vae_ch))
     msq = MSQuant(sdv, PN, phi_index_map(10))
     sd = synth_var_state(cfg, wseed)
-    kw = {}
+    kw = dict(kw0)
     if teach is not None:
         kw[teach] = split_ids(g['c_ids'].astype(np.int64))
     trace = {}
@@ -261,3 +261,22 @@ def test_sa_block_forward_logits_and_key_order(tag, cfg, seed):
 
 def test_sa_block_generate():
     _gen_check('gen_d2sa_b2', SA, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]), wseed=7)
+
+
+# ------------------------------------------------------------------------------ bidirectional (image first)
+BIDI = VarConfig(depth=2, bidirectional=True, type_pos=True)
+
+
+def test_bidirectional_image_first_forward_and_generate():
+    from controlvar_amd.spec import var_state_shapes
+    g = golden('forward_d2b')
+    assert list(var_state_shapes(BIDI)) == [str(k) for k in g['keys']]
+    sd = synth_var_state(BIDI, 9)
+    gen = torch.Generator().manual_seed(24)
+    x = torch.randn(2, BIDI.pyramid.L - BIDI.pyramid.first_l, 32, generator=gen)
+    with torch.no_grad():
+        logits = var_ref.forward_logits(sd, BIDI, t(g['labels']), x, t(g['types']), mask_first=False)
+    assert (logits[:, ::9, ::31] - t(g['logits_sample'])).abs().max() < 1e-4
+    mism = logits.argmax(-1).numpy() != g['argmax'].astype(np.int64)
+    assert mism.sum() == 0 or g['margin'][mism].max() < 1e-4
+    _gen_check('gen_d2b_b2', BIDI, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]), wseed=9, mask_first=False)

@@ -26,20 +26,23 @@ def test_lr_schedule_matches_reference_table():
         assert abs(lr - max_lr) < 1e-15 and abs(wd - max_wd) < 1e-15
 
 
-def build_inputs():
+def build_inputs(mask_first=True):
     sdv = synth_vae_state(VaeConfig(ch=32))
     msq = MSQuant(sdv, PN, phi_index_map(10))
     images, masks = synth_images(2, 256, seed=6), synth_images(2, 256, seed=7)
     with torch.no_grad():
         mi = vqvae_ref.img_to_idxBl(sdv, msq, masks); mh = msq.idx_to_var_input(mi)
         ii = vqvae_ref.img_to_idxBl(sdv, msq, images); ih = msq.idx_to_var_input(ii)
+    if not mask_first:                                # train_control_var_hpu.py:192-195: image first
+        mi, ii, mh, ih = ii, mi, ih, mh
     labels = torch.cat([torch.cat((a, b), 1) for a, b in zip(mi, ii)], dim=1)
     x = torch.cat([torch.cat((a, b), 1) for a, b in zip(mh, ih)], dim=1)
     return x, labels
 
 
 TRAIN_CASES = {'d2': (VarConfig(depth=2), 0), 'd2v': (VarConfig(depth=2, shared_aln=True, type_pos=True), 5),
-               'd2sa': (VarConfig(depth=2, sa_block=True, layer_scale=0.1), 7)}
+               'd2sa': (VarConfig(depth=2, sa_block=True, layer_scale=0.1), 7),
+               'd2b': (VarConfig(depth=2, bidirectional=True, type_pos=True), 9)}         # image first (mask_first=False)
 
 
 @pytest.mark.parametrize('tag', list(TRAIN_CASES))
@@ -48,10 +51,11 @@ def test_training_step_oracle_matches_reference(tag):
     g = golden(f'train_step_{tag}')
     cfg, wseed = TRAIN_CASES[tag]
     sd = synth_var_state(cfg, wseed)
-    x, labels = build_inputs()
+    mask_first = tag != 'd2b'
+    x, labels = build_inputs(mask_first)
     assert np.array_equal(labels.numpy(), g['labels'].astype(np.int64))
     assert (x[:, ::7] - t(g['x_sample'])).abs().max() < 2e-5
-    loss, loss_tok, grads = train_ref.loss_and_grads(sd, cfg, torch.tensor([17, 403]), x, torch.tensor([2, 0]), labels)
+    loss, loss_tok, grads = train_ref.loss_and_grads(sd, cfg, torch.tensor([17, 403]), x, torch.tensor([2, 0]), labels, mask_first=mask_first)
     assert abs(loss.item() - float(g['loss'])) < 1e-5
     assert (loss_tok[::17] - t(g['loss_tok'])).abs().max() < 1e-4
     names = [str(n) for n in g['names']]
