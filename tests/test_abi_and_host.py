@@ -128,3 +128,26 @@ def test_state_dict_roundtrip_with_module_prefix():
     wrapped = {'module.' + k: v for k, v in sd.items()}
     m.load_state_dict({k[len('module.'):]: v for k, v in wrapped.items()}, strict=True)
     assert torch.equal(m.state_dict()['blocks.0.ffn.fc1.weight'], sd['blocks.0.ffn.fc1.weight'])
+
+
+# ------------------------------------------------------------------------------ variant flags (host side)
+@pytest.mark.parametrize('fixture,kw', [('forward_d2v', dict(shared_aln=True, type_pos=True)), ('forward_d2sa', dict(aln=-1, layer_scale=0.1)),
+                                        ('forward_d2sa0', dict(aln=-1)), ('forward_d2b', dict(bidirectional=True, type_pos=True))])
+def test_variant_models_have_the_reference_state_dict_layout(fixture, kw):
+    """the module tree built from spec.var_state_shapes yields the reference's state_dict() key order for every built variant"""
+    import numpy as np
+    from controlvar_amd import models
+    keys = [str(k) for k in np.load(os.path.join(os.path.dirname(__file__), 'golden', fixture + '.npz'))['keys']]
+    vae = models.build_vae(ch=32)
+    m = models.build_control_var(vae, depth=2, mask_type='interleave_append', multi_cond=True, **kw)
+    assert list(m.state_dict().keys()) == keys
+
+
+@pytest.mark.parametrize('kw', [dict(separator=True), dict(separate_decoding=True), dict(indep=True)])
+def test_unbuilt_variant_flags_fail_loudly(kw):
+    from controlvar_amd import models
+    vae = models.build_vae(ch=32)
+    with pytest.raises(NotImplementedError):
+        models.build_control_var(vae, depth=2, mask_type='interleave_append', multi_cond=True, **kw)
+    with pytest.raises(NotImplementedError):
+        models.build_control_var(vae, depth=2, mask_type='replace', type_pos=True)
