@@ -420,3 +420,13 @@ def test_attention_randomised_sweep_with_poisoned_keys(gpu_device):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_attn.py'), '80', '5'], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_attention_backward_randomised_sweep_inside_nan_arenas(gpu_device):
+    """40 random training-attention problems (ragged block-causal level structures): the MFMA backward against the exact
+    row-wise backward of the same library, every tensor surrounded by NaN pads that must stay intact (tools/fuzz_attn_bwd.py)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'fuzz_attn_bwd.py'), '40', '3'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert '40/40 cases ok' in r.stdout
