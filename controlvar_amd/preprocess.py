@@ -103,22 +103,31 @@ def _tables_to_device(tables, device):
     return torch.from_numpy(b).to(device), torch.from_numpy(np.ascontiguousarray(k)).to(device), ksize
 
 
+def vertical_pass_first(h: int, w: int, out_h: int, out_w: int) -> bool:
+    """Pass order of ``Image.resize``: horizontal then vertical, except that Pillow 12.2 runs the vertical pass first on very
+    tall sources that shrink vertically (h > 100 * w and out_h < h).  The order matters because the intermediate image is
+    rounded to uint8.  Established against the installed Pillow (tools/fuzz_resample.py; the threshold is exact: h = 100 w
+    still goes horizontal first); no ImageNet-shaped input reaches it."""
+    return out_w != w and out_h != h and h > 100 * w and out_h < h
+
+
 def resize_u8(img, out_h: int, out_w: int, filt: str):
-    """``Image.resize((out_w, out_h), filt)`` of a uint8 HWC device tensor: horizontal pass, then vertical pass (ImagingResample)"""
+    """``Image.resize((out_w, out_h), filt)`` of a uint8 HWC device tensor: two separable passes (ImagingResample) in Pillow's order"""
     import torch
     from . import ops
     h, w, c = img.shape
     cur = img.contiguous()
-    if out_w != w:
-        b, k, ks = _tables_to_device(resample_tables(w, out_w, filt), img.device)
-        nxt = torch.empty(h, out_w, c, dtype=torch.uint8, device=img.device)
-        ops.resample_u8(cur, h, w, c, 0, out_w, b, k, ks, nxt)
-        cur, w = nxt, out_w
-    if out_h != h:
-        b, k, ks = _tables_to_device(resample_tables(h, out_h, filt), img.device)
-        nxt = torch.empty(out_h, w, c, dtype=torch.uint8, device=img.device)
-        ops.resample_u8(cur, h, w, c, 1, out_h, b, k, ks, nxt)
-        cur = nxt
+    for axis in ((1, 0) if vertical_pass_first(h, w, out_h, out_w) else (0, 1)):
+        if axis == 0 and out_w != w:
+            b, k, ks = _tables_to_device(resample_tables(w, out_w, filt), img.device)
+            nxt = torch.empty(h, out_w, c, dtype=torch.uint8, device=img.device)
+            ops.resample_u8(cur, h, w, c, 0, out_w, b, k, ks, nxt)
+            cur, w = nxt, out_w
+        elif axis == 1 and out_h != h:
+            b, k, ks = _tables_to_device(resample_tables(h, out_h, filt), img.device)
+            nxt = torch.empty(out_h, w, c, dtype=torch.uint8, device=img.device)
+            ops.resample_u8(cur, h, w, c, 1, out_h, b, k, ks, nxt)
+            cur, h = nxt, out_h
     return cur
 
 

@@ -32,12 +32,16 @@ def resample_pass(img: np.ndarray, axis: int, out: int, filt: str) -> np.ndarray
 
 
 def resize(img: np.ndarray, out_h: int, out_w: int, filt: str) -> np.ndarray:
-    """Image.resize((out_w, out_h), filt): horizontal pass first, uint8 in between (ImagingResample)"""
+    """Image.resize((out_w, out_h), filt): two passes with a uint8 image in between (ImagingResample); horizontal first
+    except for very tall shrinking sources (Pillow 12.2: h > 100 w and out_h < h - observed, see tools/fuzz_resample.py)"""
+    h, w = img.shape[:2]
     cur = img
-    if out_w != img.shape[1]:
-        cur = resample_pass(cur, 0, out_w, filt)
-    if out_h != img.shape[0]:
-        cur = resample_pass(cur, 1, out_h, filt)
+    vertical_first = out_w != w and out_h != h and h > 100 * w and out_h < h
+    for axis in ((1, 0) if vertical_first else (0, 1)):
+        if axis == 0 and out_w != w:
+            cur = resample_pass(cur, 0, out_w, filt)
+        elif axis == 1 and out_h != h:
+            cur = resample_pass(cur, 1, out_h, filt)
     return cur
 
 
