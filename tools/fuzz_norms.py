@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Randomised sweep of the normalisation kernels against torch fp32: GroupNorm(32)+SiLU over NHWC (random B / HW incl. ragged
+pixel counts / C in the VQVAE's channel set, bf16 and fp32) and the adaLN LayerNorm-modulate (random rows / sequence lengths /
+widths), inputs inside NaN-padded buffers.  usage: fuzz_norms.py [n_cases] [seed]"""
+import os
+import random
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+from controlvar_amd import ops
+
+dev = torch.device('cuda:0')
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+PAD = 2048
+
+
+def padded(t, dtype):
+    buf = torch.full((t.numel() + 2 * PAD,), float('nan'), device=dev, dtype=dtype)
+    v = buf[PAD:PAD + t.numel()].view(t.shape)
+    v.copy_(t.to(dtype))
+    return buf, v
+
+
+bad = 0
+for case in range(n_cases):
+    g = torch.Generator().manual_seed(case)
+    if case % 2 == 0:
+        dtype = rng.choice([torch.bfloat16, torch.float32])
+        B, C = rng.choice([1, 2, 5]), rng.choice([32, 64, 160, 320, 640])
+        HW = rng.choice([1, 3, 16, 100, 255, 256, 1000, 4096, 5000])
+        silu = rng.random() < 0.7
+        x = torch.randn(B, HW, C, generator=g) * rng.choice([0.2, 1.5, 6.0]) + rng.choice([0.0, 0.7, -3.0])
+        w, b = torch.randn(C, generator=g) * 0.1 + 1, torch.randn(C, generator=g) * 0.1
+        _, xd = padded(x, dtype)
+        ob, out = padded(torch.zeros_like(x), dtype)
+        ws = torch.empty(ops.groupnorm_ws_bytes(B, HW, C), device=dev, dtype=torch.uint8)
+        ops.groupnorm_silu(xd, w.to(dev), b.to(dev), out, B, HW, C, 32, 1e-6, silu, ws)
+        ref = F.group_norm(xd.float().cpu().permute(0, 2, 1), 32, w, b, eps=1e-6).permute(0, 2, 1)
+        ref = F.silu(ref) if silu else ref
+        got = out.float().cpu()
+        tol = 2e-2 if dtype == torch.bfloat16 else 1e-4
+        ok = bool(torch.isfinite(got).all()) and bool(((got - ref).abs() <= tol * (ref.abs() + 1)).all()) and bool(torch.isnan(ob[:PAD]).all() and torch.isnan(ob[-PAD:]).all())
+        desc = dict(kind='gn', dtype=str(dtype), B=B, HW=HW, C=C, silu=silu)
+    else:
+        out_dtype = rng.choice([torch.bfloat16, torch.float32])
+        R, l, C = rng.choice([1, 2, 7]), rng.choice([1, 2, 9, 50, 338, 512]), rng.choice([128, 768, 1024, 1536, 1920])
+        x = torch.randn(R * l, C, generator=g) * rng.choice([0.3, 2.0, 20.0]) + rng.choice([0.0, 0.5])
+        ada = torch.randn(R, 6 * C, generator=g) * 0.3
+        _, xd = padded(x, torch.float32)
+        ob, out = padded(torch.zeros(R * l, C), out_dtype)
+        ops.ln_modulate(xd, ada.to(dev), 2 * C, 4 * C, 6 * C, l, out, R * l, C, 1e-6)
+        sc = ada[:, 2 * C:3 * C].repeat_interleave(l, 0); sh = ada[:, 4 * C:5 * C].repeat_interleave(l, 0)
+        ref = F.layer_norm(x, (C,), eps=1e-6) * (1 + sc) + sh
+        got = out.float().cpu()
+        tol = 1e-2 if out_dtype == torch.bfloat16 else 1e-4
+        ok = bool(torch.isfinite(got).all()) and bool(((got - ref).abs() <= tol * (ref.abs() + 1)).all()) and bool(torch.isnan(ob[:PAD]).all() and torch.isnan(ob[-PAD:]).all())
+        desc = dict(kind='ln', out=str(out_dtype), R=R, l=l, C=C)
+    if not ok:
+        bad += 1
+        print('FAIL', case, desc, 'max err', (got - ref).abs().max().item(), flush=True)
+print(f'{n_cases - bad}/{n_cases} cases ok')
+sys.exit(1 if bad else 0)
