@@ -604,6 +604,8 @@ class ControlVAR(nn.Module):
                   force_idx=None, trace: bool = False):
         if more_smooth:
             raise NotImplementedError('more_smooth (Gumbel visualisation path) is not built (SURVEY.md 8f N4)')
+        if top_k > self.cfg.vocab:                     # helpers.py:8-10: torch.topk raises on k > V; top_k <= 0 means no top-k filter
+            raise RuntimeError(f'selected index k out of range (top_k={top_k} > vocabulary {self.cfg.vocab})')
         seed = int(g_seed) if g_seed is not None else int(torch.empty((), dtype=torch.int64).random_().item())
         labels_all, types_all = self._prepare_rows(B, label_B, cond_type, four_way, seed)
         mask_first = True

@@ -396,3 +396,21 @@ def test_ms_encode_fast_search_equals_sequential_search_incl_ties(gpu_device):
     assert torch.equal(slow[0], fast[0]) and torch.equal(slow[1], fast[1])
     assert int(fast[0].max()) < 2048                                   # ties resolved to the first index
     assert float(slow[2].min()) == 0.0                                 # and they really were ties
+
+
+def test_sampler_argument_edges(gpu_device):
+    """top_p -> 0 and top_k = 1 are greedy; top_k = 0 / V and top_p = 1 filter nothing (same draws); top_k > V raises as torch.topk does
+    in the reference (helpers.py:8-10)."""
+    vae = make_vae(32, F32, gpu_device)
+    m = make_var(vae, VarConfig(depth=2), F32, gpu_device)
+
+    def ids(**kw):
+        m.autoregressive_infer_cfg(2, torch.tensor([3, 7]), g_seed=0, cfg=4.0, cond_type=torch.tensor([0, 1]), _trace=True, **kw)
+        return torch.cat(m.last_trace['idx'], dim=1).cpu()
+    greedy = ids(top_k=1, top_p=0.0)
+    assert torch.equal(ids(top_k=0, top_p=1e-6), greedy) and torch.equal(ids(top_k=4096, top_p=1e-7), greedy)
+    free = ids(top_k=0, top_p=0.0)
+    assert torch.equal(ids(top_k=4096, top_p=0.0), free) and torch.equal(ids(top_k=0, top_p=1.0), free) and torch.equal(ids(top_k=-1, top_p=0.0), free)
+    assert not torch.equal(free, greedy) and 0 <= int(free.min()) and int(free.max()) < 4096
+    with pytest.raises(RuntimeError):
+        ids(top_k=5000, top_p=0.0)
