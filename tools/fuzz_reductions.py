@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Randomised sweep of the training-side reductions against torch (fp64 reference): cvar_colsum (any M incl. M < 64 and huge N,
+strided input, accumulate), cvar_rowsum, and the fused cross-entropy forward+backward.  usage: fuzz_reductions.py [n_cases] [seed]"""
+import os
+import random
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+from controlvar_amd import ops
+
+dev = torch.device('cuda:0')
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+for case in range(n_cases):
+    g = torch.Generator().manual_seed(case)
+    kind = case % 3
+    if kind == 0:                                   # column sums of an (M, N) window of a wider matrix
+        M = rng.choice([1, 2, 3, 24, 63, 64, 65, 200, 4097, 43520])
+        N = rng.choice([1, 7, 128, 1000, 4608, 9216, 100000])
+        if M * N > 3e8:
+            N = 1000
+        lda = N + rng.choice([0, 0, 5, 64])
+        dtype = rng.choice([torch.float32, torch.bfloat16])
+        A = (torch.randn(M, lda, generator=g) * 2).to(dtype).to(dev)
+        acc = rng.random() < 0.3
+        out0 = torch.randn(N + 8, generator=g).to(dev)
+        out = out0.clone()
+        ws = torch.empty(64 * N + 16, device=dev)
+        ops.colsum(A, lda, out, M, N, ws, accumulate=acc, out_off=3)
+        ref = A[:, :N].double().sum(0) + (out0[3:3 + N].double() if acc else 0)
+        err = (out[3:3 + N].double() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+        untouched = torch.equal(out[:3], out0[:3]) and torch.equal(out[3 + N:], out0[3 + N:])
+        ok = err < 1e-4 and untouched                                # fp32 accumulation over up to 43520 terms
+        desc = dict(kind='colsum', M=M, N=N, lda=lda, dtype=str(dtype), acc=acc)
+    elif kind == 1:                                 # row sums of a (nrows, ncols) window
+        nrows, ncols = rng.choice([1, 5, 128, 4096, 4608]), rng.choice([1, 3, 64, 1000, 43520])
+        lda = (ncols + 7) // 8 * 8 + rng.choice([0, 8])          # rows must be 16-byte aligned (include/cvar.h); others fail loudly
+        dtype = rng.choice([torch.float32, torch.bfloat16])
+        A = (torch.randn(nrows, lda, generator=g) * 2).to(dtype).to(dev)
+        out0 = torch.randn(nrows + 4, generator=g).to(dev)
+        out = out0.clone()
+        ops.rowsum(A, lda, out, nrows, ncols, out_off=2)
+        ref = A[:, :ncols].double().sum(1)
+        err = (out[2:2 + nrows].double() - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+        ok = err < 1e-4 and torch.equal(out[:2], out0[:2])          # fp32 accumulation over up to 43520 terms and torch.equal(out[2 + nrows:], out0[2 + nrows:])
+        desc = dict(kind='rowsum', nrows=nrows, ncols=ncols, lda=lda, dtype=str(dtype))
+    else:                                           # fused CE
+        M, V = rng.choice([1, 3, 100, 2720]), 4096
+        logits = (torch.randn(M, V, generator=g) * rng.choice([1.0, 8.0, 40.0])).to(dev)
+        tg = torch.randint(0, V, (M,), generator=g).to(torch.int32).to(dev)
+        w = (torch.rand(M, generator=g) > 0.3).float().to(dev) if rng.random() < 0.5 else None
+        gscale = rng.choice([1.0, 1.0 / M, 0.37])
+        odt = rng.choice([torch.float32, torch.bfloat16])
+        loss = torch.empty(M, device=dev); dl = torch.empty(M, V, device=dev, dtype=odt)
+        ops.ce_fwd_bwd(logits, tg, w, gscale, loss, dl, M, V)
+        lref = F.cross_entropy(logits.double(), tg.long(), reduction='none')
+        p = logits.double().softmax(-1); p[torch.arange(M), tg.long()] -= 1
+        dref = p * ((w.double() if w is not None else 1.0) * gscale).reshape(-1, 1) if w is not None else p * gscale
+        e1 = (loss.double() - lref).abs().max().item() / max(1.0, lref.abs().max().item())
+        e2 = (dl.double() - dref).abs().max().item() / max(1e-6, dref.abs().max().item())
+        ok = e1 < 1e-5 and e2 < (1e-5 if odt == torch.float32 else 1e-2)
+        err = max(e1, e2)
+        desc = dict(kind='ce', M=M, gscale=gscale, weighted=w is not None, out=str(odt))
+    if not ok:
+        bad += 1
+        print('FAIL', case, desc, 'err', err, flush=True)
+print(f'{n_cases - bad}/{n_cases} cases ok')
+sys.exit(1 if bad else 0)
