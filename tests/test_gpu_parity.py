@@ -78,6 +78,22 @@ def test_ms_encode_bit_exact_on_reference_features(gpu_device, tag, ch):
         assert (mg.cpu() - torch.cat(margins, 1)).abs().max() < 1e-3
 
 
+@pytest.mark.parametrize('B,amp,seed', [(1, 0.5, 1), (3, 1.0, 2), (5, 3.0, 3)])
+def test_ms_encode_random_features_against_oracle(gpu_device, B, amp, seed):
+    """the quantizer on random feature maps (odd batch sizes, small and large amplitudes): ids equal to the pinned oracle's wherever
+    the oracle's best-vs-second margin is not a rounding tie, for the default (fast search) and the margin-reporting path"""
+    vae = make_vae(32, F32, gpu_device)
+    sd = synth_vae_state(VaeConfig(ch=32))
+    gen = torch.Generator().manual_seed(seed)
+    f = torch.randn(B, 32, 16, 16, generator=gen) * amp
+    ids_ref, margins = MSQuant(sd, PN, phi_index_map(10)).f_to_idx(f, return_margins=True)
+    ref, mref = torch.cat(ids_ref, 1).numpy(), torch.cat(margins, 1).numpy()
+    fd = f.to(gpu_device)
+    for want_margin in (False, True):
+        idx = vae._ms_encode(fd, want_fhat=True, want_margin=want_margin)[0]
+        assert_ids(idx.cpu(), ref, mref, 1e-4 * max(1.0, amp * amp), f'ms_encode B={B} margin path={want_margin}')
+
+
 def test_next_input_all_scales(gpu_device):
     """A14: get_next_autoregressive_input for every scale against the reference fixture (<= 2e-5)."""
     g = golden('next_input')
