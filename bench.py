@@ -43,10 +43,40 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-depth', type=int, default=0, help='depth of the CPU baseline model (0 = same as --depth)')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
+                    help="infer (default, the BASELINE headline metric) | train: BASELINE config 3 - the d24 data-parallel training step, gradient "
+                         "all-reduce over RCCL overlapped with the backward; reports samples/s and the exposed communication share")
+    ap.add_argument('--train-batch', type=int, default=32, help='--mode train: samples per GPU per step (global 256 = 8 x 32)')
     return ap.parse_args()
 
 
-def cpu_baseline(depth: int, seed: int = 0, budget_s: float = 20.0, max_threads: int = 32):
+def physical_cores() -> int:
+    """physical cores of the host (BASELINE.md section 4 asks for the CPU path on the physical cores): unique (package, core) pairs of
+    /proc/cpuinfo restricted to the CPUs this process may run on; falls back to the affinity count"""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    try:
+        cores, cur = set(), {}
+        for line in open('/proc/cpuinfo'):
+            if ':' in line:
+                k, v = (x.strip() for x in line.split(':', 1))
+                cur[k] = v
+            elif not line.strip() and cur:
+                if int(cur.get('processor', -1)) in allowed:
+                    cores.add((cur.get('physical id', '0'), cur.get('core id', cur.get('processor'))))
+                cur = {}
+        if cur and int(cur.get('processor', -1)) in allowed:
+            cores.add((cur.get('physical id', '0'), cur.get('core id', cur.get('processor'))))
+        if cores:
+            return len(cores)
+    except Exception:
+        pass
+    return max(1, len(allowed))
+
+
+def cpu_baseline(depth: int, seed: int = 0, budget_s: float = 20.0, max_threads: int = 0):
     """The oracle (kind 'port': own restatement, pinned to the reference by tests/golden) on the host cores.
     Sample: ONE d{depth} generation with B=1 (2 CFG rows), fp32, greedy - run scale by scale until `budget_s` seconds
     are spent; the rate is extrapolated by the share of the sample's algorithmic FLOPs completed (both VAE decodes
@@ -55,7 +85,9 @@ def cpu_baseline(depth: int, seed: int = 0, budget_s: float = 20.0, max_threads:
     from controlvar_amd.synth import synth_vae_state, synth_var_state
     from oracle import var_ref
     from oracle.vqvae_ref import MSQuant
-    cores = min(os.cpu_count() or 1, max_threads)
+    cores = physical_cores()
+    if max_threads:
+        cores = min(cores, max_threads)
     torch.set_num_threads(cores)
     cfg = VarConfig(depth=depth)
     py, C, V = cfg.pyramid, cfg.C, cfg.vocab
@@ -81,11 +113,64 @@ def cpu_baseline(depth: int, seed: int = 0, budget_s: float = 20.0, max_threads:
     return dict(value=(gf / total) / dt, unit='images/s', cores=cores, kind='port',
                 sample=f'd{depth} B=1 (2 CFG rows) fp32 torch-CPU oracle, greedy: {done["n"]}/10 scales'
                        f'{" + 2 VAE decodes" if done["n"] == 10 else ""} = {100 * gf / total:.1f}% of the per-image FLOPs in {dt:.1f}s '
-                       f'on {cores} threads (rate extrapolated by FLOP share)')
+                       f'on {cores} threads = physical cores of the host (rate extrapolated by FLOP share)')
+
+
+def main_train(a):
+    """BASELINE config 3: d24 joint image+control training, synthetic ImageNetC-shaped batch of --train-batch samples per GPU (seeded by
+    the rank), frozen tokenizer inside the step, per-layer gradient slabs all-reduced (SUM, mean folded into AdamW) over RCCL on a side
+    stream while the backward continues.  The same K steps are timed once more with the exchange switched off; the difference is the
+    EXPOSED communication time (what the overlap did not hide)."""
+    from controlvar_amd.launcher import dist_env, init_dist, sharded_timed_run, synthetic_rank_batch
+    rank, local, world = dist_env()
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    init_dist('nccl', dev)
+    from controlvar_amd import models, ops, train as T, _lib
+    from controlvar_amd.spec import VarConfig, algorithmic_gflop_per_row
+    _lib.load()
+    B = a.train_batch
+    Tt = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
+    vae = models.build_vae(ch=160, compute_dtype=Tt).to(dev)
+    var = models.build_control_var(vae, depth=a.depth, mask_type='interleave_append', multi_cond=True, compute_dtype=Tt).to(dev)
+    tr = T.Trainer(var, vae, peak_lr=8e-5 * (B * world) / 512, weight_decay=0.08, sche='lin0', warmup_it=10, max_it=10000, clip=2.0, train_mode=True)
+    images, masks, cls, types = synthetic_rank_batch(B, rank, dev)
+    last = {}
+
+    def step(i):
+        last['out'] = tr.step(images, masks, cls, types, drop_seed=1000 * rank + i)
+
+    _, dt = sharded_timed_run(step, a.steps, a.warmup, B, sync=torch.cuda.synchronize)
+    exposed = None
+    if world > 1:
+        tr.comm = False
+        _, dt_nocomm = sharded_timed_run(step, a.steps, 1, B, sync=torch.cuda.synchronize)
+        tr.comm = True
+        exposed = max(0.0, (dt - dt_nocomm) / dt)
+    if rank == 0:
+        fl = algorithmic_gflop_per_row(VarConfig(depth=a.depth), n_ada=1)
+        per_sample_tf = (3 * fl['total'] + 2 * 215.4) / 1e3                   # fwd + 2x bwd + two frozen tokenizer encodes (SURVEY.md 8d)
+        red = tr.engine.reducer if tr.engine.reducer is not None else getattr(tr, '_reducer', None)
+        out = {'metric': 'training samples/sec (d%d joint image+control, DP all-reduce)' % a.depth, 'value': round(world * B * a.steps / dt, 2),
+               'unit': 'samples/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 2),
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+               'config': {'workload': f'ControlVAR d{a.depth} training step (tokenise image+control, forward, CE, backward, clip 2.0, AdamW), '
+                                      f'synthetic ImageNetC-shaped batch', 'batch_per_gpu': B, 'global_batch': B * world, 'seq_len': 1360,
+                          'parallelism': f'dp{world} (per-layer gradient slabs, RCCL all-reduce on a side stream)'},
+               'algorithmic_tflop_per_sample': round(per_sample_tf, 3), 'end_to_end_tflops_per_gpu': round(per_sample_tf * B * a.steps / dt, 1),
+               'loss': round(float(last['out']['loss']), 4), 'exposed_comm_frac': None if exposed is None else round(exposed, 4),
+               'allreduce_bytes_per_step': sum(b.numel() * 4 for b in tr.engine.buckets)}
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     a = parse()
+    if a.mode == 'train':
+        return main_train(a)
     from controlvar_amd.launcher import dist_env, init_dist, sharded_timed_run
     rank, local, world = dist_env()
     torch.cuda.set_device(local)

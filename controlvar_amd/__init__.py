@@ -7,7 +7,14 @@ and the pure-host modules (spec, synth) work everywhere.
 """
 from . import spec  # noqa: F401
 
-__all__ = ['VQVAE', 'VAR', 'ControlVAR', 'build_var', 'build_control_var', 'build_vae', 'spec']
+__all__ = ['VQVAE', 'VAR', 'ControlVAR', 'build_var', 'build_control_var', 'build_vae', 'spec', 'register_torch_ops']
+
+
+def register_torch_ops():
+    """Register the C-ABI kernels as ``torch.ops.cvar.*`` (controlvar_amd/torch_ops.py) and return that namespace."""
+    import torch
+    from . import torch_ops  # noqa: F401
+    return torch.ops.cvar
 
 
 def __getattr__(name):

@@ -11,7 +11,7 @@ import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CVAR_LIB') or os.path.join(HERE, 'libcvar_hip.so')      # CVAR_LIB: A/B runs against another build
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 CVAR_F32, CVAR_BF16 = 0, 1
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_GRAD = 0, 1, 2
@@ -36,6 +36,7 @@ class GemmDesc(C.Structure):
         ('C', c_p), ('out_dtype', c_i), ('ldc', c_l),
         ('remap_l', c_i), ('remap_L', c_i), ('remap_off', c_i),
         ('pre_act', c_p), ('aux', c_p), ('gate_scale', c_p),
+        ('ws', c_p), ('ws_bytes', c_l), ('tile_cfg', c_i), ('stagger', c_i),
     ]
 
 
@@ -50,7 +51,6 @@ SIGNATURES = {
     'cvar_adamw_multi': (c_i, [c_p, c_i, C.POINTER(c_f), C.POINTER(c_f), c_i, c_f, c_f, c_f, c_i, c_p, c_f, c_p]),
     'cvar_rle_paint': (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     'cvar_ignore_mask': (c_i, [c_p, c_i, c_i, c_i, C.POINTER(c_i), c_i, c_i, c_i, c_p, c_i, c_p]),
-    'cvar_gemm_set_workspace': (c_i, [c_p, c_l]),
     'cvar_ln_modulate': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p, c_i, c_i, c_i, c_f, c_p]),
     'cvar_silu_cast': (c_i, [c_p, c_p, c_i, c_l, c_p]),
     'cvar_attention': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, c_p, c_p, c_p]),

@@ -18,7 +18,6 @@
 // bf16 GEMM kernels, split-K; from gemm_conv.hip (CVAR_GEMM_CONV_TU) - the bf16 implicit-conv kernels; from gemm_f32.hip
 // (CVAR_GEMM_F32_TU) - everything fp32 (parity mode).
 #include "cvar_common.h"
-#include <stdlib.h>
 #if defined(CVAR_GEMM_CONV_TU)
 #define CVAR_TU_CONV 1
 #define CVAR_TU_PLAIN 0
@@ -64,6 +63,8 @@ struct GemmParams {
     unsigned remap_magic, gate_magic; int remap_shift, gate_shift;   // exact m / remap_l and m / gate_rows for 0 <= m < 2^31 (fast_div)
     int split_tiles;          // split-K: K tiles per blockIdx.y slice (0 = no split); partials go to C + blockIdx.y * split_stride
     long split_stride;
+    int stagger;              // > 0: the first wave of workgroups (one per CU) starts spread over this many shader cycles (see cvar_gemm_kernel)
+    int tile_cfg;             // cvar_gemm_desc::tile_cfg (0 = automatic)
 };
 
 
@@ -121,6 +122,19 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+
+    // ---- start stagger.  Tiles of one launch take the same time, so all CUs reach their epilogues together: HBM idles during
+    // the K loops (operands come out of L2) and is saturated by 256 simultaneous output bursts (plus residual reads) at the
+    // tile boundaries - the workgroups then all wait on the same queue, which also keeps them in phase for the next round.
+    // The FIRST workgroup of each CU (blockIdx < 256: one per CU and round) sleeps 0..stagger cycles by its index inside the XCD;
+    // later workgroups inherit the phase of the one they replace.  Costs <= `stagger` cycles at the tail of the launch.
+    if (p.stagger > 0 && blockIdx.x < 256u && gridDim.y == 1 && gridDim.z == 1) {
+        const unsigned ph = (blockIdx.x >> 3) & 31u;
+        if (ph) {
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime() + (unsigned long long)ph * (unsigned)p.stagger / 32u;
+            while (__builtin_amdgcn_s_memtime() < t_end) __builtin_amdgcn_s_sleep(8);
+        }
+    }
 
     // ---- tile coordinates: bijective XCD remap, then grouped-M ordering
     int bid = blockIdx.x;
@@ -767,6 +781,19 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #endif
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is sticky per (function, device): set it the first time a kernel is launched on a
+// device instead of on every launch (~1200 launches per generation)
+template <typename K>
+static void set_max_lds_once(K kfn, size_t lds) {
+    static unsigned char done[64] = {0};          // one table per kernel instantiation
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !done[dev]) {
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (dev >= 0 && dev < 64) done[dev] = 1;
+    }
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE = 2, bool CONVFAST = false, bool CUP = false>
 static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     GemmParams p = gp;
@@ -784,7 +811,7 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
         if (!p.conv) return CVAR_EINVAL;
         if constexpr (WITH_CONV) {
             auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, true, NSTAGE, true, CUP>;
-            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            set_max_lds_once(kfn, lds);
             hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
             CVAR_CHECK_LAUNCH();
             return CVAR_OK;
@@ -792,7 +819,7 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     } else if (p.conv) {
         if constexpr (WITH_CONV) {
             auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, true, NSTAGE>;
-            (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            set_max_lds_once(kfn, lds);
             hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
         } else return CVAR_EUNSUPPORTED;
     } else if constexpr (!WITH_PLAIN) {
@@ -800,21 +827,21 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     } else if (p.K % (128 / (int)sizeof(T)) == 0 && (long)(BM - 1) * p.lda * (long)sizeof(T) + (long)p.K * (long)sizeof(T) < (1L << 31) &&
                (long)(BN - 1) * p.ldw * (long)sizeof(T) + (long)p.K * (long)sizeof(T) < (1L << 31)) {
         auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, false, NSTAGE, true>;
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set_max_lds_once(kfn, lds);
         hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
     } else {
         auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, false, NSTAGE>;
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        set_max_lds_once(kfn, lds);
         hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
     }
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;
 }
 
-static int gemm_cfg_override() {
-    static int v = -2;
-    if (v == -2) { const char* e = getenv("CVAR_GEMM_CFG"); v = e ? atoi(e) : -1; }
-    return v;
+// cvar_gemm_desc::tile_cfg -> the A/B selector of launch_typed: -1 automatic, 0 128x128 tiles only, 1 the 8-wave 256x256 tile, 3 the
+// 4-wave 256x256 tile (part of the call, not of the process environment)
+static int gemm_cfg_override(const GemmParams& p) {
+    return p.tile_cfg == 1 ? 0 : p.tile_cfg == 2 ? 1 : p.tile_cfg == 3 ? 3 : -1;
 }
 
 template <typename T>
@@ -825,7 +852,7 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     // few output channels (the decoder's conv_out: 160 -> 3): a 256x32 tile wastes 10x instead of 42x of the MFMA work of a
     // 128-wide tile; the kernel is then bound by streaming the activations, as it should be
     if constexpr (sizeof(T) == 2) {
-        if (p.conv && p.N <= 32 && p.M >= 4096 && p.stride == 1 && !p.up && p.Cin % 32 == 0 && p.split_tiles == 0 && gemm_cfg_override() != 0) {
+        if (p.conv && p.N <= 32 && p.M >= 4096 && p.stride == 1 && !p.up && p.Cin % 32 == 0 && p.split_tiles == 0 && gemm_cfg_override(p) != 0) {
             const long in_bytes = (long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin * (long)sizeof(T);
             if (in_bytes < (1L << 31)) {
                 GemmParams q = p;
@@ -839,7 +866,7 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
         const long in_bytes = p.conv ? (long)(p.M / (p.Hout * p.Wout)) * p.Hin * p.Win * p.Cin * (long)sizeof(T) : 0;
         if constexpr (sizeof(T) == 2) {
             if (p.conv && (p.stride == 1 || (p.stride == 2 && !p.up)) && p.Cin % 32 == 0 && p.split_tiles == 0 && in_bytes < (1L << 31) &&
-                (long)159 * p.ldw * 2 + (long)p.K * 2 + 256 < (1L << 31) && gemm_cfg_override() != 0 &&
+                (long)159 * p.ldw * 2 + (long)p.K * 2 + 256 < (1L << 31) && gemm_cfg_override(p) != 0 &&
                 (!p.up || (p.Hout == 2 * p.Hin && p.Wout == 2 * p.Win))) {
                 GemmParams q = p;
                 q.conv_bytes = (unsigned)in_bytes;
@@ -849,18 +876,28 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
         return launch_cfg<T, 128, 160, 4, 1>(p, batch, st);
     }
     // large streaming GEMMs: 256x256 tile - halves the operand bytes per flop and doubles the MFMA work per barrier; measured
-    // +10..15 % over 128x128 on the d24 shapes.  CVAR_GEMM_CFG=0 forces the 128x128 tile, =1 the 8-wave tile everywhere (A/B runs).
-    const int ov = gemm_cfg_override();
+    // +10..15 % over 128x128 on the d24 shapes.  tile_cfg 1 forces the 128x128 tile, 2 the 8-wave tile everywhere (A/B runs).
+    const int ov = gemm_cfg_override(p);
     // N = 1920 / 5760 of d30 (C = 30 * 64) is a multiple of 128 only: the last 256-wide tile is half empty (2-6 % waste), still far
     // better than dropping the whole GEMM to the 128x128 tile
     const bool n_ok = p.N % 256 == 0 || (p.N % 128 == 0 && p.N >= 1536);
     // Two 256x256 variants share the loop and the epilogue code: 8 waves (2x4, two per SIMD, 128x64 per wave) and 4 waves (2x2, one
     // per SIMD, 128x128 per wave, accumulators in AGPRs).  The 4-wave one wins isolated GEMMs by 1-3 % (fewer LDS reads per MFMA),
     // the 8-wave one wins in the model by 1-2 % at every depth (d12 ... d30): twice the waves share the epilogue's loads / stores /
-    // GELU and fill each other's DMA-issue bubbles.  Default: 8 waves; CVAR_GEMM_CFG=3 selects the 4-wave variant (A/B runs), and the
+    // GELU and fill each other's DMA-issue bubbles.  Default: 8 waves; tile_cfg 3 selects the 4-wave variant (A/B runs), and the
     // split-K slices of long-K GEMMs (training weight gradients: plain fp32 partial stores) use it as well.
     if (sizeof(T) == 2 && (ov == 3 || (ov != 0 && ov != 1 && p.split_tiles > 0)) && (p.M >= 2048 || (p.split_tiles > 0 && p.M > 1024)) && n_ok)
         return launch_cfg<T, 256, 256, 2, 2>(p, batch, st);
+    // Partial rounds: a launch of t tiles takes ceil(t / slots) rounds of the chip.  256x256: 256 slots (one workgroup per CU), cost 1
+    // per round; 128x128: 512 slots (two per CU share its matrix cores), a quarter of the work at 0.82x the rate => 0.61 per round
+    // (measured on the d24 shapes, tools/gemm_tilecfg.py).  The mid scales of the pyramid with N = C outputs (proj, fc2: 108..432
+    // tiles of 256x256) fill the last round badly; the smaller tile wins there (M=4608: proj 464 -> 599, fc2 672 -> 873 TFLOP/s).
+    // K order per output is the same for both tiles: bit-identical results.
+    if (ov == -1 && sizeof(T) == 2 && p.split_tiles == 0 && batch == 1 && n_ok && p.M >= 2048) {
+        const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256), t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+        const double c256 = (double)((t256 + 255) / 256), c128 = 0.61 * (double)((t128 + 511) / 512);
+        if (c128 < 0.97 * c256) return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
+    }
     if (ov != 0 && (p.M >= 2048 || (p.split_tiles > 0 && p.M > 1024)) && n_ok) return launch_cfg<T, 256, 256, 2, 4>(p, batch, st);
     return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
 }
@@ -907,13 +944,6 @@ __global__ __launch_bounds__(256) void cvar_splitk_epilogue_kernel(const float* 
     }
 }
 
-static float* g_splitk_ws = nullptr;       // set by cvar_gemm_set_workspace (caller-owned device memory)
-static size_t g_splitk_ws_bytes = 0;
-extern "C" int cvar_gemm_set_workspace(void* ws, int64_t bytes) {
-    g_splitk_ws = (float*)ws;
-    g_splitk_ws_bytes = ws ? (size_t)bytes : 0;
-    return CVAR_OK;
-}
 
 extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->W || !d->C) return CVAR_EINVAL;
@@ -955,6 +985,10 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     make_fast_div(p.remap_l, &p.remap_magic, &p.remap_shift);
     make_fast_div(p.gate ? p.gate_rows : 1, &p.gate_magic, &p.gate_shift);
     p.split_tiles = 0; p.split_stride = 0;
+    p.tile_cfg = d->tile_cfg; p.stagger = d->stagger > 0 ? d->stagger : 0;
+    // split-K workspace: part of the call (caller-owned, any stream / device), nothing process-wide
+    float* const g_splitk_ws = (d->ws && d->ws_bytes > 0 && (((uintptr_t)d->ws & 15) == 0)) ? (float*)d->ws : nullptr;
+    const size_t g_splitk_ws_bytes = g_splitk_ws ? (size_t)d->ws_bytes : 0;
     hipStream_t st = as_stream(stream);
     // split-K decision: plain (non-conv, unbatched) GEMMs whose tile count leaves most CUs idle
     const int kt_elems = 128 / es;

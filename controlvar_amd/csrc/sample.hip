@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void cfg_sample_kernel(const SampleParams p) {
         int kk = p.top_k;
         for (int ps = 3; ps >= 0; --ps) {
             hist_cnt[tid] = 0;
+            if (tid == 0) { sel_digit = 0u; sel_k = kk; }
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < EPT; ++i) {
@@ -196,11 +197,19 @@ __global__ __launch_bounds__(256) void cfg_sample_kernel(const SampleParams p) {
     // ---- nucleus threshold key: smallest key whose ascending cumulative mass exceeds (1 - top_p) * Z
     unsigned tp = 0;
     if (p.top_p > 0.f) {
-        const u64 lim = (u64)((double)(1.0f - p.top_p) * (double)Z);
+        // (1 - top_p) in double and clamped: top_p < 2^-24 would round 1 - top_p to 1 in float (lim == Z: no bucket qualifies), and
+        // top_p > 1 would cast a negative double to u64.  lim <= Z - 1 guarantees that exactly one bucket per pass satisfies the
+        // selection below; Z > 0 always (the maximum carries mass 2^40).  The last (largest) element is therefore always kept, as
+        // helpers.py:14 does.  Elements TIED with the cut value are all kept here (value threshold), where the reference cuts
+        // inside the tie by sort order - a difference only for exactly equal logits.
+        const double keep_from = fmin(fmax(1.0 - (double)p.top_p, 0.0), 1.0);
+        u64 lim = (u64)(keep_from * (double)Z);
+        if (lim >= Z) lim = Z - 1;
         unsigned prefix = 0;
         u64 below = 0;
         for (int ps = 3; ps >= 0; --ps) {
             hist_mass[tid] = 0ull;
+            if (tid == 0) { sel_digit = 255u; sel_below = below; }      // defined even if no bucket were selected
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < EPT; ++i) {
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(256) void cfg_sample_kernel(const SampleParams p) {
         h = splitmix64(h ^ ((unsigned long long)p.stage << 48) ^ ((unsigned long long)((long)d * p.B + b) << 16) ^ (unsigned long long)t);
         const double u = (double)(h >> 11) * (1.0 / 9007199254740992.0);       // 53 bits -> [0,1)
         u64 target = (u64)(u * (double)Zk);
-        if (target >= Zk) target = Zk - 1;
+        if (target >= Zk) target = Zk > 0 ? Zk - 1 : 0;
         if (excl <= target && target < excl + keepsum) {                        // exactly one thread
             u64 run = excl;
             int pick = tid;

@@ -1,4 +1,4 @@
-"""One-process-per-GPU launch helpers for the sample-sharded hot path.
+"""One-process-per-GPU launch helpers for the data-parallel hot path (SURVEY.md sections 8a A22 and 8e).
 
 Inference and the tokenizer shard by sample: every rank holds a full replica of the weights and runs its own
 batch; there is NO data-path collective.  The only communication is the bench/eval harness's barrier and the
@@ -67,3 +67,83 @@ def sharded_timed_run(step: Callable[[int], object], steps: int, warmup: int, un
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return world * units_per_step * steps / dt, dt
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# A22: the data-parallel training runtime around the step (train_control_var_hpu.py:411-418,569-574,604,692-697; dist.py:19-48)
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _spawn_entry(rank: int, fn, world: int, port: int, backend: Optional[str], args: tuple):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')            # dmabuf IPC: the only mode the host driver supports (RCCL needs it)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(rank % torch.cuda.device_count())
+    import torch.distributed as dist
+    init_dist(backend, torch.device('cuda', rank % torch.cuda.device_count()) if torch.cuda.is_available() and backend != 'gloo' else None)
+    try:
+        fn(rank, world, *args)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def spawn(fn: Callable, nprocs: Optional[int] = None, args: tuple = (), backend: Optional[str] = None, port: Optional[int] = None, join: bool = True):
+    """``mp.spawn(main_worker, nprocs=ngpus_per_node, args=...)`` of the reference (train_control_var_hpu.py:692-697) without torchrun:
+    starts `nprocs` processes (default: one per visible GPU), each with RANK / LOCAL_RANK / WORLD_SIZE set, the device selected and
+    torch.distributed initialised on 127.0.0.1 (RCCL when GPUs are present, gloo otherwise), and calls ``fn(rank, world, *args)`` in it.
+    The same worker also runs under torchrun: init_dist() reads the environment either way."""
+    import torch.multiprocessing as mp
+    if nprocs is None:
+        nprocs = max(1, torch.cuda.device_count()) if torch.cuda.is_available() else 1
+    if port is None:
+        port = 29400 + (os.getpid() * 7) % 500
+    return mp.start_processes(_spawn_entry, args=(fn, nprocs, port, backend, tuple(args)), nprocs=nprocs, join=join, start_method='spawn')
+
+
+class ShardedSampler:
+    """Per-rank index shard of a data set - the arithmetic of ``torch.utils.data.DistributedSampler`` as the reference uses it
+    (train_control_var_hpu.py:569-574: shuffle=True, drop_last=False; ``set_epoch`` per epoch :651): epoch permutation from
+    ``seed + epoch``, padded by wrapping to a multiple of the world size, rank r takes every world-th index starting at r.
+    Stateless apart from the epoch, so every rank derives its shard without communication."""
+
+    def __init__(self, n_items: int, rank: Optional[int] = None, world: Optional[int] = None, shuffle: bool = True, seed: int = 0,
+                 drop_last: bool = False):
+        r, _, w = dist_env()
+        self.n, self.rank, self.world = int(n_items), r if rank is None else int(rank), w if world is None else int(world)
+        if not 0 <= self.rank < self.world:
+            raise ValueError(f'rank {self.rank} outside world {self.world}')
+        self.shuffle, self.seed, self.drop_last, self.epoch = shuffle, seed, drop_last, 0
+        if drop_last and self.n % self.world:
+            self.num_samples = self.n // self.world
+        else:
+            self.num_samples = (self.n + self.world - 1) // self.world
+        self.total_size = self.num_samples * self.world
+
+    def set_epoch(self, epoch: int):
+        self.epoch = int(epoch)
+
+    def __len__(self):
+        return self.num_samples
+
+    def __iter__(self):
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(self.seed + self.epoch)
+            idx = torch.randperm(self.n, generator=g).tolist()
+        else:
+            idx = list(range(self.n))
+        if not self.drop_last:
+            pad = self.total_size - len(idx)
+            if pad > 0:
+                idx += (idx * ((pad + len(idx) - 1) // max(len(idx), 1) + 1))[:pad]
+        else:
+            idx = idx[:self.total_size]
+        return iter(idx[self.rank:self.total_size:self.world])
+
+
+def synthetic_rank_batch(batch: int, rank: int, device, size: int = 256):
+    """the synthetic ImageNetC-shaped batch of one rank - image / control U-shaped fields seeded by the rank,
+    class ids ~ U{0..999}, condition types ~ U{0..3} (deterministic per rank, different across ranks)."""
+    from .synth import synth_images
+    g = torch.Generator().manual_seed(1000 + rank)
+    return (synth_images(batch, size, seed=2 * rank).to(device), synth_images(batch, size, seed=2 * rank + 1).to(device),
+            torch.randint(0, 1000, (batch,), generator=g), torch.randint(0, 4, (batch,), generator=g))

@@ -44,6 +44,24 @@ def _register_tree(root: nn.Module, shapes, values: Dict[str, torch.Tensor], req
             m.register_buffer(parts[-1], t)
 
 
+def _tensor_sig(module: nn.Module):
+    """identity + in-place-version stamp of every parameter and buffer: changes when a tensor is replaced (load_state_dict(assign),
+    .data swaps, .to()) or written in place through autograd-visible ops (torch.optim steps, p.mul_(), p.copy_())"""
+    return tuple((t.data_ptr(), t._version) for t in list(module.parameters(recurse=True)) + list(module.buffers(recurse=True)))
+
+
+def _check_index_range(t: torch.Tensor, lo: int, hi: int, what: str):
+    """nn.Embedding raises on an out-of-range index (the reference's failure mode); the gather kernels read unchecked, so ids are
+    validated here: for free on host tensors, with one tiny reduction + read-back on device tensors (outside any graph capture)."""
+    if t.numel() == 0:
+        return
+    if t.is_cuda and torch.cuda.is_current_stream_capturing():
+        return
+    mn, mx = (int(v) for v in torch.stack((t.min(), t.max())).tolist())
+    if mn < lo or mx > hi:
+        raise IndexError(f'{what}: index out of range (got [{mn}, {mx}], valid [{lo}, {hi}])')
+
+
 def _compute_dtype(d) -> torch.dtype:
     if isinstance(d, torch.dtype):
         return d
@@ -97,8 +115,13 @@ class VQVAE(nn.Module):
         return self.quant_conv.weight.device
 
     # ---- weight packing (one-time layout work, not on the timed path)
-    def _pack(self):
-        if self._packed is not None:
+    def _state_sig(self):
+        return _tensor_sig(self)
+
+    def _pack(self, check: bool = False):
+        """GEMM-ready device copies of the weights.  check=True (public entry points): rebuild them when any parameter / buffer
+        was replaced or modified in place since they were made (optimizer steps, manual edits, .data swaps)."""
+        if self._packed is not None and (not check or self._packed_sig == self._state_sig()):
             return self._packed
         dev, T = self.device, self.compute_dtype
         if dev.type != 'cuda':
@@ -136,6 +159,7 @@ class VQVAE(nn.Module):
         P['tab_off'] = [int(o) for o in offs]
         P['phi_map'] = self.cfg.phi_map
         self._packed = P
+        self._packed_sig = self._state_sig()
         return P
 
     # ---- conv-stack building blocks (NHWC activations of compute dtype)
@@ -292,6 +316,7 @@ class VQVAE(nn.Module):
     @torch.no_grad()
     def img_to_idxBl(self, inp_img_no_grad: torch.Tensor, v_patch_nums=None) -> List[torch.Tensor]:
         """vqvae.py:73-75 -> list of (B, pn*pn) int64 ids, coarse to fine"""
+        self._pack(check=True)
         if v_patch_nums is not None and tuple(v_patch_nums) != tuple(self.cfg.patch_nums):
             raise NotImplementedError('v_patch_nums must equal the constructor patch_nums')
         idx, _, _ = self._ms_encode(self._encode_f(inp_img_no_grad))
@@ -300,6 +325,7 @@ class VQVAE(nn.Module):
     @torch.no_grad()
     def idxBl_to_h(self, gt_ms_idx_Bl: List[torch.Tensor]) -> List[torch.Tensor]:
         """vqvae.py:77-78 / quant.py:217-240 -> teacher-forcing inputs, list of (B, pn_{k+1}^2, Cvae) fp32"""
+        self._pack(check=True)
         B = gt_ms_idx_Bl[0].shape[0]
         dev = gt_ms_idx_Bl[0].device
         S = self.cfg.patch_nums[-1]
@@ -320,11 +346,13 @@ class VQVAE(nn.Module):
     @torch.no_grad()
     def fhat_to_img(self, f_hat: torch.Tensor) -> torch.Tensor:
         """vqvae.py:88-89"""
+        self._pack(check=True)
         return self._decode(f_hat)
 
     @torch.no_grad()
     def idxBl_to_img(self, ms_idx_Bl: List[torch.Tensor], same_shape: bool = True, last_one: bool = False):
         """vqvae.py:97-104 (same_shape=True path)"""
+        self._pack(check=True)
         if not same_shape:
             raise NotImplementedError('all_to_max_scale=False is an experimental visualisation path upstream (quant.py:171-180)')
         if last_one:
@@ -341,6 +369,7 @@ class VQVAE(nn.Module):
     @torch.no_grad()
     def img_to_recon(self, x, v_patch_nums=None, last_one=False):
         """vqvae.py:80-86"""
+        self._pack(check=True)
         idx, fh, _ = self._ms_encode(self._encode_f(x), want_fhat=True)
         if last_one:
             return self._decode(fh, lo=-3.0e38, hi=3.0e38)
@@ -396,7 +425,7 @@ class ControlVAR(nn.Module):
         self.cfg = VarConfig(depth=depth, mask_factor=mask_factor, multi_cond=bool(multi_cond) and self._control and mask_factor == 2,
                              control=self._control, patch_nums=tuple(patch_nums), vocab=vae_local.vocab_size, cvae=vae_local.Cvae,
                              num_classes=num_classes, embed_dim=embed_dim, num_heads=num_heads, norm_eps=norm_eps, tau=float(tau),
-                             cos_attn=bool(cos_attn), mlp_ratio=mlp_ratio, cond_drop_rate=cond_drop_rate,
+                             cos_attn=bool(cos_attn), mlp_ratio=mlp_ratio, cond_drop_rate=cond_drop_rate, drop_path_rate=float(drop_path_rate),
                              shared_aln=bool(shared_aln) and not sa_block, type_pos=bool(type_pos), sa_block=sa_block,
                              layer_scale=float(layer_scale) if sa_block else -1.0, bidirectional=bool(bidirectional))
         cfg = self.cfg
@@ -433,8 +462,14 @@ class ControlVAR(nn.Module):
     def device(self):
         return self.pos_1LC.device
 
-    def _pack(self):
-        if self._packed is not None:
+    def _state_sig(self):
+        return _tensor_sig(self)
+
+    def _pack(self, check: bool = False):
+        """GEMM-ready device copies of the weights (stacked per kind, compute dtype).  check=True (every public entry point and
+        the training engine's forward): rebuild when any parameter changed since - torch.optim steps through the autograd bridge,
+        manual in-place edits, .data swaps (the copies used to go stale on that path)."""
+        if self._packed is not None and (not check or self._packed_sig == self._state_sig()):
             return self._packed
         dev, T, cfg = self.device, self.compute_dtype, self.cfg
         if dev.type != 'cuda':
@@ -501,6 +536,8 @@ class ControlVAR(nn.Module):
         if cfg.uses_cos_attn:
             P['scale_mul'] = torch.stack([blk(i, 'attn.scale_mul_1H11').reshape(-1) for i in range(depth)]).float().contiguous()
         self._packed = P
+        self._packed_sig = self._state_sig()
+        self._pack_gen = getattr(self, '_pack_gen', 0) + 1          # consumers of derived copies (TrainEngine.WT) compare this
         return P
 
     def _first_tokens(self, P, labels, types, x, cond, R: int, x_rows: int, table, mask_first: bool = True):
@@ -569,6 +606,7 @@ class ControlVAR(nn.Module):
             label_B = torch.randint(0, self.num_classes, (B,), generator=g)
         elif isinstance(label_B, int):
             label_B = torch.full((B,), self.num_classes if label_B < 0 else label_B)
+        _check_index_range(label_B, 0, self.num_classes, 'label_B')
         return label_B.to(device=dev, dtype=torch.int32)
 
     def _as_types(self, B, cond_type, seed, allow_none=True):
@@ -582,6 +620,7 @@ class ControlVAR(nn.Module):
         elif isinstance(cond_type, int):
             assert 0 < cond_type <= 3                                      # control_var.py:395
             cond_type = torch.full((B,), cond_type)
+        _check_index_range(cond_type, 0, 4, 'cond_type')
         return cond_type.to(device=dev, dtype=torch.int32)
 
     @torch.no_grad()
@@ -607,6 +646,10 @@ class ControlVAR(nn.Module):
         if top_k > self.cfg.vocab:                     # helpers.py:8-10: torch.topk raises on k > V; top_k <= 0 means no top-k filter
             raise RuntimeError(f'selected index k out of range (top_k={top_k} > vocabulary {self.cfg.vocab})')
         seed = int(g_seed) if g_seed is not None else int(torch.empty((), dtype=torch.int64).random_().item())
+        self._pack(check=True); self.vae_proxy[0]._pack(check=True)
+        for name, ids in (('c_mask', c_mask), ('c_img', c_img), ('_force_idx', force_idx)):
+            if ids is not None:
+                _check_index_range(torch.cat([t.reshape(-1) for t in ids]), 0, self.cfg.vocab - 1, name)
         labels_all, types_all = self._prepare_rows(B, label_B, cond_type, four_way, seed)
         mask_first = True
         if self.cfg.mask_factor == 2 and not four_way:
@@ -735,8 +778,9 @@ class ControlVAR(nn.Module):
     def forward(self, label_B: torch.LongTensor, x_BLCv_wo_first_l: torch.Tensor, cond_type=None, mask_first=True) -> torch.Tensor:
         """control_var.py:568-651 teacher-forced logits (B, L, V) fp32.  Under autograd (grad mode on and trainable
         parameters) the call is differentiable - `loss.backward()` runs the hand-written backward kernels
-        (controlvar_amd/train.py); otherwise it is the inference-only fast path.  Label / cond-type dropout follows
-        ``self.training`` (torch.rand, as the reference)."""
+        (controlvar_amd/train.py); otherwise it is the inference-only fast path.  Label / cond-type dropout (rate ``cond_drop_rate``,
+        torch.rand) is applied on EVERY call, in train and eval mode alike, exactly as the reference's forward does
+        (control_var.py:578,584); DropPath follows ``self.training`` (helpers.py:39-46)."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from .train import teacher_forced_with_grad
             return teacher_forced_with_grad(self, label_B, x_BLCv_wo_first_l, cond_type, bool(mask_first))
@@ -744,18 +788,20 @@ class ControlVAR(nn.Module):
             return self._forward_nograd(label_B, x_BLCv_wo_first_l, cond_type, mask_first)
 
     def _forward_nograd(self, label_B, x_BLCv_wo_first_l, cond_type=None, mask_first=True):
-        cfg, P = self.cfg, self._pack()
+        cfg, P = self.cfg, self._pack(check=True)
         py, C = cfg.pyramid, cfg.C
         dev = self.device
         mask_first = bool(mask_first) or cfg.mask_factor != 2
         B = x_BLCv_wo_first_l.shape[0]
+        _check_index_range(label_B, 0, self.num_classes, 'label_B')
         labels = label_B.to(dev)
-        if self.training and cfg.cond_drop_rate > 0:
+        if cfg.cond_drop_rate > 0:                  # control_var.py:578,584: applied on every forward(), train or eval mode
             labels = torch.where(torch.rand(B, device=dev) < cfg.cond_drop_rate, self.num_classes, labels)
         types = None
         if cfg.mask_factor == 2:
+            _check_index_range(cond_type, 0, 4, 'cond_type')
             types = cond_type.to(dev)
-            if self.training and cfg.cond_drop_rate > 0:
+            if cfg.cond_drop_rate > 0:
                 types = torch.where(torch.rand(B, device=dev) < cfg.cond_drop_rate, 4, types)
             types = types.to(torch.int32).contiguous()
         labels = labels.to(torch.int32).contiguous()

@@ -40,14 +40,24 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 _SPLITK_WS = {}
+# per-call execution options of cvar_gemm (include/cvar.h): A/B measurement knobs, never needed for correctness
+GEMM_TILE_CFG = 0          # 0 automatic, 1 128x128 only, 2 8-wave 256x256, 3 4-wave 256x256
+GEMM_STAGGER = 0           # start-stagger window in shader cycles (0 = the library's default: off)
 
 
-def ensure_splitk_workspace(device, nbytes: int = 256 << 20):
-    """give the library a split-K workspace on `device` (kept alive here; one per process)"""
-    key = str(device)
-    if key not in _SPLITK_WS or _SPLITK_WS[key].numel() < nbytes:
-        _SPLITK_WS[key] = torch.empty(nbytes, device=device, dtype=torch.uint8)
-        check(_lib.load().cvar_gemm_set_workspace(_SPLITK_WS[key].data_ptr(), nbytes), 'cvar_gemm_set_workspace')
+def ensure_splitk_workspace(device, nbytes: int = 256 << 20) -> torch.Tensor:
+    """The split-K workspace ops.gemm hands to every cvar_gemm call on `device` issued from the current stream.  Caller-owned
+    memory (the library keeps no state); one buffer per (device, stream), created on first use, so that GEMMs on different
+    streams never share partial-sum storage and the split-K decision - hence the summation order - is the same on every stream
+    (eager, side-stream warm-up, graph capture)."""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _SPLITK_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _SPLITK_WS[key] = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    return ws
 
 
 def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, lda: int = 0, ldw: int = 0, ldc: int = 0,
@@ -83,6 +93,11 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
     if remap is not None:
         d.remap_l, d.remap_L, d.remap_off = remap
     d.pre_act, d.aux, d.gate_scale = _ptr(pre_act), _ptr(aux), _ptr(gate_scale)
+    ws = _SPLITK_WS.get((A.device.index, _stream()))
+    if ws is None:
+        ws = ensure_splitk_workspace(A.device)
+    d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
+    d.tile_cfg, d.stagger = GEMM_TILE_CFG, GEMM_STAGGER
     if GEMM_PROFILE is None:
         check(_lib.load().cvar_gemm(C.byref(d), _stream()), 'cvar_gemm')
     else:

@@ -1,0 +1,196 @@
+"""Drop-in implementations of the reference's L0 operator slots (models/basic_var.py:15-29).
+
+The reference picks its fast operators by assigning module globals in ``models/basic_var.py``:
+
+    dropout_add_layer_norm, fused_mlp_func     (flash_attn.ops)        basic_var.py:17-18, used at :44-49 and :163-171
+    memory_efficient_attention                 (xformers.ops)          basic_var.py:20,   used at :114-115
+    flash_attn_func                            (flash_attn)            basic_var.py:22,   used at :111-113   q, k, v: B L H c
+    slow_attn                                  (F.scaled_dot_product_attention)  :24,    used at :117        q, k, v: B H L c
+
+The functions below have exactly those names, argument names and layouts and run on the gfx950 kernels through
+``torch.ops.cvar.*`` (controlvar_amd/torch_ops.py -> C ABI).  ``install(basic_var_module)`` assigns them into the reference's module so
+that its own class tree (FFN / SelfAttention / SABlock) calls them; nothing in the reference has to be edited.  They are differentiable
+where the reference differentiates through the slot (fused MLP, attention, fused add + LayerNorm).  float32 tensors take the exact-f32
+path, bfloat16 the throughput path; float16 is not supported (the reference's HPU/GPU runs use bf16 autocast).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import torch_ops  # noqa: F401  (registers torch.ops.cvar.*)
+from ._lib import ACT_GELU_TANH, ACT_NONE
+
+cvar = torch.ops.cvar
+
+__all__ = ['fused_mlp_func', 'flash_attn_func', 'slow_attn', 'memory_efficient_attention', 'dropout_add_layer_norm', 'install']
+
+
+def _need_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(f'{what}: controlvar_amd operator slots run on the GPU only (no CPU fallback)')
+
+
+# --------------------------------------------------------------------------------------------------------------------- fused MLP
+def fused_mlp_func(x, weight1, weight2, bias1=None, bias2=None, activation='gelu_approx', save_pre_act=True, return_residual=False,
+                   checkpoint_lvl=0, heuristic=0, process_group=None):
+    """flash_attn.ops.fused_dense.fused_mlp_func as FFN.forward calls it (basic_var.py:44-49): fc2(act(fc1(x))).
+    GELU(tanh) runs in fc1's GEMM epilogue.  save_pre_act / checkpoint_lvl / heuristic only steer what upstream keeps for its
+    backward; here the backward recomputes the pre-activation with one extra GEMM, so they are accepted and ignored."""
+    _need_cuda(x, 'fused_mlp_func')
+    if activation not in ('gelu_approx', 'relu'):
+        raise ValueError(f'fused_mlp_func: activation {activation!r} (upstream accepts gelu_approx / relu; only gelu_approx is built)')
+    if activation != 'gelu_approx':
+        raise NotImplementedError('fused_mlp_func: only activation="gelu_approx" (the one FFN passes) is built')
+    if process_group is not None:
+        raise NotImplementedError('fused_mlp_func: tensor-parallel process groups are out of scope (replicas only, SURVEY.md 8e)')
+    h = cvar.linear(x, weight1, bias1, ACT_GELU_TANH)
+    y = cvar.linear(h, weight2, bias2, ACT_NONE)
+    return (y, x) if return_residual else y
+
+
+# --------------------------------------------------------------------------------------------------------------------- attention
+def _prefix_levels(attn_mask: torch.Tensor, Lq: int, Lk: int):
+    """The kernels implement 'query i sees keys [0, n_i)' with n_i = the first level end above position i - exactly the structure of
+    the reference's attn_bias_for_masking (control_var.py:158-168) and of its slices.  Recover the level ends from an additive
+    {0, -inf} mask and verify that it has that form; anything else is not something the reference passes."""
+    m = attn_mask
+    while m.dim() > 2:
+        if m.shape[0] != 1:
+            raise NotImplementedError('attention slot: per-batch / per-head masks are not built (the reference broadcasts one (1,1,L,L) mask)')
+        m = m[0]
+    if tuple(m.shape) != (Lq, Lk):
+        raise ValueError(f'attention slot: mask shape {tuple(attn_mask.shape)} does not match (L_q={Lq}, L_k={Lk})')
+    vis = (m == 0)
+    if not bool((vis | torch.isneginf(m)).all()):
+        raise NotImplementedError('attention slot: only additive {0, -inf} masks are built')
+    n = vis.sum(dim=1)                                            # visible keys per query
+    cols = torch.arange(Lk, device=m.device).view(1, -1)
+    if not bool((vis == (cols < n.view(-1, 1))).all()):
+        raise NotImplementedError('attention slot: the mask must make a PREFIX of the keys visible to every query')
+    n_list = [int(v) for v in n.tolist()]
+    q_off = Lk - Lq
+    ends = sorted(set(n_list))
+    for i, ni in enumerate(n_list):                               # n_i must be the first level end above the query's own position
+        pos = q_off + i
+        want = next((e for e in ends if e > pos), None)
+        if want != ni:
+            raise NotImplementedError('attention slot: mask is not block-causal over contiguous levels (control_var.py:158-168 form)')
+    return ends
+
+
+def _attention_blhc(q, k, v, scale: float, attn_mask=None, dropout_p: float = 0.0):
+    """q (B, Lq, H, c), k / v (B, Lk, H, c) -> (B, Lq, H, c).  The queries are the LAST Lq positions of the key sequence (KV-cache
+    convention of SelfAttention.forward, basic_var.py:106-108)."""
+    _need_cuda(q, 'attention slot')
+    if dropout_p:
+        raise NotImplementedError('attention dropout is not built (attn_drop_rate = 0 in every shipped config, control_var.py:27)')
+    B, Lq, H, c = q.shape
+    Lk = k.shape[1]
+    if c != 64:
+        raise NotImplementedError('attention slot: head_dim must be 64 (embed_dim = 64 * depth in every reference model)')
+    if k.shape != v.shape or k.shape[0] != B or k.shape[2] != H or Lq > Lk:
+        raise ValueError(f'attention slot: inconsistent shapes q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)}')
+    if q.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f'attention slot: dtype {q.dtype} not supported (float32 or bfloat16)')
+    q_off = Lk - Lq
+    lvl_end = _prefix_levels(attn_mask, Lq, Lk) if attn_mask is not None else []
+    # pack the (q | k | v) arena the kernel reads: the model path writes this layout straight from the QKV GEMM; the slot pays a copy
+    qfull = q if q_off == 0 else torch.cat((q.new_zeros(B, q_off, H, c), q), dim=1)
+    arena = torch.stack((qfull, k.to(q.dtype), v.to(q.dtype)), dim=2).reshape(B, Lk, 3 * H * c).contiguous()
+    out, _ = cvar.attention(arena, H, q_off, Lq, float(scale), lvl_end, False)
+    return out.view(B, Lq, H, c)
+
+
+def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, **unused):
+    """flash_attn.flash_attn_func as called at basic_var.py:113 - q, k, v: (B, L, H, c), returns (B, L, H, c)."""
+    if causal:
+        raise NotImplementedError('flash_attn_func: causal=True is never used by the reference (block-causal masks go through slow_attn)')
+    scale = softmax_scale if softmax_scale is not None else q.shape[-1] ** -0.5
+    return _attention_blhc(q, k, v, scale, None, dropout_p)
+
+
+def memory_efficient_attention(query, key, value, attn_bias=None, p=0.0, scale=None, **unused):
+    """xformers.ops.memory_efficient_attention as called at basic_var.py:115 - (B, L, H, c) layout, optional additive bias."""
+    scale = scale if scale is not None else query.shape[-1] ** -0.5
+    return _attention_blhc(query, key, value, scale, attn_bias, p)
+
+
+def slow_attn(query, key, value, scale: Optional[float] = None, attn_mask=None, dropout_p=0.0, **unused):
+    """F.scaled_dot_product_attention as called at basic_var.py:117 - q, k, v: (B, H, L, c), returns (B, H, L, c)."""
+    scale = scale if scale is not None else query.shape[-1] ** -0.5
+    o = _attention_blhc(query.transpose(1, 2), key.transpose(1, 2), value.transpose(1, 2), scale, attn_mask, dropout_p)
+    return o.transpose(1, 2)
+
+
+# --------------------------------------------------------------------------------------------------------------------- fused add + LayerNorm
+class _AddResidual(torch.autograd.Function):
+    """residual_out = residual + x0 * rowscale * layerscale (fp32), in one kernel"""
+
+    @staticmethod
+    def forward(ctx, x0, residual, rowscale, layerscale):
+        C = x0.shape[-1]
+        rows = x0.numel() // C
+        out = residual.float().clone().contiguous() if residual is not None else torch.zeros(x0.shape, device=x0.device, dtype=torch.float32)
+        gate = layerscale.float().reshape(1, C) if layerscale is not None else torch.ones(1, C, device=x0.device)
+        f = x0 if x0.dtype in (torch.float32, torch.bfloat16) else x0.float()
+        if rowscale is not None:                     # per-token scale (drop_path over (B, L), basic_var.py:165,169): gate row = one token
+            cvar.gate_residual_(out.view(rows, C), f.reshape(rows, C), gate, 1, rowscale.reshape(rows))
+        else:
+            cvar.gate_residual_(out.view(rows, C), f.reshape(rows, C), gate, rows, None)
+        ctx.save_for_backward(x0, rowscale, layerscale)
+        ctx.has_res = residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x0, rowscale, layerscale = ctx.saved_tensors
+        C = x0.shape[-1]
+        sc = g
+        if layerscale is not None:
+            sc = sc * layerscale.float()
+        if rowscale is not None:
+            sc = sc * rowscale.reshape(*x0.shape[:-1], 1).float()
+        dls = None
+        if layerscale is not None:
+            t = g * x0.float()
+            if rowscale is not None:
+                t = t * rowscale.reshape(*x0.shape[:-1], 1).float()
+            dls = t.reshape(-1, C).sum(0).to(layerscale.dtype)
+        return sc.to(x0.dtype), (g if ctx.has_res else None), None, dls
+
+
+def dropout_add_layer_norm(x0, residual, weight, bias, dropout_p, epsilon, rowscale=None, layerscale=None, prenorm=False,
+                           residual_in_fp32=False, return_dropout_mask=False):
+    """flash_attn.ops.layer_norm.dropout_add_layer_norm as SABlock.fused_forward_wo_cond calls it (basic_var.py:163-171):
+        residual_out = residual + drop(x0 * rowscale * layerscale);  y = LayerNorm(residual_out) * weight + bias
+    returns y (dtype of x0), or (y, residual_out) with prenorm=True.  The affine LayerNorm runs on the adaLN kernel
+    (LN(x) * (1 + (weight - 1)) + bias)."""
+    _need_cuda(x0, 'dropout_add_layer_norm')
+    if dropout_p:
+        raise NotImplementedError('dropout_add_layer_norm: dropout_p > 0 is never used by the reference (basic_var.py:164: "no drop")')
+    if return_dropout_mask:
+        raise NotImplementedError('dropout_add_layer_norm: return_dropout_mask is not built')
+    C = x0.shape[-1]
+    res = _AddResidual.apply(x0, residual, rowscale, layerscale)
+    out_dtype = x0.dtype if x0.dtype in (torch.float32, torch.bfloat16) else torch.float32
+    rows = res.numel() // C
+    y = cvar.ln_modulate(res, (weight.float() - 1.0).reshape(1, C), bias.float().reshape(1, C) if bias is not None else res.new_zeros(1, C),
+                         rows, float(epsilon), out_dtype)
+    if not residual_in_fp32 and residual is not None:
+        res = res.to(residual.dtype)
+    return (y, res) if prenorm else y
+
+
+# --------------------------------------------------------------------------------------------------------------------- installation
+def install(basic_var_module, flash: bool = True, fused: bool = True):
+    """Assign the slots into the reference's ``models.basic_var`` module (or any module with the same globals).  Models built AFTER this
+    call with flash_if_available / fused_if_available pick them up (FFN.__init__ :35, SelfAttention.__init__ :83-84, SABlock :141)."""
+    if fused:
+        basic_var_module.fused_mlp_func = fused_mlp_func
+        basic_var_module.dropout_add_layer_norm = dropout_add_layer_norm
+    if flash:
+        basic_var_module.flash_attn_func = flash_attn_func
+    basic_var_module.slow_attn = slow_attn
+    return basic_var_module

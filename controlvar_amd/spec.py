@@ -97,6 +97,7 @@ class VarConfig:
     cos_attn: bool = False          # ControlVAR forces True when depth == 30 (control_var.py:35)
     mlp_ratio: float = 4.0
     cond_drop_rate: float = 0.1
+    drop_path_rate: float = 0.0     # stochastic depth: block i drops its branches with rate linspace(0, drop_path_rate, depth)[i] (control_var.py:123-124)
     shared_aln: bool = False        # N4: one SharedAdaLin for all blocks + per-block ada_gss (control_var.py:120, basic_var.py:194-205)
     type_pos: bool = False          # N4: type_embed added per control / image half (control_var.py:99-117,423,482,623)
     bidirectional: bool = False     # N4: image-first order allowed (mask_first=False: first two tokens and type ids swapped; control_var.py:403-407,587,624)

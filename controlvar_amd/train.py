@@ -116,6 +116,7 @@ class TrainEngine:
         self.drop_path = drop_path
         self.reducer = reducer
         self._B = None
+        self._wt_gen = -1
 
     # ---------------------------------------------------------------- buffers
     def _setup(self, B: int):
@@ -199,6 +200,7 @@ class TrainEngine:
         ops.transpose(P['w_fc2'], self.WT['fc2'], depth, C, hid, hid)
         ops.transpose(P['w_head'], self.WT['head'], 1, V, C, C)
         ops.transpose(P['w_ada'], self.WT['ada'], 1, P['n_ada'], C, C)
+        self._wt_gen = self.var._pack_gen
 
     def grads(self) -> Dict[str, torch.Tensor]:
         """state_dict key -> gradient view (fp32)"""
@@ -280,21 +282,27 @@ class TrainEngine:
                       mask_first: bool = True):
         """teacher-forced forward that keeps every block's activations; returns logits (B*L, V) fp32"""
         cfg, var = self.cfg, self.var
-        P = var._pack()
+        P = var._pack(check=True)
         py, C, depth, V, H = cfg.pyramid, cfg.C, cfg.depth, cfg.vocab, cfg.H
         L, fl = py.L, py.first_l
         dev, T = var.device, var.compute_dtype
         B = x_wo_first.shape[0]
         self._setup(B)
+        if self._wt_gen != var._pack_gen:          # the W^T copies follow the packed weights (any optimizer, manual edits, resume)
+            self._transposed_weights()
         M, Mp = self.M, self.Mp
         hid = P['w_fc1'].shape[1]
         n_ada = P['n_ada']
         eps = cfg.norm_eps
         lvl_end = list(py.end)
         scale = float(cfg.attn_scale)
+        from .models import _check_index_range
+        _check_index_range(label_B, 0, cfg.num_classes, 'label_B')
         labels = label_B.to(dev)
         types = cond_type.to(dev) if (cond_type is not None and cfg.mask_factor == 2) else None
-        if var.training and cfg.cond_drop_rate > 0:                 # control_var.py:578,584
+        if types is not None:
+            _check_index_range(types, 0, 4, 'cond_type')
+        if cfg.cond_drop_rate > 0:                                  # control_var.py:578,584: every forward(), train or eval
             labels = torch.where(torch.rand(B, device=dev) < cfg.cond_drop_rate, cfg.num_classes, labels)
             if types is not None:
                 types = torch.where(torch.rand(B, device=dev) < cfg.cond_drop_rate, 4, types)
@@ -302,7 +310,7 @@ class TrainEngine:
         types = types.to(torch.int32).contiguous() if types is not None else None
         # DropPath row scales (helpers.py:39-46): per sample, per block, per branch
         dp1 = dp2 = None
-        rate = 0.1 * depth / 24                                       # models/__init__.py:15,40
+        rate = cfg.drop_path_rate                                     # constructor argument; the factories pass 0.1 * depth / 24 (models/__init__.py:15,40)
         if self.drop_path and var.training and rate > 0:
             g = torch.Generator(device=dev)
             g.manual_seed(drop_seed if drop_seed is not None else int(torch.empty((), dtype=torch.int64).random_().item()))
@@ -473,21 +481,26 @@ class BucketReducer:
     generator, then head + embeddings), launched on a side stream the moment the backward has finished that bucket, so that
     RCCL traffic over xGMI overlaps the remaining backward.  The 1/world mean is folded into the optimizer's gradient scale."""
 
-    def __init__(self, buckets: Sequence[torch.Tensor], group=None):
+    def __init__(self, buckets: Sequence[torch.Tensor], group=None, force: bool = False):
+        """force=True issues the collectives even in a one-rank group (SUM over one rank = identity): the real slabs then travel the
+        whole path - side stream, RCCL call, event hand-back - on a single GPU, which is how the path is tested without a node."""
         import torch.distributed as dist
         self.dist = dist
         self.buckets = list(buckets)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.cuda = len(self.buckets) > 0 and self.buckets[0].is_cuda
-        self.stream = torch.cuda.Stream() if (self.cuda and self.world > 1) else None
+        self.stream = torch.cuda.Stream() if (self.cuda and self.active) else None
         self.handles: List = []
         self.launched: List[int] = []
+        self.bytes_sent = 0
 
     def ready(self, idx: int):
         self.launched.append(idx)
-        if self.world == 1:
+        if not self.active:
             return
+        self.bytes_sent += self.buckets[idx].numel() * self.buckets[idx].element_size()
         b = self.buckets[idx]
         if self.cuda:
             ev = torch.cuda.Event()
@@ -601,9 +614,14 @@ class Trainer:
     """One process per GPU; the step of train_control_var_hpu.py:130-255 (minus its logging / gradient-accumulation quirks)."""
 
     def __init__(self, var, vae, peak_lr: float, weight_decay: float, weight_decay_end: Optional[float] = None, sche: str = 'lin0',
-                 warmup_it: float = 0, max_it: int = 1000, clip: float = 2.0, wp0: float = 0.005, wpe: float = 0.01, drop_path: bool = True):
+                 warmup_it: float = 0, max_it: int = 1000, clip: float = 2.0, wp0: float = 0.005, wpe: float = 0.01, drop_path: bool = True,
+                 train_mode: Optional[bool] = None, force_reducer: bool = False):
+        """train_mode: True puts the model in train() (DropPath active, as the reference's loop runs it, train_control_var_hpu.py:136),
+        False in eval(); None leaves the mode as the caller set it."""
         import torch.distributed as dist
         self.var, self.vae = var, vae
+        if train_mode is not None:
+            var.train(train_mode)
         self.engine = TrainEngine(var, drop_path=drop_path)
         self.opt = FusedAdamW(var, lr=peak_lr, weight_decay=weight_decay)
         self.sched = dict(sche=sche, peak_lr=peak_lr, wd=weight_decay, wd_end=weight_decay if weight_decay_end is None else weight_decay_end,
@@ -611,6 +629,8 @@ class Trainer:
         self.clip = clip
         self.it = 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.force_reducer = force_reducer
+        self.comm = True                        # False: skip the gradient exchange (bench.py measures the exposed communication time with it)
         self._reducer_for = None
 
     @torch.no_grad()
@@ -635,9 +655,13 @@ class Trainer:
         _, max_lr, _, max_wd = lr_wd_annealing(s['sche'], self.opt, s['peak_lr'], s['wd'], s['wd_end'], self.it, s['wp_it'], s['max_it'], wp0=s['wp0'], wpe=s['wpe'])
         x, labels = self.tokenize(images, masks, mask_first)
         self.engine._setup(x.shape[0])
-        if self.world > 1 and self._reducer_for is not self.engine.buckets:
-            self.engine.reducer = BucketReducer(self.engine.buckets)
-            self._reducer_for = self.engine.buckets
+        if (self.world > 1 or self.force_reducer) and self.comm:
+            if self._reducer_for is not self.engine.buckets:
+                self._reducer = BucketReducer(self.engine.buckets, force=self.force_reducer)
+                self._reducer_for = self.engine.buckets
+            self.engine.reducer = self._reducer
+        else:
+            self.engine.reducer = None
         loss, _ = self.engine.forward_backward(cls, x, types, labels, ignore_mask, drop_seed, mask_first)
         if self.engine.reducer is not None:
             self.engine.reducer.wait()

@@ -9,7 +9,8 @@
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (no allocation inside the library), except the
  *     small parameter arrays suffixed `_host` (copied into the launch); row-major, dims passed explicitly; `stream` is a hipStream_t passed as void* (NULL = default);
- *   - all calls are asynchronous on `stream`, re-entrant, no global mutable state;
+ *   - all calls are asynchronous on `stream`, re-entrant, thread-safe for distinct streams; no global mutable state, no environment
+ *     variables (workspaces and tuning knobs are arguments);
  *   - return 0 on success, a negative cvar_status otherwise (never aborts across the ABI);
  *   - dtype codes: CVAR_F32 (parity mode, exact-f32 MFMA) or CVAR_BF16 (throughput mode, f32 accumulate).
  */
@@ -68,12 +69,20 @@ typedef struct {
     void* pre_act;
     const void* aux;
     const float* gate_scale;
+    /* per-call execution options (ABI 10; zero = defaults).  Nothing here is process-wide: the library keeps no mutable state
+     * and reads no environment variables.
+     *   ws, ws_bytes  optional caller-owned, 16-byte aligned device workspace for split-K: fp32 partial tiles of small-M / long-K
+     *                 GEMMs, summed in a fixed order by a second kernel that applies the epilogue.  NULL: never splits.  The caller
+     *                 must not share one workspace between streams that may run concurrently;
+     *   tile_cfg      0 automatic; 1 only 128x128 tiles; 2 the 8-wave 256x256 tile wherever it applies; 3 the 4-wave 256x256
+     *                 tile (A/B measurements - results are bit-identical across tile choices of one split-K decision);
+     *   stagger       > 0: the first workgroup of every CU starts delayed by up to this many shader cycles (by its index), which
+     *                 de-phases the output bursts of equally long tiles; 0: off.  Never changes results. */
+    void* ws; int64_t ws_bytes;
+    int tile_cfg;
+    int stagger;
 } cvar_gemm_desc;
 int cvar_gemm(const cvar_gemm_desc* d, void* stream);
-/* Optional caller-owned device workspace for split-K (fp32 partial tiles of small-M GEMMs, summed in a fixed order by a
- * second kernel that applies the epilogue).  Without it cvar_gemm never splits.  Process-wide; pass NULL to clear.
- * GEMMs that use it must be issued on ONE stream at a time. */
-int cvar_gemm_set_workspace(void* ws, int64_t bytes);
 
 /* ---------------------------------------------------------------------------------------------
  * adaLN: out[m,:] = cast( LN(x[m,:]) * (1 + scale[m / rows_per, :]) + shift[m / rows_per, :] ), LN over C with

@@ -502,6 +502,70 @@ def case_variants():
     save('gen_var_d2s_b2', keys=np.array(list(mv.state_dict().keys())), **r)
 
 
+def case_forward_d12():
+    """BASELINE config 2 anchor: the reference's teacher-forced logits at d12 width (C=768, 12 heads, 12 blocks), B=2."""
+    vae = make_vae(32)
+    cfg = VarConfig(depth=12)
+    m = make_cvar(vae, cfg)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, cfg.pyramid.L - cfg.pyramid.first_l, 32, generator=g)
+    labels, types = torch.tensor([12, 800]), torch.tensor([3, 1])
+    with torch.no_grad():
+        logits = m(labels, x, types, True)
+    t2 = logits.topk(2, dim=-1).values
+    save('forward_d12', labels=labels, types=types, logits_sample=logits[:, ::9, ::31].contiguous(), argmax=logits.argmax(-1).to(torch.int16),
+         margin=(t2[..., 0] - t2[..., 1]), lsum=logits.double().sum(-1).float(), absmax=logits.abs().amax())
+
+
+def case_generate_d12_bf16emu():
+    """BASELINE config 2: d12, bf16 weights / activations with fp32 accumulation and fp32 logits.  The reference cannot run this
+    mode on a CPU (bf16 autocast hits addmm_ dtype errors), so the trace is the ORACLE's, with its bf16 storage
+    points (oracle.vqvae_ref.Prec(True)) - the oracle itself is pinned to the reference in fp32 by every other fixture, and its fp32
+    d12 trace equals gen_d12_b2.npz.  B=8 rows: labels arange(8), types arange(8) % 4, greedy, cfg 4."""
+    from oracle import var_ref
+    from oracle.vqvae_ref import MSQuant, Prec
+    from controlvar_amd.spec import phi_index_map
+    cfg = VarConfig(depth=12)
+    sdv, sd = synth_vae_state(VaeConfig(ch=160)), synth_var_state(cfg)
+    msq = MSQuant(sdv, PN, phi_index_map(10))
+    B = 8
+    labels, types = torch.arange(B) % 1000, torch.arange(B) % 4
+    trace = {}
+    t0 = time.time()
+    with torch.no_grad():
+        var_ref.generate(sd, cfg, msq, B, labels, 4.0, top_k=1, cond_type=types, prec=Prec(True), trace=trace)
+    print(f'  oracle d12 B={B} bf16-emulated generate {time.time() - t0:.1f}s')
+    ids = torch.cat(trace['idx'], dim=1)
+    lg = torch.cat(trace['logits'], dim=1)                              # (B, L, V) CFG-combined
+    t2 = lg.topk(2, dim=-1).values
+    save('gen_d12_bf16emu', ids=ids.to(torch.int16), margin=(t2[..., 0] - t2[..., 1]), logit_samples=lg[:4, :, 5::128].contiguous(),
+         absmax_per_scale=torch.stack([t.abs().amax() for t in trace['logits']]), labels=labels, types=types)
+
+
+def case_generate_d30():
+    """BASELINE config 4: d30 (cos-attention, C=1920, 30 heads) at FULL width with the full VQVAE, B=4, cond_type=None -> the four
+    condition types [0,1,2,3] (control_var.py:387-389), cfg 4, greedy; and conditional_infer_cfg with cfg=(4,4,4) (the script
+    default, train_control_var_hpu.py:77) and c_mask from synthetic control images."""
+    vae = make_vae(160)
+    m = make_cvar(vae, VarConfig(depth=30))
+    t0 = time.time()
+    r = _run_generate(m, ref_cv, 4, torch.tensor([1, 10, 100, 999]), 4.0, cond_type=None)
+    print(f'  d30 B=4 reference generate {time.time() - t0:.1f}s')
+    save('gen_d30_b4none', **r)
+    ctrl = synth_images(2, 256, seed=4)
+    with torch.no_grad():
+        c_ids = vae.img_to_idxBl(ctrl, v_patch_nums=PN)
+    t0 = time.time()
+    r = _run_generate(m, ref_cv, 2, torch.tensor([5, 6]), (4.0, 4.0, 4.0), cond_type=torch.tensor([2, 3]), four=True, c_mask=c_ids)
+    print(f'  d30 B=2 reference conditional_infer_cfg {time.time() - t0:.1f}s')
+    save('gen_d30_cmask', c_ids=torch.cat(c_ids, dim=1).to(torch.int16), **r)
+
+
+def case_train_step_d24():
+    """BASELINE config 3 anchor: one reference training step at d24 width (C=1536, 24 blocks), B=2, tiny VQVAE for the tokens."""
+    case_train_step(VarConfig(depth=24), 'd24', 0)
+
+
 CASES = {
     'interp': case_interp,
     'tok_tiny': lambda: case_tokenizer(32, 3, 'ch32'),
@@ -524,6 +588,10 @@ CASES = {
     'sa_block': case_sa_block,
     'train_sa_block': lambda: case_train_step(VarConfig(depth=2, sa_block=True, layer_scale=0.1), 'd2sa', 7),
     'train_variants': lambda: case_train_step(VarConfig(depth=2, shared_aln=True, type_pos=True), 'd2v', 5),
+    'fwd_d12': case_forward_d12,
+    'gen_d12_bf16emu': case_generate_d12_bf16emu,
+    'gen_d30': case_generate_d30,
+    'train_d24': case_train_step_d24,
 }
 
 if __name__ == '__main__':

@@ -45,10 +45,10 @@ def make_var(vae, cfg: VarConfig, dtype, dev, seed=0):
         m = models.ControlVAR(vae, depth=cfg.depth, embed_dim=cfg.C, num_heads=cfg.H, mask_factor=cfg.mask_factor,
                               multi_cond=cfg.multi_cond, patch_nums=PN, compute_dtype=dtype, shared_aln=cfg.shared_aln,
                               type_pos=cfg.type_pos, aln=-1 if cfg.sa_block else 1, layer_scale=cfg.layer_scale,
-                              bidirectional=cfg.bidirectional, init_seed=seed)
+                              bidirectional=cfg.bidirectional, init_seed=seed, cond_drop_rate=0.0)
     else:
         m = models.VAR(vae, depth=cfg.depth, embed_dim=cfg.C, num_heads=cfg.H, patch_nums=PN, compute_dtype=dtype,
-                       shared_aln=cfg.shared_aln, init_seed=seed)
+                       shared_aln=cfg.shared_aln, init_seed=seed, cond_drop_rate=0.0)
     return m.to(dev).eval()
 
 

@@ -183,6 +183,67 @@ def test_autograd_bridge_and_loss_decreases(gpu_device):
     assert losses[-1] < losses[0] - 0.05, losses
 
 
+def test_reference_loop_with_torch_optimizer_tracks_the_weights(gpu_device):
+    """The reference's own loop - `logits = var(...)`, `loss.backward()`, `torch.optim.AdamW.step()`, `zero_grad()`
+    (train_control_var_hpu.py:207-250) - updates the parameters in place behind the model's back: the GEMM-ready packed copies and
+    the engine's transposed copies must follow (they used to go stale, so training silently did not progress).  Also
+    a manual in-place edit, and the equivalence of the path with the fused optimizer's."""
+    cfg = VarConfig(depth=2)
+    vae, m = make(cfg, torch.float32, gpu_device)
+    m.eval()
+    gen = torch.Generator().manual_seed(6)
+    B, L, fl = 2, cfg.pyramid.L, cfg.pyramid.first_l
+    x = torch.randn(B, L - fl, 32, generator=gen).to(gpu_device)
+    tg = torch.randint(0, 4096, (B, L), generator=gen).to(gpu_device)
+    cls, ty = torch.tensor([5, 999]), torch.tensor([1, 3])
+    opt = torch.optim.AdamW(m.parameters(), lr=3e-3, betas=(0.9, 0.95), weight_decay=0.0)
+    losses, logit_hist = [], []
+    for it in range(5):
+        logits = m(cls, x, ty)
+        loss = torch.nn.functional.cross_entropy(logits.view(-1, 4096), tg.view(-1))
+        loss.backward()
+        opt.step(); opt.zero_grad(set_to_none=True)
+        losses.append(loss.item()); logit_hist.append(logits.detach()[0, :4, :8].clone())
+    assert not torch.equal(logit_hist[0], logit_hist[1]) and not torch.equal(logit_hist[1], logit_hist[2])
+    assert losses[-1] < losses[0] - 0.05, losses
+    # the same five steps with the fused optimizer on a twin model land on the same loss curve (fp32 mode)
+    vae2, m2 = make(cfg, torch.float32, gpu_device)
+    m2.eval()
+    eng, fopt = T.TrainEngine(m2, drop_path=False), T.FusedAdamW(m2, lr=3e-3, weight_decay=0.0)
+    for it in range(5):
+        l2, _ = eng.forward_backward(cls, x, ty, tg)
+        fopt.step(eng.grads(), max_norm=0.0)
+        assert abs(l2.item() - losses[it]) < 2e-4 * max(1.0, abs(losses[it])), (it, l2.item(), losses[it])
+    # manual in-place edit -> the inference path sees it too
+    with torch.no_grad():
+        a = m(cls, x, ty).clone()
+        m.head.bias.add_(1.0)
+        b = m(cls, x, ty)
+    assert (b - a - 1.0).abs().max() < 1e-3
+
+
+def test_index_inputs_fail_loudly(gpu_device):
+    """labels / condition types / token ids outside their tables raise (the reference's nn.Embedding does; the gather kernels read
+    unchecked) - for host tensors and for device tensors alike."""
+    cfg = VarConfig(depth=2)
+    vae, m = make(cfg, torch.float32, gpu_device)
+    m.eval()
+    ok = dict(cfg=4.0, top_k=1, g_seed=0)
+    for bad_label in (torch.tensor([3, 1001]), torch.tensor([3, -1]), torch.tensor([3, 1001]).to(gpu_device)):
+        with pytest.raises(IndexError):
+            m.autoregressive_infer_cfg(2, bad_label, cond_type=torch.tensor([0, 1]), **ok)
+    with pytest.raises(IndexError):
+        m.autoregressive_infer_cfg(2, torch.tensor([3, 7]), cond_type=torch.tensor([0, 5]), **ok)
+    ids = [torch.zeros(2, 2 * p * p, dtype=torch.long) for p in PN]
+    ids[3][1, 5] = 4096
+    with pytest.raises(IndexError):
+        m.autoregressive_infer_cfg(2, torch.tensor([3, 7]), cond_type=torch.tensor([0, 1]), _force_idx=ids, **ok)
+    x = torch.zeros(2, cfg.pyramid.L - cfg.pyramid.first_l, 32, device=gpu_device)
+    with pytest.raises(IndexError), torch.no_grad():
+        m(torch.tensor([3, 2000]), x, torch.tensor([0, 1]))
+    m.autoregressive_infer_cfg(2, torch.tensor([1000, 0]), cond_type=torch.tensor([4, 0]), **ok)      # the boundary values are legal
+
+
 def test_resume_from_checkpoint_continues_bit_identically(gpu_device, tmp_path):
     """N1: save_checkpoint after step 2, resume into a freshly built model + optimizer, step 3 there == step 3 of the
     uninterrupted run (parameters and loss bit-identical: the kernels are deterministic and the snapshot is complete)."""
