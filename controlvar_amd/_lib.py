@@ -53,13 +53,13 @@ SIGNATURES = {
     'cvar_ignore_mask': (c_i, [c_p, c_i, c_i, c_i, C.POINTER(c_i), c_i, c_i, c_i, c_p, c_i, c_p]),
     'cvar_ln_modulate': (c_i, [c_p, c_p, c_p, c_l, c_i, c_p, c_i, c_i, c_i, c_f, c_p]),
     'cvar_silu_cast': (c_i, [c_p, c_p, c_i, c_l, c_p]),
-    'cvar_attention': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, c_p, c_p, c_p]),
-    'cvar_attention_rowwise': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, c_p, c_p, c_p]),
-    'cvar_attention_bwd': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, c_p, c_p, c_p]),
-    'cvar_attention_bwd_rowwise': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, c_p, c_p, c_p]),
+    'cvar_attention': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, C.POINTER(c_i), c_p, c_p, c_p]),
+    'cvar_attention_rowwise': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, C.POINTER(c_i), c_p, c_p, c_p]),
+    'cvar_attention_bwd': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, C.POINTER(c_i), c_p, c_p, c_p]),
+    'cvar_attention_bwd_rowwise': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, C.POINTER(c_i), c_p, c_p, c_p]),
     'cvar_cos_qk_norm': (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
     'cvar_cos_qk_norm_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
-    'cvar_cfg_sample': (c_i, [c_p, c_i, c_i, c_i, c_i, C.POINTER(c_f), c_i, c_f, C.c_uint64, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p]),
+    'cvar_cfg_sample': (c_i, [c_p, c_i, c_i, c_i, c_i, C.POINTER(c_f), c_i, c_f, C.c_uint64, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_f, c_f, c_p, c_p, c_p]),
     'cvar_ms_next_input': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'cvar_ms_encode': (c_i, [c_p, c_p, c_i, c_p, c_p, C.POINTER(c_i), C.POINTER(c_i), c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
     'cvar_word_embed': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

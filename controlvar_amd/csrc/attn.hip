@@ -7,23 +7,55 @@
 #include "cvar_common.h"
 #include <type_traits>
 
+constexpr int CVAR_ATTN_MAX_LVL = 32;
+
 struct AttnParams {
     const void* qkv;
     void* out;
     int R, H, Lmax, q_off, l;
     float scale;
     int n_lvl;
-    int lvl_end[16];
+    int lvl_end[CVAR_ATTN_MAX_LVL];
+    int hole_lo[CVAR_ATTN_MAX_LVL], hole_hi[CVAR_ATTN_MAX_LVL];     // per level: keys [lo, hi) are invisible to its queries (empty: lo = hi = INT_MAX)
     float* lse;          // optional [R][H][l] log-sum-exp of the scaled scores (saved for the backward pass)
 };
 
-__device__ __forceinline__ int kv_len_of(const AttnParams& p, int pos) {
-    if (p.n_lvl == 0) return p.q_off + p.l;
-    int e = p.lvl_end[p.n_lvl - 1];
-    for (int k = p.n_lvl - 1; k >= 0; --k)
-        if (pos < p.lvl_end[k]) e = p.lvl_end[k];
-    return e;
+// Visibility of one query: keys [0, kvlen) minus the hole [hlo, hhi).  The prefix is the block-causal level mask of training
+// (control_var.py:158-168) or, with half-scale levels, of separate_decoding (:170-180); the hole is the `indep` variant, where the image
+// half of a scale does not see the control half of the same scale (:182-191).  Both bounds are non-decreasing in the query position.
+struct Vis { int kvlen, hlo, hhi; };
+template <typename P>
+__device__ __forceinline__ Vis vis_of(const P& p, int pos) {
+    Vis v;
+    if (p.n_lvl == 0) { v.kvlen = p.q_off + p.l; v.hlo = v.hhi = 0x7fffffff; return v; }
+    int k = p.n_lvl - 1;
+    for (int i = p.n_lvl - 1; i >= 0; --i)
+        if (pos < p.lvl_end[i]) k = i;
+    v.kvlen = p.lvl_end[k]; v.hlo = p.hole_lo[k]; v.hhi = p.hole_hi[k];
+    return v;
 }
+__device__ __forceinline__ bool vis_key(const Vis& v, int key) { return key < v.kvlen && !(key >= v.hlo && key < v.hhi); }
+__device__ __forceinline__ int vis_full_prefix(const Vis& v) { return min(v.kvlen, v.hlo); }       // keys below this are all visible
+
+// keys below the returned bound are visible to EVERY query at positions [pos_lo, pos_hi]: the minimum of min(end, hole start) over the
+// levels the range touches (not monotone in the position: a control half ends after the hole of the image half that follows it)
+template <typename P>
+__device__ __forceinline__ int range_full_prefix(const P& p, int pos_lo, int pos_hi) {
+    if (p.n_lvl == 0) return p.q_off + p.l;
+    int best = 0x7fffffff, begin = 0;
+    for (int i = 0; i < p.n_lvl; ++i) {
+        const int end = p.lvl_end[i];
+        const bool last = i == p.n_lvl - 1;
+        if (pos_lo < end || last) {                       // level i holds positions [begin, end) (the last level also everything behind it)
+            if (pos_hi >= begin || last) best = min(best, min(end, p.hole_lo[i]));
+        }
+        begin = end;
+        if (pos_hi < end) break;
+    }
+    return best;
+}
+
+__device__ __forceinline__ int kv_len_of(const AttnParams& p, int pos) { return vis_of(p, pos).kvlen; }
 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p) {
@@ -39,7 +71,7 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p) {
     const int qi = blockIdx.x * 256 + tid;
     const bool valid = qi < p.l;
     const int pos = p.q_off + (valid ? qi : p.l - 1);
-    const int kvlen = kv_len_of(p, pos);
+    const Vis vis = vis_of(p, pos);
     const int last_q = min(p.l, (int)(blockIdx.x + 1) * 256) - 1;
     const int kv_end = kv_len_of(p, p.q_off + last_q);          // monotone in pos -> block maximum
 
@@ -78,7 +110,7 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p) {
                 a = fmaf(q[d], kv[0], a); a = fmaf(q[d + 1], kv[1], a);
                 a = fmaf(q[d + 2], kv[2], a); a = fmaf(q[d + 3], kv[3], a);
             }
-            s[kk] = (kt0 + kk < kvlen) ? a : -INFINITY;
+            s[kk] = vis_key(vis, kt0 + kk) ? a : -INFINITY;
             tmax = fmaxf(tmax, s[kk]);
         }
         if (tmax > -INFINITY) {
@@ -115,13 +147,33 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p) {
 __global__ void attn_mfma_bf16_kernel(const AttnParams p);
 
 // impl: 0 = auto (MFMA flash kernel for bf16, row-wise exact kernel for fp32), 1 = row-wise
+template <typename P>
+static int fill_levels(P& p, const int* lvl_end_host, int n_lvl, const int* hole_host) {
+    if (n_lvl < 0 || n_lvl > CVAR_ATTN_MAX_LVL || (n_lvl > 0 && !lvl_end_host)) return CVAR_EINVAL;
+    p.n_lvl = n_lvl;
+    int prev = 0;
+    for (int i = 0; i < CVAR_ATTN_MAX_LVL; ++i) {
+        p.lvl_end[i] = i < n_lvl ? lvl_end_host[i] : 0;
+        p.hole_lo[i] = p.hole_hi[i] = 0x7fffffff;
+        if (i < n_lvl) {
+            if (p.lvl_end[i] <= prev) return CVAR_EINVAL;                   // strictly increasing level ends
+            if (hole_host && hole_host[2 * i + 1] > hole_host[2 * i]) {
+                // a hole lies inside the keys its level sees and in front of the level's own tokens (they always see themselves)
+                if (hole_host[2 * i] < 0 || hole_host[2 * i + 1] > prev) return CVAR_EINVAL;
+                p.hole_lo[i] = hole_host[2 * i]; p.hole_hi[i] = hole_host[2 * i + 1];
+            }
+            prev = p.lvl_end[i];
+        }
+    }
+    return CVAR_OK;
+}
+
 static int cvar_attention_impl(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
-                               const int* lvl_end_host, int n_lvl, void* out, float* lse, void* stream, int impl) {
+                               const int* lvl_end_host, int n_lvl, const int* hole_host, void* out, float* lse, void* stream, int impl) {
     if (!qkv || !out || R <= 0 || H <= 0 || l <= 0 || q_off < 0 || q_off + l > Lmax) return CVAR_EINVAL;
-    if (n_lvl < 0 || n_lvl > 16 || (n_lvl > 0 && !lvl_end_host)) return CVAR_EINVAL;
     AttnParams p;
-    p.qkv = qkv; p.out = out; p.R = R; p.H = H; p.Lmax = Lmax; p.q_off = q_off; p.l = l; p.scale = scale; p.n_lvl = n_lvl; p.lse = lse;
-    for (int i = 0; i < 16; ++i) p.lvl_end[i] = i < n_lvl ? lvl_end_host[i] : 0;
+    p.qkv = qkv; p.out = out; p.R = R; p.H = H; p.Lmax = Lmax; p.q_off = q_off; p.l = l; p.scale = scale; p.lse = lse;
+    { const int rc = fill_levels(p, lvl_end_host, n_lvl, hole_host); if (rc != CVAR_OK) return rc; }
     if (dtype == CVAR_BF16 && impl == 0) {
         hipLaunchKernelGGL(attn_mfma_bf16_kernel, dim3(cdiv(l, 128), H, R), dim3(256), 0, as_stream(stream), p);
         CVAR_CHECK_LAUNCH();
@@ -166,8 +218,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int q0 = blockIdx.x * 128 + w * 32;
     const int qi = q0 + lrow;
     const int qrow = min(qi, p.l - 1);
-    const int kvlen = kv_len_of(p, p.q_off + qrow);
-    const int wave_min_kv = kv_len_of(p, p.q_off + min(q0, p.l - 1));
+    const Vis vis = vis_of(p, p.q_off + qrow);
     const int kv_end = kv_len_of(p, p.q_off + min(p.l, (int)(blockIdx.x + 1) * 128) - 1);
 
     bf16x8_t qf[4];
@@ -238,7 +289,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int i = 0; i < 16; ++i) {
                 if constexpr (decltype(MASK)::value) {
                     const int key = kt0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hi;
-                    if (key >= kvlen) s[kb][i] = -INFINITY;
+                    if (!vis_key(vis, key)) s[kb][i] = -INFINITY;
                 }
                 tmax = fmaxf(tmax, s[kb][i]);
             }
@@ -287,7 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     int kt0 = 0;
     // wave_min_kv is wave-uniform per construction but tiles are shared by the workgroup (barriers inside): the split point
     // must be the same for all four waves, so it is taken over the workgroup's first query
-    const int wg_min_kv = kv_len_of(p, p.q_off + min((int)blockIdx.x * 128, p.l - 1));
+    const int wg_min_kv = range_full_prefix(p, p.q_off + min((int)blockIdx.x * 128, p.l - 1), p.q_off + min(p.l, (int)(blockIdx.x + 1) * 128) - 1);
     for (; kt0 + KT <= wg_min_kv && kt0 < kv_end; kt0 += KT) tile(kt0, MaskOff{});
     for (; kt0 < kv_end; kt0 += KT) tile(kt0, MaskOn{});
     lsum += __shfl_xor(lsum, 32, 64);
@@ -308,12 +359,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 extern "C" int cvar_attention_rowwise(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
-                                      const int* lvl_end_host, int n_lvl, void* out, float* lse, void* stream) {
-    return cvar_attention_impl(qkv, dtype, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, out, lse, stream, 1);
+                                      const int* lvl_end_host, int n_lvl, const int* hole_host, void* out, float* lse, void* stream) {
+    return cvar_attention_impl(qkv, dtype, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, hole_host, out, lse, stream, 1);
 }
 extern "C" int cvar_attention(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
-                              const int* lvl_end_host, int n_lvl, void* out, float* lse, void* stream) {
-    return cvar_attention_impl(qkv, dtype, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, out, lse, stream, 0);
+                              const int* lvl_end_host, int n_lvl, const int* hole_host, void* out, float* lse, void* stream) {
+    return cvar_attention_impl(qkv, dtype, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, hole_host, out, lse, stream, 0);
 }
 
 // ================================================================================================
@@ -328,15 +379,10 @@ struct AttnBwdParams {
     int R, H, Lmax, q_off, l;
     float scale;
     int n_lvl;
-    int lvl_end[16];
+    int lvl_end[CVAR_ATTN_MAX_LVL];
+    int hole_lo[CVAR_ATTN_MAX_LVL], hole_hi[CVAR_ATTN_MAX_LVL];
 };
-__device__ __forceinline__ int kv_len_of_b(const AttnBwdParams& p, int pos) {
-    if (p.n_lvl == 0) return p.q_off + p.l;
-    int e = p.lvl_end[p.n_lvl - 1];
-    for (int k = p.n_lvl - 1; k >= 0; --k)
-        if (pos < p.lvl_end[k]) e = p.lvl_end[k];
-    return e;
-}
+__device__ __forceinline__ int kv_len_of_b(const AttnBwdParams& p, int pos) { return vis_of(p, pos).kvlen; }
 // first query position (relative to q_off) that can see key position `key`
 __device__ __forceinline__ int first_query_of(const AttnBwdParams& p, int key) {
     if (p.n_lvl == 0) return 0;
@@ -375,7 +421,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
     const bool valid = qi < p.l;
     const int qrow = valid ? qi : p.l - 1;
     const int pos = p.q_off + qrow;
-    const int kvlen = kv_len_of_b(p, pos);
+    const Vis vis = vis_of(p, pos);
+    const int kvlen = vis.kvlen;
     const int kv_end = kv_len_of_b(p, p.q_off + min(p.l, (int)(blockIdx.x + 1) * 256) - 1);
     float q[D], dO[D], dq[D];
     {
@@ -402,7 +449,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
         }
         __syncthreads();
         for (int kk = 0; kk < KT; ++kk) {
-            if (kt0 + kk >= kvlen) break;                 // keys are visible as a prefix
+            if (kt0 + kk >= kvlen) break;                 // keys are visible as a prefix ...
+            if (kt0 + kk >= vis.hlo && kt0 + kk < vis.hhi) continue;      // ... minus the level's hole
             float s = 0.f, dp = 0.f;
 #pragma unroll
             for (int d = 0; d < D; d += 4) {
@@ -436,7 +484,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
     __shared__ __attribute__((aligned(16))) float Qs[QT][D];
     __shared__ __attribute__((aligned(16))) float Os[QT][D];
     __shared__ float Ls[QT], Ds[QT];
-    __shared__ int Kv[QT];
+    __shared__ int Kv[QT], Hlo[QT], Hhi[QT];
     const int tid = threadIdx.x, h = blockIdx.y;
     const long r = blockIdx.z;
     const int C3 = 3 * p.H * D;
@@ -472,11 +520,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
             const bool ok = qi < p.l;
             Ls[tid] = ok ? p.lse[(r * p.H + h) * (long)p.l + qi] : 0.f;
             Ds[tid] = ok ? p.dsum[(r * p.H + h) * (long)p.l + qi] : 0.f;
-            Kv[tid] = ok ? kv_len_of_b(p, p.q_off + qi) : 0;
+            const Vis vq = vis_of(p, p.q_off + (ok ? qi : 0));
+            Kv[tid] = ok ? vq.kvlen : 0; Hlo[tid] = vq.hlo; Hhi[tid] = vq.hhi;
         }
         __syncthreads();
         for (int qq = 0; qq < QT; ++qq) {
-            if (krow >= Kv[qq]) continue;                  // query does not see this key (or is padding)
+            if (krow >= Kv[qq] || (krow >= Hlo[qq] && krow < Hhi[qq])) continue;      // query does not see this key (or is padding)
             float s = 0.f, dp = 0.f;
 #pragma unroll
             for (int d = 0; d < D; d += 4) {
@@ -510,13 +559,13 @@ __global__ void attn_bwd_dkv_mfma_kernel(const AttnBwdParams p);
 
 // ws: R*H*l floats (D = rowsum(dO * O)).  impl: 0 = auto (MFMA kernels for bf16, row-wise exact kernels for fp32), 1 = row-wise
 static int cvar_attention_bwd_impl(const void* qkv, int dtype, const void* o, const void* dout, const float* lse, int R, int H, int Lmax,
-                                   int q_off, int l, float scale, const int* lvl_end_host, int n_lvl, void* dqkv, float* ws, void* stream, int impl) {
+                                   int q_off, int l, float scale, const int* lvl_end_host, int n_lvl, const int* hole_host, void* dqkv, float* ws,
+                                   void* stream, int impl) {
     if (!qkv || !o || !dout || !lse || !dqkv || !ws || R <= 0 || H <= 0 || l <= 0 || q_off != 0 || l > Lmax) return CVAR_EINVAL;
-    if (n_lvl < 0 || n_lvl > 16 || (n_lvl > 0 && !lvl_end_host)) return CVAR_EINVAL;
     AttnBwdParams p;
     p.qkv = qkv; p.o = o; p.dout = dout; p.lse = lse; p.dsum = ws; p.dqkv = dqkv;
-    p.R = R; p.H = H; p.Lmax = Lmax; p.q_off = q_off; p.l = l; p.scale = scale; p.n_lvl = n_lvl;
-    for (int i = 0; i < 16; ++i) p.lvl_end[i] = i < n_lvl ? lvl_end_host[i] : 0;
+    p.R = R; p.H = H; p.Lmax = Lmax; p.q_off = q_off; p.l = l; p.scale = scale;
+    { const int rc = fill_levels(p, lvl_end_host, n_lvl, hole_host); if (rc != CVAR_OK) return rc; }
     const long tot = (long)R * l * H;
     hipStream_t st = as_stream(stream);
     if (dtype == CVAR_BF16) {
@@ -596,8 +645,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int q0 = blockIdx.x * 128 + w * 32;
     const int qi = q0 + lrow;
     const int qrow = min(qi, p.l - 1);
-    const int kvlen = kv_len_of_b(p, p.q_off + qrow);
-    const int wave_min_kv = kv_len_of_b(p, p.q_off + min(q0, p.l - 1));
+    const Vis vis = vis_of(p, p.q_off + qrow);
+    const int wave_min_kv = range_full_prefix(p, p.q_off + min(q0, p.l - 1), p.q_off + min(q0 + 31, p.l - 1));
     const int kv_end = kv_len_of_b(p, p.q_off + min(p.l, (int)(blockIdx.x + 1) * 128) - 1);
     bf16x8_t qf[4], of[4];
     {
@@ -647,7 +696,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], c2, -lse2));
                     if (need_mask) {
                         const int key = kt0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hi;
-                        if (key >= kvlen) pr = 0.f;
+                        if (!vis_key(vis, key)) pr = 0.f;
                     }
                     ds[j] = pr * (dp[kb][i] - Dq);
                 }
@@ -685,6 +734,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdPar
     __shared__ __attribute__((aligned(16))) float Ls[QT];
     __shared__ __attribute__((aligned(16))) float Dsum[QT];
     __shared__ __attribute__((aligned(16))) int Kv[QT];
+    __shared__ __attribute__((aligned(16))) int Hlo[QT];
+    __shared__ __attribute__((aligned(16))) int Hhi[QT];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lrow = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
     const int h = blockIdx.y;
@@ -721,7 +772,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdPar
             const bool ok = qi < p.l;
             Ls[tid] = ok ? p.lse[(r * p.H + h) * (long)p.l + qi] * 1.4426950408889634f : 0.f;
             Dsum[tid] = ok ? p.dsum[(r * p.H + h) * (long)p.l + qi] : 0.f;
-            Kv[tid] = ok ? kv_len_of_b(p, p.q_off + qi) : 0;
+            const Vis vq = vis_of(p, p.q_off + (ok ? qi : 0));
+            Kv[tid] = ok ? vq.kvlen : 0; Hlo[tid] = vq.hlo; Hhi[tid] = vq.hhi;
         }
         __syncthreads();
 #pragma unroll
@@ -748,12 +800,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdPar
                     const f32x4_t l4 = *(const f32x4_t*)&Ls[qloc];
                     const f32x4_t d4 = *(const f32x4_t*)&Dsum[qloc];
                     const int4 k4 = *(const int4*)&Kv[qloc];
+                    const int4 l4i = *(const int4*)&Hlo[qloc];
+                    const int4 h4i = *(const int4*)&Hhi[qloc];
                     const int kvl[4] = {k4.x, k4.y, k4.z, k4.w};
+                    const int hlo4[4] = {l4i.x, l4i.y, l4i.z, l4i.w}, hhi4[4] = {h4i.x, h4i.y, h4i.z, h4i.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int i = 4 * g + e;
                         float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c2, -l4[e]));
-                        if (krow >= kvl[e]) pr = 0.f;
+                        if (krow >= kvl[e] || (krow >= hlo4[e] && krow < hhi4[e])) pr = 0.f;
                         pv[4 * g2 + e] = pr;
                         dsv[4 * g2 + e] = pr * (dp[i] - d4[e]);
                     }
@@ -789,10 +844,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdPar
 }
 
 extern "C" int cvar_attention_bwd_rowwise(const void* qkv, int dtype, const void* o, const void* dout, const float* lse, int R, int H, int Lmax,
-                                          int q_off, int l, float scale, const int* lvl_end_host, int n_lvl, void* dqkv, float* ws, void* stream) {
-    return cvar_attention_bwd_impl(qkv, dtype, o, dout, lse, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, dqkv, ws, stream, 1);
+                                          int q_off, int l, float scale, const int* lvl_end_host, int n_lvl, const int* hole_host, void* dqkv,
+                                          float* ws, void* stream) {
+    return cvar_attention_bwd_impl(qkv, dtype, o, dout, lse, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, hole_host, dqkv, ws, stream, 1);
 }
 extern "C" int cvar_attention_bwd(const void* qkv, int dtype, const void* o, const void* dout, const float* lse, int R, int H, int Lmax,
-                                  int q_off, int l, float scale, const int* lvl_end_host, int n_lvl, void* dqkv, float* ws, void* stream) {
-    return cvar_attention_bwd_impl(qkv, dtype, o, dout, lse, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, dqkv, ws, stream, 0);
+                                  int q_off, int l, float scale, const int* lvl_end_host, int n_lvl, const int* hole_host, void* dqkv, float* ws,
+                                  void* stream) {
+    return cvar_attention_bwd_impl(qkv, dtype, o, dout, lse, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, hole_host, dqkv, ws, stream, 0);
 }

@@ -19,6 +19,14 @@ struct SampleParams {
     float* combined;
     float* margin;
     int* kept;
+    int ldv;                                // row stride of `logits` in floats (>= V: a wider head whose first V columns are the codes)
+    // more_smooth (control_var.py:511-515; helpers.py:22-36): soft code embedding of the top-k / top-p MASKED logits
+    //   soft_out[(d*B + b)][t][:] = softmax_v( (lg_v * smooth_mul + g_v) / smooth_tau ) . codebook[v][:]      over the kept v
+    const float* codebook;                  // [V][Cvae] fp32; NULL: no soft output
+    int Cvae;
+    float smooth_mul, smooth_tau;
+    const float* gumbel;                    // optional injected Gumbel noise [n_draw*B][l][V] (tests); NULL: drawn from the counter generator
+    float* soft_out;
 };
 
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
@@ -34,8 +42,8 @@ __device__ __forceinline__ float uniform01(unsigned long long seed, int stage, l
 }
 
 __device__ __forceinline__ float combine_logits(const SampleParams& p, long b, long t, int e) {
-    const long rowstride = (long)p.l * p.V;
-    const float* base = p.logits + (b * p.l + t) * p.V + e;
+    const long rowstride = (long)p.l * p.ldv;
+    const float* base = p.logits + (b * p.l + t) * p.ldv + e;
     float v = __fmul_rn(p.coef[0], base[0]);
     for (int r = 1; r < p.nrep; ++r) v = __fadd_rn(v, __fmul_rn(p.coef[r], base[(long)r * p.B * rowstride]));
     return v;
@@ -261,14 +269,85 @@ __global__ __launch_bounds__(256) void cfg_sample_kernel(const SampleParams p) {
             p.idx_out[((long)d * p.B + b) * p.l + t] = pick;
         }
     }
+    if (p.soft_out) {
+        // Gumbel-softmax over the KEPT logits (the reference masks `logits` in place before it calls gumbel_softmax_with_rng), then the
+        // expectation of the code vectors under it.  One pass per draw row: the reference draws fresh noise for every replicated row.
+        __shared__ float red[4];
+        __shared__ float accs[4][32];
+        for (int d = 0; d < p.n_draw; ++d) {
+            const long row = (long)d * p.B + b;
+            float z[EPT];
+            float zmax = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const int e = i * 256 + tid;
+                z[i] = -INFINITY;
+                if (e < p.V && key[i] >= thr) {
+                    float g;
+                    if (p.gumbel) g = p.gumbel[(row * p.l + t) * (long)p.V + e];
+                    else {
+                        unsigned long long h = splitmix64((p.seed + (p.seed_dev ? p.seed_dev[0] : 0ull)) ^ 0x5EEDF00D77ull);
+                        h = splitmix64(h ^ ((unsigned long long)p.stage << 52) ^ ((unsigned long long)row << 28) ^ ((unsigned long long)t << 12) ^ (unsigned long long)e);
+                        const float u = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);          // (0, 1)
+                        g = -__logf(-__logf(u));                                                 // -log(Exp(1) sample)
+                    }
+                    z[i] = (v[i] * p.smooth_mul + g) / p.smooth_tau;
+                    zmax = fmaxf(zmax, z[i]);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, o, 64));
+            __syncthreads();
+            if ((tid & 63) == 0) red[tid >> 6] = zmax;
+            __syncthreads();
+            zmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            float acc[32];
+#pragma unroll
+            for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+            float wsum = 0.f;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                const float w = z[i] > -INFINITY ? __expf(z[i] - zmax) : 0.f;
+                if (w > 0.f) {
+                    wsum += w;
+                    const float* er = p.codebook + (long)(i * 256 + tid) * p.Cvae;
+                    for (int c = 0; c < p.Cvae; ++c) acc[c] = fmaf(w, er[c], acc[c]);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                wsum += __shfl_xor(wsum, o, 64);
+#pragma unroll
+                for (int c = 0; c < 32; ++c) acc[c] += __shfl_xor(acc[c], o, 64);
+            }
+            __syncthreads();
+            if ((tid & 63) == 0) {
+                red[tid >> 6] = wsum;
+                for (int c = 0; c < p.Cvae; ++c) accs[tid >> 6][c] = acc[c];
+            }
+            __syncthreads();
+            if (tid < p.Cvae) {
+                const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+                const float a = (accs[0][tid] + accs[1][tid]) + (accs[2][tid] + accs[3][tid]);
+                p.soft_out[(row * p.l + t) * (long)p.Cvae + tid] = a / tot;
+            }
+        }
+    }
 }
 
 extern "C" int cvar_cfg_sample(const float* logits, int B, int nrep, int l, int V, const float* coef_host,
                                int top_k, float top_p, uint64_t seed, const uint64_t* seed_dev, int stage, int n_draw,
-                               int32_t* idx_out, float* combined, float* margin, int32_t* kept, void* stream) {
+                               int32_t* idx_out, float* combined, float* margin, int32_t* kept, int ldv,
+                               const float* codebook, int Cvae, float smooth_mul, float smooth_tau, const float* gumbel, float* soft_out,
+                               void* stream) {
     if (!logits || !coef_host || !idx_out || B <= 0 || l <= 0 || V <= 1) return CVAR_EINVAL;
     if (nrep < 1 || nrep > 4 || n_draw < 1 || n_draw > 4 || V > 4096) return CVAR_EUNSUPPORTED;
+    if (ldv != 0 && ldv < V) return CVAR_EINVAL;
+    if (soft_out && (!codebook || Cvae < 1 || Cvae > 32 || !(smooth_tau > 0.f))) return CVAR_EINVAL;
+    if (soft_out && top_k == 1) return CVAR_EUNSUPPORTED;          // greedy: the masked softmax is one-hot, the soft embedding IS codebook[idx]
     SampleParams p;
+    p.ldv = ldv ? ldv : V;
+    p.codebook = codebook; p.Cvae = Cvae; p.smooth_mul = smooth_mul; p.smooth_tau = smooth_tau; p.gumbel = gumbel; p.soft_out = soft_out;
     p.logits = logits; p.B = B; p.nrep = nrep; p.l = l; p.V = V;
     for (int i = 0; i < 4; ++i) p.coef[i] = i < nrep ? coef_host[i] : 0.f;
     p.top_k = top_k; p.top_p = top_p; p.seed = seed; p.seed_dev = (const unsigned long long*)seed_dev; p.stage = stage; p.n_draw = n_draw;

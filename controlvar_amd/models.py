@@ -20,7 +20,7 @@ import torch.nn as nn
 from . import ops
 from ._lib import ACT_GELU_TANH
 from .pyramid import packed_tables
-from .spec import DEFAULT_PATCH_NUMS, VaeConfig, VarConfig, vae_state_shapes, var_state_shapes
+from .spec import DEFAULT_PATCH_NUMS, VaeConfig, VarConfig, attention_levels, vae_state_shapes, var_state_shapes
 from .synth import synth_vae_state, synth_var_state
 
 
@@ -288,28 +288,61 @@ class VQVAE(nn.Module):
             o += n
         return outs
 
-    def _ms_encode(self, f: torch.Tensor, want_fhat=False, want_margin=False):
+    def _scale_tables(self, v_patch_nums):
+        """operator tables + phi map of a caller-chosen scale list (vqvae.py:73-75 passes v_patch_nums through to
+        f_to_idxBl_or_fhat, quant.py:184-215, which accepts any list ending at the latent size; phi by the nearest-tick rule :282-290)"""
+        P = self._pack()
+        pns = tuple(int(p[0] if isinstance(p, (tuple, list)) else p) for p in v_patch_nums)
+        if any(isinstance(p, (tuple, list)) and p[0] != p[1] for p in v_patch_nums):
+            raise NotImplementedError('non-square scales (ph != pw) are not built')
+        if pns == tuple(self.cfg.patch_nums):
+            return pns, P['up'], P['down'], P['phi_map']
+        if pns[-1] != self.cfg.patch_nums[-1]:
+            raise AssertionError(f'patch_hws[-1]={pns[-1]} != latent size {self.cfg.patch_nums[-1]}')          # quant.py:193
+        if len(pns) > 16:
+            raise NotImplementedError('at most 16 scales')
+        cache = P.setdefault('alt_tables', {})
+        if pns not in cache:
+            from .spec import phi_index_map
+            up, down, _ = packed_tables(pns)
+            cache[pns] = (torch.from_numpy(up).to(self.device), torch.from_numpy(down).to(self.device), phi_index_map(len(pns), self.cfg.share_quant_resi))
+        up, down, pm = cache[pns]
+        return pns, up, down, pm
+
+    def _ms_encode(self, f: torch.Tensor, want_fhat=False, want_margin=False, v_patch_nums=None):
         P = self._pack()
         B = f.shape[0]
-        pns = self.cfg.patch_nums
+        pns, up, down, phi_map = self._scale_tables(v_patch_nums) if v_patch_nums is not None else (self.cfg.patch_nums, P['up'], P['down'], P['phi_map'])
         Ltot = sum(p * p for p in pns)
         idx = torch.empty(B, Ltot, device=f.device, dtype=torch.int32)
         fh = torch.empty_like(f) if want_fhat else None
         mg = torch.empty(B, Ltot, device=f.device, dtype=torch.float32) if want_margin else None
-        ops.ms_encode(f.contiguous(), P['E'], self.V, P['phi_w'], P['phi_b'], P['phi_map'], list(pns), P['up'], P['down'], idx, fh, mg,
+        ops.ms_encode(f.contiguous(), P['E'], self.V, P['phi_w'], P['phi_b'], phi_map, list(pns), up, down, idx, fh, mg,
                       B, pns[-1], self.Cvae)
         return idx, fh, mg
 
-    def _next_input(self, si: int, idx: torch.Tensor, f_hat: torch.Tensor, nb: int, nmaps: int, want_tok: bool):
-        """one scale step for all (nb, nmaps) maps: f_hat updated in place, returns tokens of the next scale or None"""
+    def _next_input(self, si: int, idx: torch.Tensor, f_hat: torch.Tensor, nb: int, nmaps: int, want_tok: bool, soft: Optional[torch.Tensor] = None,
+                    pn_next: Optional[int] = None):
+        """one scale step for all (nb, nmaps) maps: f_hat updated in place, returns tokens of the next scale or None.
+        soft: (nb, nmaps*pn*pn, Cvae) embeddings used INSTEAD of E[idx] (more_smooth, control_var.py:511-515) - they are handed to the
+        kernel as a one-off codebook addressed by the identity index.  pn_next: pool the updated map to this size instead of the next
+        scale's (the control pass of separate_decoding feeds area(f_hat -> the SAME scale), control_var.py:467-468)."""
         P = self._pack()
         pns = self.cfg.patch_nums
         pn = pns[si]
         last = si == len(pns) - 1
-        pn_next = pns[si + 1] if not last else pn
-        tok = torch.empty(nb, nmaps * pn_next * pn_next, self.Cvae, device=f_hat.device, dtype=torch.float32) if (want_tok and not last) else None
-        ops.ms_next_input(idx, P['E'], P['phi_w'], P['phi_b'], P['up'], P['down'], f_hat, tok, nb, nmaps, pn, pn_next, pns[-1], self.Cvae,
-                          P['phi_map'][si], P['tab_off'][si], P['tab_off'][si + 1] if not last else 0)
+        explicit = pn_next is not None
+        if not explicit:
+            pn_next = pns[si + 1] if not last else pn
+        codebook = P['E']
+        if soft is not None:
+            codebook = soft.reshape(-1, self.Cvae).float().contiguous()
+            idx = torch.arange(codebook.shape[0], device=f_hat.device, dtype=torch.int32).view(nb, -1)
+        make_tok = want_tok and (explicit or not last)
+        tok = torch.empty(nb, nmaps * pn_next * pn_next, self.Cvae, device=f_hat.device, dtype=torch.float32) if make_tok else None
+        down_off = P['tab_off'][pns.index(pn_next)] if make_tok else 0
+        ops.ms_next_input(idx, codebook, P['phi_w'], P['phi_b'], P['up'], P['down'], f_hat, tok, nb, nmaps, pn, pn_next, pns[-1], self.Cvae,
+                          P['phi_map'][si], P['tab_off'][si], down_off)
         return tok
 
     # ---- public API (same names / meaning as models/vqvae.py)
@@ -317,10 +350,13 @@ class VQVAE(nn.Module):
     def img_to_idxBl(self, inp_img_no_grad: torch.Tensor, v_patch_nums=None) -> List[torch.Tensor]:
         """vqvae.py:73-75 -> list of (B, pn*pn) int64 ids, coarse to fine"""
         self._pack(check=True)
-        if v_patch_nums is not None and tuple(v_patch_nums) != tuple(self.cfg.patch_nums):
-            raise NotImplementedError('v_patch_nums must equal the constructor patch_nums')
-        idx, _, _ = self._ms_encode(self._encode_f(inp_img_no_grad))
-        return [t.long() for t in self._split(idx)]
+        idx, _, _ = self._ms_encode(self._encode_f(inp_img_no_grad), v_patch_nums=v_patch_nums)
+        pns = self._scale_tables(v_patch_nums)[0] if v_patch_nums is not None else self.cfg.patch_nums
+        outs, o = [], 0
+        for pn in pns:
+            outs.append(idx[:, o:o + pn * pn].long())
+            o += pn * pn
+        return outs
 
     @torch.no_grad()
     def idxBl_to_h(self, gt_ms_idx_Bl: List[torch.Tensor]) -> List[torch.Tensor]:
@@ -370,9 +406,11 @@ class VQVAE(nn.Module):
     def img_to_recon(self, x, v_patch_nums=None, last_one=False):
         """vqvae.py:80-86"""
         self._pack(check=True)
-        idx, fh, _ = self._ms_encode(self._encode_f(x), want_fhat=True)
+        idx, fh, _ = self._ms_encode(self._encode_f(x), want_fhat=True, v_patch_nums=v_patch_nums)
         if last_one:
             return self._decode(fh, lo=-3.0e38, hi=3.0e38)
+        if v_patch_nums is not None and tuple(self._scale_tables(v_patch_nums)[0]) != tuple(self.cfg.patch_nums):
+            raise NotImplementedError('per-scale reconstructions are built for the constructor scale list; pass last_one=True for another list')
         return self._recon_all(idx)
 
     def _recon_all(self, idx):
@@ -400,7 +438,10 @@ class ControlVAR(nn.Module):
     and ``type_pos`` for inference, forward and training (both fold into tables at pack time, no extra kernel).
     ``aln < 0`` (SABlock: affine LayerNorms + layer scale, basic_var.py:128-176) is likewise folded into the adaLN layout.
     ``bidirectional`` (image-first order, mask_first=False) swaps the first two tokens and the type ids.
-    separator / separate_decoding / indep raise NotImplementedError.
+    ``separate_decoding`` (control half of a scale decoded before its image half; with ``indep`` the halves are blind to each other):
+    masks as (level end, hole) tables of the attention kernels, the two-pass inference branch, and the mask applied at inference for
+    ``indep``.  ``indep`` defaults to True as upstream's class does (a no-op without separate_decoding); the factory passes False.
+    ``more_smooth`` = Gumbel-softmax soft code embeddings.  ``separator`` raises: upstream cannot run it either.
     """
     _control = True
 
@@ -408,11 +449,14 @@ class ControlVAR(nn.Module):
                  cond_drop_rate=0.1, depth=16, embed_dim=1024, num_heads=16, mlp_ratio=4., drop_rate=0., attn_drop_rate=0.,
                  drop_path_rate=0., layer_scale=-1., tau=4, cos_attn=False, patch_nums=DEFAULT_PATCH_NUMS,
                  flash_if_available=True, fused_if_available=True, mask_factor=2, bidirectional=False, separate_decoding=False,
-                 separator=False, type_pos=False, indep=False, multi_cond=False,
+                 separator=False, type_pos=False, indep=True, multi_cond=False,
                  compute_dtype=None, init_seed: int = 0):
         super().__init__()
-        if separator or separate_decoding or indep:
-            raise NotImplementedError('separator / separate_decoding / indep variants (SURVEY.md 8f N4) are not built')
+        if separator:
+            raise NotImplementedError('separator (SURVEY.md 8f N4): upstream raises IndexError in forward() and in every inference branch '
+                                      '(special_embed is indexed with V + k, control_var.py:549,606) - not built')
+        if separate_decoding and not (self._control and mask_factor == 2):
+            raise NotImplementedError('separate_decoding needs the joint (control, image) sequence')
         if bidirectional and not (self._control and mask_factor == 2):
             raise NotImplementedError('bidirectional needs the joint (control, image) sequence')
         sa_block = aln < 0                                           # control_var.py:41: using_aln = aln >= 0
@@ -427,7 +471,9 @@ class ControlVAR(nn.Module):
                              num_classes=num_classes, embed_dim=embed_dim, num_heads=num_heads, norm_eps=norm_eps, tau=float(tau),
                              cos_attn=bool(cos_attn), mlp_ratio=mlp_ratio, cond_drop_rate=cond_drop_rate, drop_path_rate=float(drop_path_rate),
                              shared_aln=bool(shared_aln) and not sa_block, type_pos=bool(type_pos), sa_block=sa_block,
-                             layer_scale=float(layer_scale) if sa_block else -1.0, bidirectional=bool(bidirectional))
+                             layer_scale=float(layer_scale) if sa_block else -1.0, bidirectional=bool(bidirectional),
+                             separate_decoding=bool(separate_decoding), indep=bool(indep) and self._control and mask_factor == 2)
+        self.separate_decoding, self.indep, self.separator, self.type_pos = self.cfg.separate_decoding, bool(indep), False, self.cfg.type_pos
         cfg = self.cfg
         self.bidirectional = cfg.bidirectional
         self.Cvae, self.V = cfg.cvae, cfg.vocab
@@ -559,7 +605,7 @@ class ControlVAR(nn.Module):
         return self._arena[1]
 
     # ---- one pass of all blocks + head over l new tokens per sequence
-    def _blocks_and_head(self, x, ada, R: int, l: int, q_off: int, Lmax: int, arena, lvl_end=None):
+    def _blocks_and_head(self, x, ada, R: int, l: int, q_off: int, Lmax: int, arena, lvl_end=None, holes=None):
         """x: (R*l, C) fp32 residual stream (updated in place).  Returns logits (R*l, V) fp32."""
         P, cfg = self._pack(), self.cfg
         C, H, T = cfg.C, cfg.H, self.compute_dtype
@@ -578,7 +624,7 @@ class ControlVAR(nn.Module):
                      ldc=3 * C, remap=(l, Lmax, q_off))
             if cfg.uses_cos_attn:
                 ops.cos_qk_norm(arena, R, H, Lmax, q_off, l, P['scale_mul'], qkv_off=i * arena_stride, sm_off=i * H)
-            ops.attention(arena, o, R, H, Lmax, q_off, l, float(cfg.attn_scale), lvl_end, qkv_off=i * arena_stride)
+            ops.attention(arena, o, R, H, Lmax, q_off, l, float(cfg.attn_scale), lvl_end, qkv_off=i * arena_stride, holes=holes)
             ops.gemm(o, P['w_proj'], x, M=M, N=C, K=C, w_off=i * C * C, bias=P['b_proj'][i], gate=ada, gate_off=a0, ldg=n_ada, gate_rows=l,
                      residual=x)
             ops.ln_modulate(x, ada, a0 + 3 * C, a0 + 5 * C, n_ada, l, u, M, C, cfg.norm_eps)
@@ -640,9 +686,7 @@ class ControlVAR(nn.Module):
 
     @torch.no_grad()
     def _generate(self, B, label_B, g_seed, cfg_scale, top_k, top_p, more_smooth, cond_type, four_way, c_mask, c_img,
-                  force_idx=None, trace: bool = False):
-        if more_smooth:
-            raise NotImplementedError('more_smooth (Gumbel visualisation path) is not built (SURVEY.md 8f N4)')
+                  force_idx=None, trace: bool = False, gumbel=None):
         if top_k > self.cfg.vocab:                     # helpers.py:8-10: torch.topk raises on k > V; top_k <= 0 means no top-k filter
             raise RuntimeError(f'selected index k out of range (top_k={top_k} > vocabulary {self.cfg.vocab})')
         seed = int(g_seed) if g_seed is not None else int(torch.empty((), dtype=torch.int64).random_().item())
@@ -657,12 +701,14 @@ class ControlVAR(nn.Module):
             # random.seed(k) before the call reproduces the reference's choice of order
             import random
             mask_first = True if (random.random() < 0.5 or not self.bidirectional) else False
+        if self.cfg.separate_decoding and not self.cfg.indep and not four_way:              # control_var.py:428-485
+            return self._generate_two_pass(B, labels_all, types_all, seed, cfg_scale, top_k, top_p, bool(more_smooth), force_idx, trace, mask_first, gumbel)
         return self._generate_core(B, labels_all, types_all, seed, None, cfg_scale, top_k, top_p, four_way, c_mask, c_img, force_idx, trace,
-                                   mask_first=mask_first)
+                                   mask_first=mask_first, more_smooth=bool(more_smooth), gumbel=gumbel)
 
     @torch.no_grad()
     def _generate_core(self, B, labels_all, types_all, seed, seed_dev, cfg_scale, top_k, top_p, four_way, c_mask=None, c_img=None,
-                       force_idx=None, trace: bool = False, mask_first: bool = True):
+                       force_idx=None, trace: bool = False, mask_first: bool = True, more_smooth: bool = False, gumbel=None):
         """the 10-scale loop on device-resident inputs only (capturable in a HIP graph: no host sync, static shapes)"""
         cfg, P = self.cfg, self._pack()
         vae: VQVAE = self.vae_proxy[0]
@@ -681,10 +727,14 @@ class ControlVAR(nn.Module):
         f_hat = torch.zeros(nb, mf, cfg.cvae, S, S, device=dev, dtype=torch.float32)
         tr = {'idx': [], 'margin': [], 'logits': []} if trace else None
         nstage = len(py.patch_nums)
+        # `indep` models hand the rows of the training mask to every inference pass (control_var.py:283,497); those rows hide something
+        # only under separate_decoding (otherwise every cached key is visible anyway)
+        inf_lvl, inf_holes = attention_levels(cfg) if (cfg.indep and cfg.separate_decoding) else (None, None)
+        Pv = vae._pack()
         for si, pn in enumerate(py.patch_nums):
             l = py.l[si]
             ratio = si / (nstage - 1)
-            logits = self._blocks_and_head(x[:R * l], ada, R, l, py.begin[si], py.L, arena)
+            logits = self._blocks_and_head(x[:R * l], ada, R, l, py.begin[si], py.L, arena, lvl_end=inf_lvl, holes=inf_holes)
             if four_way:
                 t1, t2, t3 = [c * ratio for c in cfg_scale]
                 coef = [1 + t1, t2 - t1, t3 - t2, -t3]
@@ -695,7 +745,14 @@ class ControlVAR(nn.Module):
             idx = torch.empty(n_draw * B, l, device=dev, dtype=torch.int32)
             comb = torch.empty(B, l, cfg.vocab, device=dev, dtype=torch.float32) if trace else None
             mg = torch.empty(B, l, device=dev, dtype=torch.float32) if trace else None
-            ops.cfg_sample(logits, B, nrep, l, cfg.vocab, coef, top_k, top_p, seed, si, n_draw, idx, comb, mg, seed_dev=seed_dev)
+            soft = None
+            if more_smooth and top_k != 1:          # greedy: the in-place masked softmax is one-hot, i.e. exactly E[idx] (control_var.py:511-515)
+                soft = torch.empty(n_draw * B, l, cfg.cvae, device=dev, dtype=torch.float32)
+                ops.cfg_sample(logits, B, nrep, l, cfg.vocab, coef, top_k, top_p, seed, si, n_draw, idx, comb, mg, seed_dev=seed_dev, codebook=Pv['E'],
+                               smooth_mul=1.0 + ratio, smooth_tau=max(0.27 * (1 - ratio * 0.95), 0.005),
+                               gumbel=gumbel[si].to(device=dev, dtype=torch.float32).contiguous() if gumbel is not None else None, soft_out=soft)
+            else:
+                ops.cfg_sample(logits, B, nrep, l, cfg.vocab, coef, top_k, top_p, seed, si, n_draw, idx, comb, mg, seed_dev=seed_dev)
             if trace:
                 tr['idx'].append(idx.clone()); tr['margin'].append(mg); tr['logits'].append(comb)
             if force_idx is not None:
@@ -705,7 +762,7 @@ class ControlVAR(nn.Module):
                     idx[:3 * B, :pn * pn] = c_mask[si].to(device=dev, dtype=torch.int32).repeat(3, 1)
                 if c_img is not None:
                     idx[:3 * B, pn * pn:] = c_img[si].to(device=dev, dtype=torch.int32).repeat(3, 1)
-            tok = vae._next_input(si, idx, f_hat, nb, mf, True)
+            tok = vae._next_input(si, idx, f_hat, nb, mf, True, soft=soft)
             if si != nstage - 1:
                 ln = py.l[si + 1]
                 ops.word_embed(tok, P['w_we'], P['b_we'], gen_table, x, nb, 1 if four_way else 2, ln,
@@ -714,6 +771,67 @@ class ControlVAR(nn.Module):
             tr['f_hat'] = f_hat[:B].clone()
             self.last_trace = tr
         return f_hat[:B]
+
+    @torch.no_grad()
+    def _generate_two_pass(self, B, labels_all, types_all, seed, cfg_scale, top_k, top_p, more_smooth, force_idx, trace, mask_first, gumbel):
+        """separate_decoding without indep (control_var.py:428-485): 2 x 10 passes over the same KV arena - per scale first the control
+        tokens, then the image tokens, which see their scale's control tokens through the cache (attn_bias=None upstream).  The inputs
+        cross over as upstream's do: the image pass of scale k is fed the CONTROL f_hat pooled to pn_k (:467-468), the control pass of
+        scale k+1 the IMAGE f_hat pooled to pn_{k+1} (:470)."""
+        cfg, P = self.cfg, self._pack()
+        if cfg.type_pos:
+            raise NotImplementedError('type_pos + separate_decoding: upstream indexes patch_nums[si + 1] with si up to 18 (control_var.py:483) and raises')
+        vae: VQVAE = self.vae_proxy[0]
+        Pv = vae._pack()
+        py, C, dev = cfg.pyramid, cfg.C, self.device
+        pns = py.patch_nums
+        R = 2 * B
+        xf = torch.empty(R * 2, C, device=dev, dtype=torch.float32)
+        cond = torch.empty(R, C, device=dev, dtype=torch.float32)
+        self._first_tokens(P, labels_all, types_all, xf, cond, R, 2, P['lvl_pos'], mask_first)
+        ada = self._ada(cond, R)
+        arena = self._get_arena(R, py.L)
+        S = pns[-1]
+        f = [torch.zeros(B, 1, cfg.cvae, S, S, device=dev, dtype=torch.float32) for _ in range(2)]
+        x = torch.empty(R * S * S, C, device=dev, dtype=torch.float32)
+        tr = {'idx': [], 'margin': [], 'logits': []} if trace else None
+        nstage, pos = len(pns), 0
+        for si in range(2 * nstage):
+            half, k = si % 2, si // 2
+            pn = pns[k]
+            l = pn * pn
+            ratio = k / (nstage - 1)
+            if si < 2:
+                x[:R].copy_(xf.view(R, 2, C)[:, si])
+            logits = self._blocks_and_head(x[:R * l], ada, R, l, pos, py.L, arena)
+            pos += l
+            t = cfg_scale * ratio
+            idx = torch.empty(B, l, device=dev, dtype=torch.int32)
+            comb = torch.empty(B, l, cfg.vocab, device=dev, dtype=torch.float32) if trace else None
+            mg = torch.empty(B, l, device=dev, dtype=torch.float32) if trace else None
+            soft = None
+            if more_smooth and top_k != 1:
+                soft = torch.empty(B, l, cfg.cvae, device=dev, dtype=torch.float32)
+                ops.cfg_sample(logits, B, 2, l, cfg.vocab, [1 + t, -t], top_k, top_p, seed, si, 1, idx, comb, mg, codebook=Pv['E'], smooth_mul=1.0 + ratio,
+                               smooth_tau=max(0.27 * (1 - ratio * 0.95), 0.005),
+                               gumbel=gumbel[si].to(device=dev, dtype=torch.float32).contiguous() if gumbel is not None else None, soft_out=soft)
+            else:
+                ops.cfg_sample(logits, B, 2, l, cfg.vocab, [1 + t, -t], top_k, top_p, seed, si, 1, idx, comb, mg)
+            if trace:
+                tr['idx'].append(idx.clone()); tr['margin'].append(mg); tr['logits'].append(comb)
+            if force_idx is not None:
+                idx = force_idx[si].to(device=dev, dtype=torch.int32).contiguous()
+            if si == 2 * nstage - 1:
+                vae._next_input(k, idx, f[1], B, 1, False, soft=soft)
+                break
+            tok = vae._next_input(k, idx, f[half], B, 1, True, soft=soft, pn_next=pn if half == 0 else None)
+            ln = tok.shape[1]
+            ops.word_embed(tok, P['w_we'], P['b_we'], P['lvl_pos'], x, B, 2, ln, cfg.cvae, C, ln, 0, lvl_off=pos)
+        f_hat = torch.cat(f, dim=1)
+        if trace:
+            tr['f_hat'] = f_hat.clone()
+            self.last_trace = tr
+        return f_hat
 
     @torch.no_grad()
     def graphed_generator(self, B: int, cfg=1.5, top_k: int = 0, top_p: float = 0.0):
@@ -761,18 +879,19 @@ class ControlVAR(nn.Module):
     # ---- public API
     @torch.no_grad()
     def autoregressive_infer_cfg(self, B: int, label_B, g_seed: Optional[int] = None, cfg=1.5, top_k=0, top_p=0.0,
-                                 more_smooth=False, cond_type=None, _force_idx=None, _trace=False) -> torch.Tensor:
-        """control_var.py:356-565: returns (B, 3, 512, 256) in [0,1] (control image on top, RGB below)."""
-        f_hat = self._generate(B, label_B, g_seed, cfg, top_k, top_p, more_smooth, cond_type, False, None, None, _force_idx, _trace)
+                                 more_smooth=False, cond_type=None, _force_idx=None, _trace=False, _gumbel=None) -> torch.Tensor:
+        """control_var.py:356-565: returns (B, 3, 512, 256) in [0,1] (control image on top, RGB below).
+        more_smooth: Gumbel-softmax soft code embeddings (:511-515); `_gumbel` (tests) injects the per-pass noise instead of drawing it."""
+        f_hat = self._generate(B, label_B, g_seed, cfg, top_k, top_p, more_smooth, cond_type, False, None, None, _force_idx, _trace, _gumbel)
         return self._decode_pair(f_hat)
 
     @torch.no_grad()
     def conditional_infer_cfg(self, B: int, label_B, g_seed: Optional[int] = None, cfg=(1.5, 1.5, 1.5), top_k=0, top_p=0.0,
-                              more_smooth=False, cond_type=None, c_mask=None, c_img=None, _force_idx=None, _trace=False) -> torch.Tensor:
+                              more_smooth=False, cond_type=None, c_mask=None, c_img=None, _force_idx=None, _trace=False, _gumbel=None) -> torch.Tensor:
         """control_var.py:223-354: 4-branch CFG with teacher forcing of the control (c_mask) or image (c_img) ids."""
         if self.mask_factor != 2:
             raise NotImplementedError('conditional_infer_cfg needs mask_factor == 2 (control_var.py:333)')
-        f_hat = self._generate(B, label_B, g_seed, tuple(cfg), top_k, top_p, more_smooth, cond_type, True, c_mask, c_img, _force_idx, _trace)
+        f_hat = self._generate(B, label_B, g_seed, tuple(cfg), top_k, top_p, more_smooth, cond_type, True, c_mask, c_img, _force_idx, _trace, _gumbel)
         return self._decode_pair(f_hat)
 
     def forward(self, label_B: torch.LongTensor, x_BLCv_wo_first_l: torch.Tensor, cond_type=None, mask_first=True) -> torch.Tensor:
@@ -813,7 +932,8 @@ class ControlVAR(nn.Module):
         ops.word_embed(tok, P['w_we'], P['b_we'], table, x, B, 1, py.L - py.first_l, cfg.cvae, C, py.L, py.first_l, lvl_off=py.first_l)
         ada = self._ada(cond, B)
         arena = self._get_arena(B, py.L)
-        logits = self._blocks_and_head(x, ada, B, py.L, 0, py.L, arena, lvl_end=list(py.end))
+        lvl_end, holes = attention_levels(cfg)
+        logits = self._blocks_and_head(x, ada, B, py.L, 0, py.L, arena, lvl_end=lvl_end, holes=holes)
         return logits.view(B, py.L, cfg.vocab)
 
 

@@ -123,22 +123,33 @@ def silu_cast(x: torch.Tensor, out: torch.Tensor):
     return out
 
 
-def attention(qkv: torch.Tensor, out: torch.Tensor, R: int, H: int, Lmax: int, q_off: int, l: int, scale: float,
-              lvl_end: Optional[Sequence[int]] = None, qkv_off: int = 0, rowwise: bool = False, lse: Optional[torch.Tensor] = None):
+def _level_arrays(lvl_end, holes):
+    """lvl_end: level ends; holes: optional [(lo, hi)] per level (keys the level's queries do not see) -> ctypes int arrays"""
     n = len(lvl_end) if lvl_end else 0
     arr = (C.c_int * max(n, 1))(*(lvl_end or [0]))
+    harr = None
+    if holes:
+        if len(holes) != n:
+            raise ValueError('one (lo, hi) hole per level')
+        harr = (C.c_int * (2 * n))(*[int(v) for h in holes for v in h])
+    return n, arr, harr
+
+
+def attention(qkv: torch.Tensor, out: torch.Tensor, R: int, H: int, Lmax: int, q_off: int, l: int, scale: float,
+              lvl_end: Optional[Sequence[int]] = None, qkv_off: int = 0, rowwise: bool = False, lse: Optional[torch.Tensor] = None,
+              holes: Optional[Sequence[Sequence[int]]] = None):
+    n, arr, harr = _level_arrays(lvl_end, holes)
     fn = _lib.load().cvar_attention_rowwise if rowwise else _lib.load().cvar_attention
     check(fn(_ptr(qkv) + qkv_off * qkv.element_size(), dt(qkv), R, H, Lmax, q_off, l, scale,
-                                     arr, n, _ptr(out), _ptr(lse), _stream()), 'cvar_attention')
+                                     arr, n, harr, _ptr(out), _ptr(lse), _stream()), 'cvar_attention')
     return out
 
 
-def attention_bwd(qkv, o, dout, lse, dqkv, ws, R, H, Lmax, l, scale, lvl_end=None, qkv_off: int = 0, rowwise: bool = False):
-    n = len(lvl_end) if lvl_end else 0
-    arr = (C.c_int * max(n, 1))(*(lvl_end or [0]))
+def attention_bwd(qkv, o, dout, lse, dqkv, ws, R, H, Lmax, l, scale, lvl_end=None, qkv_off: int = 0, rowwise: bool = False, holes=None):
+    n, arr, harr = _level_arrays(lvl_end, holes)
     fn = _lib.load().cvar_attention_bwd_rowwise if rowwise else _lib.load().cvar_attention_bwd
     check(fn(_ptr(qkv) + qkv_off * qkv.element_size(), dt(qkv), _ptr(o), _ptr(dout), _ptr(lse), R, H, Lmax, 0, l, scale,
-                                         arr, n, _ptr(dqkv), _ptr(ws), _stream()), 'cvar_attention_bwd')
+                                         arr, n, harr, _ptr(dqkv), _ptr(ws), _stream()), 'cvar_attention_bwd')
     return dqkv
 
 
@@ -155,10 +166,14 @@ def cos_qk_norm_bwd(qkv, dqkv, R, H, Lmax, l, scale_mul, norms, dsm_tok, sm_off:
 
 def cfg_sample(logits: torch.Tensor, B: int, nrep: int, l: int, V: int, coef: Sequence[float], top_k: int, top_p: float,
                seed: int, stage: int, n_draw: int, idx_out: torch.Tensor, combined: Optional[torch.Tensor] = None,
-               margin: Optional[torch.Tensor] = None, kept: Optional[torch.Tensor] = None, seed_dev: Optional[torch.Tensor] = None):
+               margin: Optional[torch.Tensor] = None, kept: Optional[torch.Tensor] = None, seed_dev: Optional[torch.Tensor] = None,
+               ldv: int = 0, codebook: Optional[torch.Tensor] = None, smooth_mul: float = 1.0, smooth_tau: float = 1.0,
+               gumbel: Optional[torch.Tensor] = None, soft_out: Optional[torch.Tensor] = None):
     arr = (C.c_float * 4)(*(list(coef) + [0.0] * (4 - len(coef))))
     check(_lib.load().cvar_cfg_sample(_ptr(logits), B, nrep, l, V, arr, top_k, float(top_p), int(seed) & (2 ** 64 - 1), _ptr(seed_dev), stage, n_draw,
-                                      _ptr(idx_out), _ptr(combined), _ptr(margin), _ptr(kept), _stream()), 'cvar_cfg_sample')
+                                      _ptr(idx_out), _ptr(combined), _ptr(margin), _ptr(kept), int(ldv), _ptr(codebook),
+                                      codebook.shape[1] if codebook is not None else 0, float(smooth_mul), float(smooth_tau), _ptr(gumbel), _ptr(soft_out),
+                                      _stream()), 'cvar_cfg_sample')
     return idx_out
 
 

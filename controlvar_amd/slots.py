@@ -52,9 +52,10 @@ def fused_mlp_func(x, weight1, weight2, bias1=None, bias2=None, activation='gelu
 
 # --------------------------------------------------------------------------------------------------------------------- attention
 def _prefix_levels(attn_mask: torch.Tensor, Lq: int, Lk: int):
-    """The kernels implement 'query i sees keys [0, n_i)' with n_i = the first level end above position i - exactly the structure of
-    the reference's attn_bias_for_masking (control_var.py:158-168) and of its slices.  Recover the level ends from an additive
-    {0, -inf} mask and verify that it has that form; anything else is not something the reference passes."""
+    """The kernels implement 'query at position p sees keys [0, end(level(p))) minus one hole of its level', with level(p) = the first
+    level whose end lies above p - exactly the structure of the reference's attn_bias_for_masking (control_var.py:158-191: plain,
+    separate_decoding, separate_decoding + indep) and of its row slices.  Recover (level ends, holes) from an additive {0, -inf} mask
+    and verify that it has that form; anything else is not something the reference passes and is refused, not approximated."""
     m = attn_mask
     while m.dim() > 2:
         if m.shape[0] != 1:
@@ -65,19 +66,29 @@ def _prefix_levels(attn_mask: torch.Tensor, Lq: int, Lk: int):
     vis = (m == 0)
     if not bool((vis | torch.isneginf(m)).all()):
         raise NotImplementedError('attention slot: only additive {0, -inf} masks are built')
-    n = vis.sum(dim=1)                                            # visible keys per query
-    cols = torch.arange(Lk, device=m.device).view(1, -1)
-    if not bool((vis == (cols < n.view(-1, 1))).all()):
-        raise NotImplementedError('attention slot: the mask must make a PREFIX of the keys visible to every query')
-    n_list = [int(v) for v in n.tolist()]
+    v = vis.cpu().numpy()
     q_off = Lk - Lq
-    ends = sorted(set(n_list))
-    for i, ni in enumerate(n_list):                               # n_i must be the first level end above the query's own position
+    rows = []
+    for i in range(Lq):
+        on = v[i].nonzero()[0]
+        if len(on) == 0:
+            raise NotImplementedError('attention slot: a query with no visible key')
+        n = int(on[-1]) + 1
+        off = (~v[i, :n]).nonzero()[0]
+        if len(off) and (off[-1] - off[0] + 1 != len(off)):
+            raise NotImplementedError('attention slot: more than one invisible run inside the visible prefix')
+        rows.append((n, (int(off[0]), int(off[-1]) + 1) if len(off) else (0, 0)))
+    ends = sorted(set(n for n, _ in rows))
+    holes = {}
+    for i, (n, hole) in enumerate(rows):
         pos = q_off + i
         want = next((e for e in ends if e > pos), None)
-        if want != ni:
-            raise NotImplementedError('attention slot: mask is not block-causal over contiguous levels (control_var.py:158-168 form)')
-    return ends
+        if want != n:
+            raise NotImplementedError('attention slot: mask is not block-causal over contiguous levels (control_var.py:158-191 form)')
+        if holes.setdefault(n, hole) != hole:
+            raise NotImplementedError('attention slot: queries of one level must share their hole')
+    hl = [holes[e] for e in ends]
+    return ends, (hl if any(b > a for a, b in hl) else None)
 
 
 def _attention_blhc(q, k, v, scale: float, attn_mask=None, dropout_p: float = 0.0):
@@ -95,11 +106,11 @@ def _attention_blhc(q, k, v, scale: float, attn_mask=None, dropout_p: float = 0.
     if q.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError(f'attention slot: dtype {q.dtype} not supported (float32 or bfloat16)')
     q_off = Lk - Lq
-    lvl_end = _prefix_levels(attn_mask, Lq, Lk) if attn_mask is not None else []
+    lvl_end, holes = _prefix_levels(attn_mask, Lq, Lk) if attn_mask is not None else ([], None)
     # pack the (q | k | v) arena the kernel reads: the model path writes this layout straight from the QKV GEMM; the slot pays a copy
     qfull = q if q_off == 0 else torch.cat((q.new_zeros(B, q_off, H, c), q), dim=1)
     arena = torch.stack((qfull, k.to(q.dtype), v.to(q.dtype)), dim=2).reshape(B, Lk, 3 * H * c).contiguous()
-    out, _ = cvar.attention(arena, H, q_off, Lq, float(scale), lvl_end, False)
+    out, _ = cvar.attention(arena, H, q_off, Lq, float(scale), lvl_end, False, [x for h in holes for x in h] if holes else [])
     return out.view(B, Lq, H, c)
 
 

@@ -103,6 +103,9 @@ class VarConfig:
     bidirectional: bool = False     # N4: image-first order allowed (mask_first=False: first two tokens and type ids swapped; control_var.py:403-407,587,624)
     sa_block: bool = False          # N4: aln < 0 -> SABlock (affine LayerNorms, no adaLN; basic_var.py:128-176) + head = Sequential(LN, Linear)
     layer_scale: float = -1.0       # SABlock only: >= 0 -> learned per-channel gamma1 / gamma2 (basic_var.py:145-149)
+    separate_decoding: bool = False # N4: per scale the control half is decoded before the image half (control_var.py:170-180,428-485)
+    indep: bool = False             # N4: with separate_decoding, the two halves of a scale are blind to each other (control_var.py:182-191);
+                                    #     without it the flag only makes inference pass (all-visible) slices of the mask (:283,:497)
 
     @property
     def C(self) -> int:
@@ -124,6 +127,47 @@ class VarConfig:
     def attn_scale(self) -> float:
         # basic_var.py:66-71: cos-attn uses scale 1, else 1/sqrt(head_dim)/tau
         return 1.0 if self.uses_cos_attn else 1.0 / np.sqrt(self.C // self.H) / self.tau
+
+
+def attention_levels(cfg: VarConfig):
+    """(lvl_end, holes) describing ``attn_bias_for_masking`` for the attention kernels (include/cvar.h cvar_attention): a query at
+    position p sees keys [0, lvl_end[level(p)]) minus holes[level(p)] = [lo, hi).
+      default .................. levels = scales (control_var.py:158-168);
+      separate_decoding ........ levels = half scales: control queries stop at the end of their own half, image queries see the
+                                 whole scale (:170-180);
+      separate_decoding+indep .. the image half additionally does not see the control half of its own scale (:182-191).
+    holes is None when no level has one."""
+    py = cfg.pyramid
+    if not (cfg.separate_decoding and cfg.mask_factor == 2):
+        return list(py.end), None
+    ends, holes = [], []
+    for b, e in zip(py.begin, py.end):
+        half = (e - b) // 2
+        ends += [b + half, e]
+        holes += [(0, 0), (b, b + half) if cfg.indep else (0, 0)]
+    return ends, (holes if cfg.indep else None)
+
+
+def attention_bias_matrix(cfg: VarConfig):
+    """the reference's own construction of the (L, L) additive {0, -inf} buffer (control_var.py:158-191), as a numpy bool 'visible' map"""
+    py = cfg.pyramid
+    L = py.L
+    lvl = py.level_of_token()
+    vis = lvl[:, None] >= lvl[None, :]
+    if cfg.separate_decoding and cfg.mask_factor == 2:
+        d, dT = np.zeros(L, np.int64), np.zeros(L, np.int64)
+        for i, (b, e) in enumerate(zip(py.begin, py.end)):
+            h = (e - b) // 2
+            d[b:b + h], d[b + h:e] = 1 + 4 * i, 3 + 4 * i
+            dT[b:b + h], dT[b + h:e] = 1 + 4 * i, 2 + 4 * i
+        vis = d[:, None] >= dT[None, :]
+        if cfg.indep:
+            for i, (b, e) in enumerate(zip(py.begin, py.end)):
+                h = (e - b) // 2
+                d[b:b + h], d[b + h:e] = 3 + 4 * i, 1 + 4 * i
+                dT[b:b + h], dT[b + h:e] = 2 + 4 * i, 0 + 4 * i
+            vis = vis & (d[:, None] >= dT[None, :])
+    return vis
 
 
 def var_state_shapes(cfg: VarConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":

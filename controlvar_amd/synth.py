@@ -37,9 +37,9 @@ def synth_var_state(cfg: VarConfig, seed: int = 0, head_gain: float = 4.0) -> Di
         if key == 'lvl_1L':
             out[key] = torch.from_numpy(py.level_of_token()).view(1, -1)
         elif key == 'attn_bias_for_masking':
-            lvl = torch.from_numpy(py.level_of_token())
-            d = lvl.view(1, py.L, 1)
-            out[key] = torch.where(d >= d.transpose(1, 2), 0.0, -torch.inf).reshape(1, 1, py.L, py.L).contiguous()
+            from .spec import attention_bias_matrix
+            vis = torch.from_numpy(attention_bias_matrix(cfg))
+            out[key] = torch.where(vis, 0.0, -torch.inf).reshape(1, 1, py.L, py.L).contiguous()
         elif key in ('type_1L', 'type_1L_'):
             first = 1 if key == 'type_1L' else 0                     # control half id; the image half gets the other one
             ids = []

@@ -251,51 +251,57 @@ _define('gate_residual_', '(Tensor(a!) x, Tensor f, Tensor gate, int gate_rows, 
 
 
 # ------------------------------------------------------------------------------------------------------------------- attention
-def _attention(qkv, H, q_off, l, scale, lvl_end, rowwise=False):
-    """qkv: (R, Lmax, 3*H*64) arena (q | k | v thirds); queries = rows [q_off, q_off + l) -> (out (R*l, H*64), lse (R, H, l) fp32)"""
+def _holes(flat):
+    return [(int(flat[2 * i]), int(flat[2 * i + 1])) for i in range(len(flat) // 2)] if flat else None
+
+
+def _attention(qkv, H, q_off, l, scale, lvl_end, rowwise=False, holes=()):
+    """qkv: (R, Lmax, 3*H*64) arena (q | k | v thirds); queries = rows [q_off, q_off + l) -> (out (R*l, H*64), lse (R, H, l) fp32).
+    lvl_end / holes (flattened lo, hi pairs, one per level): the visibility tables of cvar_attention (include/cvar.h)."""
     _check_operand(qkv, 'attention: qkv')
     if qkv.dim() != 3 or qkv.shape[2] != 3 * H * 64 or not qkv.is_contiguous():
         raise ValueError(f'attention: arena must be contiguous (R, Lmax, 3*H*64); got {tuple(qkv.shape)} for H={H}')
     R, Lmax, _ = qkv.shape
     out = torch.empty(R * l, H * 64, device=qkv.device, dtype=qkv.dtype)
     lse = torch.empty(R, H, l, device=qkv.device, dtype=torch.float32)
-    K.attention(qkv, out, R, H, Lmax, q_off, l, scale, list(lvl_end) or None, rowwise=rowwise or qkv.dtype == torch.float32, lse=lse)
+    K.attention(qkv, out, R, H, Lmax, q_off, l, scale, list(lvl_end) or None, rowwise=rowwise or qkv.dtype == torch.float32, lse=lse, holes=_holes(list(holes)))
     return out, lse
 
 
-_define('attention', '(Tensor qkv, int H, int q_off, int l, float scale, int[] lvl_end, bool rowwise=False) -> (Tensor, Tensor)', _attention,
-        lambda qkv, H, q_off, l, scale, lvl_end, rowwise=False: (qkv.new_empty(qkv.shape[0] * l, H * 64), qkv.new_empty(qkv.shape[0], H, l, dtype=torch.float32)))
+_define('attention', '(Tensor qkv, int H, int q_off, int l, float scale, int[] lvl_end, bool rowwise=False, int[] holes=[]) -> (Tensor, Tensor)', _attention,
+        lambda qkv, H, q_off, l, scale, lvl_end, rowwise=False, holes=(): (qkv.new_empty(qkv.shape[0] * l, H * 64),
+                                                                          qkv.new_empty(qkv.shape[0], H, l, dtype=torch.float32)))
 
 
-def _attention_bwd(qkv, o, dout, lse, H, scale, lvl_end, rowwise=False):
+def _attention_bwd(qkv, o, dout, lse, H, scale, lvl_end, rowwise=False, holes=()):
     """gradient of attention over the WHOLE arena (q_off = 0, l = Lmax: the teacher-forced form) -> dqkv with the arena layout"""
     R, Lmax, _ = qkv.shape
     dqkv = torch.empty_like(qkv)
     ws = torch.empty(R * H * Lmax + 16, device=qkv.device, dtype=torch.float32)
     K.attention_bwd(qkv, o.contiguous(), dout.to(qkv.dtype).contiguous(), lse.contiguous(), dqkv, ws, R, H, Lmax, Lmax, scale, list(lvl_end) or None,
-                    rowwise=rowwise or qkv.dtype == torch.float32)
+                    rowwise=rowwise or qkv.dtype == torch.float32, holes=_holes(list(holes)))
     return dqkv
 
 
-_define('attention_bwd', '(Tensor qkv, Tensor o, Tensor dout, Tensor lse, int H, float scale, int[] lvl_end, bool rowwise=False) -> Tensor',
-        _attention_bwd, lambda qkv, o, dout, lse, H, scale, lvl_end, rowwise=False: qkv.new_empty(qkv.shape))
+_define('attention_bwd', '(Tensor qkv, Tensor o, Tensor dout, Tensor lse, int H, float scale, int[] lvl_end, bool rowwise=False, int[] holes=[]) -> Tensor',
+        _attention_bwd, lambda qkv, o, dout, lse, H, scale, lvl_end, rowwise=False, holes=(): qkv.new_empty(qkv.shape))
 
 
 def _attn_setup(ctx, inputs, output):
-    qkv, H, q_off, l, scale, lvl_end, rowwise = inputs
-    ctx.args = (H, q_off, l, scale, tuple(lvl_end), rowwise, qkv.shape[1])
+    qkv, H, q_off, l, scale, lvl_end, rowwise, holes = inputs
+    ctx.args = (H, q_off, l, scale, tuple(lvl_end), rowwise, qkv.shape[1], tuple(holes))
     ctx.save_for_backward(qkv, output[0], output[1])
     ctx.mark_non_differentiable(output[1])
 
 
 def _attn_backward(ctx, dout, dlse):
-    H, q_off, l, scale, lvl_end, rowwise, Lmax = ctx.args
+    H, q_off, l, scale, lvl_end, rowwise, Lmax, holes = ctx.args
     if q_off != 0 or l != Lmax:
         raise RuntimeError('cvar::attention backward needs the whole-sequence form (q_off = 0, l = Lmax); the KV-cached form is inference-only')
     qkv, o, lse = ctx.saved_tensors
     with torch.no_grad():
-        dqkv = torch.ops.cvar.attention_bwd(qkv, o, dout.contiguous(), lse, H, scale, list(lvl_end), rowwise)
-    return dqkv, None, None, None, None, None, None
+        dqkv = torch.ops.cvar.attention_bwd(qkv, o, dout.contiguous(), lse, H, scale, list(lvl_end), rowwise, list(holes))
+    return dqkv, None, None, None, None, None, None, None
 
 
 register_autograd('cvar::attention', _attn_backward, setup_context=_attn_setup)

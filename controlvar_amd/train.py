@@ -294,7 +294,8 @@ class TrainEngine:
         hid = P['w_fc1'].shape[1]
         n_ada = P['n_ada']
         eps = cfg.norm_eps
-        lvl_end = list(py.end)
+        from .spec import attention_levels
+        lvl_end, holes = attention_levels(cfg)
         scale = float(cfg.attn_scale)
         from .models import _check_index_range
         _check_index_range(label_B, 0, cfg.num_classes, 'label_B')
@@ -337,7 +338,7 @@ class TrainEngine:
             ops.gemm(self.U[i], P['w_qkv'], self.arena[i], M=M, N=3 * C, K=C, w_off=i * 3 * C * C, bias=P['b_qkv'][i])
             if cfg.uses_cos_attn:
                 ops.cos_qk_norm(self.arena[i], B, H, L, 0, L, P['scale_mul'], sm_off=i * H, norms=self.NORMS[i])
-            ops.attention(self.arena[i], self.O[i], B, H, L, 0, L, scale, lvl_end, lse=self.LSE[i])
+            ops.attention(self.arena[i], self.O[i], B, H, L, 0, L, scale, lvl_end, lse=self.LSE[i], holes=holes)
             # x1 = x + (gamma1 * keep1) * proj(o): gate / DropPath scale / residual in the GEMM epilogue; the branch output the backward
             # needs (d gamma1 = sum dx * f) is stored next to it
             ops.gemm(self.O[i], P['w_proj'], self.X1s[i], M=M, N=C, K=C, w_off=i * C * C, bias=P['b_proj'][i], gate=ada, ldg=n_ada, gate_rows=L,
@@ -368,7 +369,8 @@ class TrainEngine:
         hid = P['w_fc1'].shape[1]
         n_ada = P['n_ada']
         eps = cfg.norm_eps
-        lvl_end = list(py.end)
+        from .spec import attention_levels
+        lvl_end, holes = attention_levels(cfg)
         scale = float(cfg.attn_scale)
         ah = depth * 6 * C
         # ---- backward: head
@@ -407,7 +409,7 @@ class TrainEngine:
             ops.transpose(self.O[i], TB, 1, M, C, C, ld_out=Mp)
             ops.gemm(TA, TB, G, M=C, N=C, K=Mp, c_off=go + so['w_proj'])
             ops.rowsum(TA, Mp, G, C, M, out_off=go + so['b_proj'])
-            ops.attention_bwd(self.arena[i], self.O[i], self.DU, self.LSE[i], self.DQKV, ws, B, H, L, L, scale, lvl_end)
+            ops.attention_bwd(self.arena[i], self.O[i], self.DU, self.LSE[i], self.DQKV, ws, B, H, L, L, scale, lvl_end, holes=holes)
             if cfg.uses_cos_attn:           # normalisation + learned temperature of basic_var.py:99-104
                 ops.cos_qk_norm_bwd(self.arena[i], self.DQKV, B, H, L, L, P['scale_mul'], self.NORMS[i], self.DSM, sm_off=i * H)
                 ops.colsum(self.DSM, H, G, M, H, ws, out_off=go + so['scale_mul'])

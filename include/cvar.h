@@ -99,22 +99,26 @@ int cvar_silu_cast(const float* x, void* out, int out_dtype, int64_t n, void* st
  * qkv arena: [R][Lmax][3*H*64] of `dtype` (q | k | v thirds, head-major inside a third), written by cvar_gemm
  * with the row remap.  Queries are rows [q_off, q_off+l) of every sequence, keys rows [0, kv_len(q)).
  * kv_len: if n_lvl == 0 every query sees [0, q_off+l) (inference, attn_bias=None); otherwise lvl_end[] holds the
- * n_lvl cumulative scale ends and a query at position p sees keys < lvl_end[level(p)] - the block-causal
- * attn_bias_for_masking of training (control_var.py:158-168).  out: [R*l][H*64] of `dtype`. */
+ * n_lvl (<= 32) strictly increasing level ends and a query at position p sees keys < lvl_end[level(p)] - the block-causal
+ * attn_bias_for_masking of training (control_var.py:158-168; levels = scales) and of `separate_decoding` (:170-180; levels =
+ * half scales: a control token does not see the image half of its own scale).  hole_host (optional, 2*n_lvl ints): per level a key
+ * range [lo, hi) in FRONT of the level that its queries do not see (lo >= hi: none) - the `indep` mask (:182-191), where the image
+ * half of a scale is blind to the control half of the same scale.  out: [R*l][H*64] of `dtype`. */
 int cvar_attention(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
-                   const int* lvl_end_host, int n_lvl, void* out, float* lse /* optional [R][H][l], saved for backward */,
-                   void* stream);
+                   const int* lvl_end_host, int n_lvl, const int* hole_host, void* out,
+                   float* lse /* optional [R][H][l], saved for backward */, void* stream);
 /* same contract, always the exact row-per-lane fp32-math kernel (the parity-mode implementation; also the in-library
  * reference the bf16 MFMA flash kernel is A/B-tested against). */
 int cvar_attention_rowwise(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
-                           const int* lvl_end_host, int n_lvl, void* out, float* lse, void* stream);
+                           const int* lvl_end_host, int n_lvl, const int* hole_host, void* out, float* lse, void* stream);
 /* backward of the level-masked attention (training forward, control_var.py:626-639 under autograd): given dO and the saved
  * lse, writes dQ | dK | dV into dqkv with the arena layout [R][Lmax][3*H*64].  ws: R*H*l floats.  q_off must be 0. */
 int cvar_attention_bwd(const void* qkv, int dtype, const void* o, const void* dout, const float* lse, int R, int H, int Lmax,
-                       int q_off, int l, float scale, const int* lvl_end_host, int n_lvl, void* dqkv, float* ws, void* stream);
+                       int q_off, int l, float scale, const int* lvl_end_host, int n_lvl, const int* hole_host, void* dqkv, float* ws, void* stream);
 /* same contract, always the exact row-per-lane kernels (fp32-mode implementation / A-B reference of the bf16 MFMA backward) */
 int cvar_attention_bwd_rowwise(const void* qkv, int dtype, const void* o, const void* dout, const float* lse, int R, int H, int Lmax,
-                               int q_off, int l, float scale, const int* lvl_end_host, int n_lvl, void* dqkv, float* ws, void* stream);
+                               int q_off, int l, float scale, const int* lvl_end_host, int n_lvl, const int* hole_host, void* dqkv, float* ws,
+                               void* stream);
 
 /* cos-attention pre-pass (basic_var.py:99-104), in place on rows [q_off, q_off+l) of the arena:
  * q = normalize(q) * exp(min(scale_mul[h], log 100)),  k = normalize(k). */
@@ -131,10 +135,17 @@ int cvar_cos_qk_norm_bwd(const void* qkv, void* dqkv, int dtype, int R, int H, i
  * ((1+t, -t) or the 4-branch form).  top_k == 1: greedy argmax (lowest index on ties).  Otherwise top-k /
  * top-p filtering as the reference, then one draw per row of `n_draw` independent rows from a counter-based
  * generator keyed by (seed, stage, row).  idx_out: [n_draw*B][l] int32.  Optional outputs (may be NULL):
- * combined [B][l][V] fp32, margin [B][l] fp32 (top1 - top2 of the combined logits), kept [B][l] int32. */
+ * combined [B][l][V] fp32, margin [B][l] fp32 (top1 - top2 of the combined logits), kept [B][l] int32.
+ * ldv: row stride of `logits` in floats (0 = V): a head with extra columns behind the V codes (`separator`, control_var.py:202,504).
+ * more_smooth (control_var.py:326-330,459-463,511-515; helpers.py:22-36), sampling mode only: with soft_out != NULL also
+ *   soft_out[d*B + b][t][:] = softmax_v((combined_v * smooth_mul + g_v) / smooth_tau) . codebook[v][:]  over the top-k / top-p KEPT v
+ * (the reference masks its logits in place before the Gumbel softmax); g = Gumbel noise, injected ([n_draw*B][l][V]) or drawn from
+ * the counter-based generator. */
 int cvar_cfg_sample(const float* logits, int B, int nrep, int l, int V, const float* coef_host,
                     int top_k, float top_p, uint64_t seed, const uint64_t* seed_dev /* optional, added to seed */, int stage, int n_draw,
-                    int32_t* idx_out, float* combined, float* margin, int32_t* kept, void* stream);
+                    int32_t* idx_out, float* combined, float* margin, int32_t* kept, int ldv,
+                    const float* codebook /* [V][Cvae] */, int Cvae, float smooth_mul, float smooth_tau, const float* gumbel, float* soft_out,
+                    void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Token-pyramid helpers of VectorQuantizer2 (models/quant.py).

@@ -70,7 +70,7 @@ def make_cvar(vae, cfg: VarConfig, seed=0):
             m = quiet(build_control_var, vae, depth=cfg.depth, patch_nums=PN, mask_type='interleave_append' if cfg.mask_factor == 2 else 'replace',
                       cond_drop_rate=0.0, multi_cond=cfg.multi_cond, flash_if_available=False, fused_if_available=False,
                       shared_aln=cfg.shared_aln, type_pos=cfg.type_pos, aln=-1 if cfg.sa_block else 1, layer_scale=cfg.layer_scale,
-                      bidirectional=cfg.bidirectional)
+                      bidirectional=cfg.bidirectional, separate_decoding=cfg.separate_decoding, indep=cfg.indep)
     else:
         m = quiet(build_var, vae, depth=cfg.depth, patch_nums=PN, flash_if_available=False, fused_if_available=False, shared_aln=cfg.shared_aln)
         m.cond_drop_rate = 0.0
@@ -203,13 +203,14 @@ def case_forward(depth, tag, mf=2):
          argmax=logits.argmax(-1).to(torch.int16), margin=(t2[..., 0] - t2[..., 1]), lsum=logits.double().sum(-1).float())
 
 
-def _run_generate(m, module, B, labels, cfg_scale, cond_type=None, four=False, c_mask=None, c_img=None, top_k=1, top_p=0.0, seed=0):
+def _run_generate(m, module, B, labels, cfg_scale, cond_type=None, four=False, c_mask=None, c_img=None, top_k=1, top_p=0.0, seed=0, more_smooth=False):
     with CaptureIdx(module) as cap, torch.no_grad():
         if four:
             img = m.conditional_infer_cfg(B=B, label_B=labels, g_seed=seed, cfg=cfg_scale, top_k=top_k, top_p=top_p,
-                                          cond_type=cond_type, c_mask=c_mask, c_img=c_img)
+                                          cond_type=cond_type, c_mask=c_mask, c_img=c_img, more_smooth=more_smooth)
         elif module is ref_cv:
-            img = m.autoregressive_infer_cfg(B=B, label_B=labels, g_seed=seed, cfg=cfg_scale, top_k=top_k, top_p=top_p, cond_type=cond_type)
+            img = m.autoregressive_infer_cfg(B=B, label_B=labels, g_seed=seed, cfg=cfg_scale, top_k=top_k, top_p=top_p, cond_type=cond_type,
+                                             more_smooth=more_smooth)
         else:
             img = m.autoregressive_infer_cfg(B=B, label_B=labels, g_seed=seed, cfg=cfg_scale, top_k=top_k, top_p=top_p)
     ids = torch.cat(cap.idx, dim=1)
@@ -566,6 +567,70 @@ def case_train_step_d24():
     case_train_step(VarConfig(depth=24), 'd24', 0)
 
 
+def case_tokenizer_alt():
+    """vqvae.py:73-75 with a caller-chosen scale list: ids of the tiny VQVAE for v_patch_nums (1,2,4,8,16) and (1,3,5,7,9,11,13,16)"""
+    vae = make_vae(32)
+    img = synth_images(2, 256, seed=1)
+    out = {}
+    with torch.no_grad():
+        for tag, pns in (('a', (1, 2, 4, 8, 16)), ('b', (1, 3, 5, 7, 9, 11, 13, 16))):
+            ids = vae.img_to_idxBl(img, v_patch_nums=pns)
+            rec = vae.img_to_recon(img, v_patch_nums=pns, last_one=True)
+            out[f'pns_{tag}'] = np.array(pns)
+            out[f'ids_{tag}'] = torch.cat(ids, dim=1).to(torch.int16)
+            out[f'rec_crop_{tag}'] = rec[:, :, 100:116, 60:76].clone()
+    save('tokenizer_alt', **out)
+
+
+def _forward_fixture(m, cfg, tag, xseed, labels, types, mask_first=True):
+    g = torch.Generator().manual_seed(xseed)
+    x = torch.randn(2, cfg.pyramid.L - cfg.pyramid.first_l, 32, generator=g)
+    with torch.no_grad():
+        logits = m(labels, x, types, mask_first)
+    t2 = logits.topk(2, dim=-1).values
+    save(f'forward_{tag}', keys=np.array(list(m.state_dict().keys())), labels=labels, types=types, logits_sample=logits[:, ::9, ::31].contiguous(),
+         argmax=logits.argmax(-1).to(torch.int16), margin=(t2[..., 0] - t2[..., 1]), lsum=logits.double().sum(-1).float())
+
+
+def case_separate_decoding():
+    """separate_decoding (per scale the control half is decoded before the image half) without and with indep:
+    masked teacher-forced logits, the two-pass inference branch (control_var.py:428-485) and the indep branch, which applies
+    the training mask's rows at inference (:497); conditional_infer_cfg for the indep model (:283)."""
+    vae = make_vae(32)
+    for tag, cfg, seed in (('d2s', VarConfig(depth=2, separate_decoding=True), 11), ('d2si', VarConfig(depth=2, separate_decoding=True, indep=True), 12)):
+        m = make_cvar(vae, cfg, seed=seed)
+        _forward_fixture(m, cfg, tag, 25, torch.tensor([8, 450]), torch.tensor([1, 3]))
+        r = _run_generate(m, ref_cv, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]))
+        save(f'gen_{tag}_b2', **r)
+    ctrl = synth_images(2, 256, seed=4)
+    with torch.no_grad():
+        c_ids = vae.img_to_idxBl(ctrl, v_patch_nums=PN)
+    r = _run_generate(m, ref_cv, 2, torch.tensor([5, 6]), (4.0, 3.0, 2.0), cond_type=torch.tensor([2, 3]), four=True, c_mask=c_ids)
+    save('gen_d2si_cmask', c_ids=torch.cat(c_ids, dim=1).to(torch.int16), **r)
+
+
+def case_more_smooth():
+    """more_smooth=True - Gumbel-softmax soft code embeddings instead of E[idx] (control_var.py:511-515,
+    helpers.py:22-36), drawn from the model's CPU generator after the id draw: joint branch with the sampling defaults, greedy
+    (top_k=1 masks all but the maximum in place, so the soft embedding collapses to E[argmax]), the 4-branch conditional form and the
+    two-pass branch."""
+    vae = make_vae(32)
+    m = make_cvar(vae, VarConfig(depth=2))
+    r = _run_generate(m, ref_cv, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]), top_k=900, top_p=0.96, seed=42, more_smooth=True)
+    save('gen_d2_smooth', **r)
+    r = _run_generate(m, ref_cv, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]), top_k=1, seed=1, more_smooth=True)
+    save('gen_d2_smooth_greedy', **r)
+    ctrl = synth_images(2, 256, seed=4)
+    with torch.no_grad():
+        c_ids = vae.img_to_idxBl(ctrl, v_patch_nums=PN)
+    r = _run_generate(m, ref_cv, 2, torch.tensor([5, 6]), (4.0, 4.0, 4.0), cond_type=torch.tensor([2, 3]), four=True, c_mask=c_ids, top_k=900, top_p=0.96,
+                      seed=7, more_smooth=True)
+    save('gen_d2_smooth_cmask', c_ids=torch.cat(c_ids, dim=1).to(torch.int16), **r)
+    ms = make_cvar(vae, VarConfig(depth=2, separate_decoding=True), seed=11)
+    r = _run_generate(ms, ref_cv, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]), top_k=900, top_p=0.96, seed=42, more_smooth=True)
+    save('gen_d2s_smooth', **r)
+
+
 CASES = {
     'interp': case_interp,
     'tok_tiny': lambda: case_tokenizer(32, 3, 'ch32'),
@@ -588,6 +653,10 @@ CASES = {
     'sa_block': case_sa_block,
     'train_sa_block': lambda: case_train_step(VarConfig(depth=2, sa_block=True, layer_scale=0.1), 'd2sa', 7),
     'train_variants': lambda: case_train_step(VarConfig(depth=2, shared_aln=True, type_pos=True), 'd2v', 5),
+    'tok_alt': case_tokenizer_alt,
+    'separate_decoding': case_separate_decoding,
+    'more_smooth': case_more_smooth,
+    'train_separate_decoding': lambda: case_train_step(VarConfig(depth=2, separate_decoding=True, indep=True), 'd2si', 12),
     'fwd_d12': case_forward_d12,
     'gen_d12_bf16emu': case_generate_d12_bf16emu,
     'gen_d30': case_generate_d30,

@@ -94,6 +94,27 @@ def test_ms_encode_random_features_against_oracle(gpu_device, B, amp, seed):
         assert_ids(idx.cpu(), ref, mref, 1e-4 * max(1.0, amp * amp), f'ms_encode B={B} margin path={want_margin}')
 
 
+def test_tokenizer_with_caller_chosen_scale_lists(gpu_device):
+    """vqvae.py:73-75: img_to_idxBl(v_patch_nums=...) with scale lists other than the constructor's, ids against the reference's
+    (tokenizer_alt.npz); img_to_recon(last_one=True) for the same lists; a list that does not end at the latent size raises as upstream"""
+    g = golden('tokenizer_alt')
+    vae = make_vae(32, F32, gpu_device)
+    img = synth_images(2, 256, seed=1).to(gpu_device)
+    for tag in ('a', 'b'):
+        pns = tuple(int(p) for p in g[f'pns_{tag}'])
+        ids = vae.img_to_idxBl(img, v_patch_nums=pns)
+        assert [tuple(i.shape) for i in ids] == [(2, p * p) for p in pns]
+        got = torch.cat(ids, dim=1).cpu().numpy()
+        mism = got != g[f'ids_{tag}'].astype(np.int64)
+        assert mism.mean() < 0.005, f'{tag}: {mism.sum()} of {mism.size} ids differ'        # fp32 conv-stack noise may flip a near-tie
+        if not mism.any():
+            rec = vae.img_to_recon(img, v_patch_nums=pns, last_one=True).cpu()
+            assert (rec[:, :, 100:116, 60:76] - t(g[f'rec_crop_{tag}'])).abs().max() < 2e-3
+    with pytest.raises(AssertionError):
+        vae.img_to_idxBl(img, v_patch_nums=(1, 2, 4, 8))
+    assert all(torch.equal(a, b) for a, b in zip(vae.img_to_idxBl(img, v_patch_nums=PN), vae.img_to_idxBl(img)))
+
+
 def test_next_input_all_scales(gpu_device):
     """A14: get_next_autoregressive_input for every scale against the reference fixture (<= 2e-5)."""
     g = golden('next_input')

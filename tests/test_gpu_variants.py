@@ -1,0 +1,243 @@
+"""SURVEY.md 8f N4 on the MI355X: separate_decoding (with / without indep) and more_smooth, against the reference's recorded
+generations / logits / training step; plus the (level end, hole) visibility of the attention kernels - forward and backward, row-wise
+and MFMA - against torch's softmax attention with the explicit additive mask the reference builds (control_var.py:158-191)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import golden  # noqa: E402
+from controlvar_amd import models, ops  # noqa: E402
+from controlvar_amd import train as T  # noqa: E402
+from controlvar_amd.spec import DEFAULT_PATCH_NUMS as PN, VaeConfig, VarConfig, attention_bias_matrix, attention_levels, phi_index_map  # noqa: E402
+from controlvar_amd.synth import synth_images, synth_vae_state, synth_var_state  # noqa: E402
+from oracle import var_ref  # noqa: E402
+from oracle.vqvae_ref import MSQuant  # noqa: E402
+
+F32, BF16 = torch.float32, torch.bfloat16
+SEPDEC = {'d2s': (VarConfig(depth=2, separate_decoding=True), 11), 'd2si': (VarConfig(depth=2, separate_decoding=True, indep=True), 12)}
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def make(cfg, dtype, dev, seed=0):
+    vae = models.build_vae(ch=32, compute_dtype=dtype).to(dev)
+    m = models.build_control_var(vae, depth=cfg.depth, mask_type='interleave_append', multi_cond=True, compute_dtype=dtype, cond_drop_rate=0.0,
+                                 separate_decoding=cfg.separate_decoding, indep=cfg.indep, init_seed=seed).to(dev).eval()
+    return vae, m
+
+
+def check_ids(got, ref, margin, tol, what):
+    got, ref = np.asarray(got).astype(np.int64), np.asarray(ref).astype(np.int64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    mism = got != ref
+    if mism.any():
+        worst = float(np.asarray(margin)[mism].max())
+        assert worst < tol, f'{what}: {int(mism.sum())} id mismatches, largest reference margin at a mismatch {worst:.3e}'
+    return int(mism.sum())
+
+
+# ---------------------------------------------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize('dtype', [F32, BF16])
+@pytest.mark.parametrize('variant', ['sep', 'sep_indep'])
+def test_attention_level_and_hole_masks_forward_backward(gpu_device, dtype, variant):
+    cfg = VarConfig(depth=2, separate_decoding=True, indep=variant == 'sep_indep')
+    lvl_end, holes = attention_levels(cfg)
+    vis = torch.from_numpy(attention_bias_matrix(cfg))
+    L = cfg.pyramid.L
+    bias = torch.where(vis, 0.0, -torch.inf)
+    R, H, c = 2, 2, 64
+    g = torch.Generator().manual_seed(9)
+    qkv = (torch.randn(R, L, 3 * H * c, generator=g) * 1.2).to(dtype)
+    qd = qkv.to(gpu_device).contiguous()
+    scale = 0.125
+    qf = qkv.float().view(R, L, 3, H, c).permute(2, 0, 3, 1, 4)
+    q, k, v = (x.clone().requires_grad_(True) for x in qf)
+    ref = torch.softmax(q @ k.transpose(-1, -2) * scale + bias, dim=-1) @ v               # (R, H, L, c)
+    do = torch.randn(R, L, H * c, generator=g).to(dtype)
+    gq, gk, gv = torch.autograd.grad(ref, (q, k, v), do.float().view(R, L, H, c).permute(0, 2, 1, 3))
+    ref_o = ref.detach().permute(0, 2, 1, 3).reshape(R * L, H * c)
+    ref_d = torch.stack((gq, gk, gv), dim=0).permute(1, 3, 0, 2, 4).reshape(R, L, 3 * H * c)
+    tol = 2e-4 if dtype == F32 else 2.5e-2
+    for rowwise in ([True] if dtype == F32 else [True, False]):
+        out = torch.empty(R * L, H * c, device=gpu_device, dtype=dtype)
+        lse = torch.empty(R, H, L, device=gpu_device)
+        ops.attention(qd, out, R, H, L, 0, L, scale, lvl_end, rowwise=rowwise, lse=lse, holes=holes)
+        err = (out.float().cpu() - ref_o).abs().max().item() / ref_o.abs().max().item()
+        assert err < tol, (variant, rowwise, err)
+        dqkv = torch.empty_like(qd)
+        ws = torch.empty(R * H * L + 16, device=gpu_device)
+        ops.attention_bwd(qd, out, do.to(gpu_device), lse, dqkv, ws, R, H, L, L, scale, lvl_end, rowwise=rowwise, holes=holes)
+        errb = (dqkv.float().cpu() - ref_d).abs().max().item() / ref_d.abs().max().item()
+        assert errb < 2 * tol, (variant, rowwise, errb)
+    # KV-cached form: only the last scale's queries, same visibility
+    b9, l9 = cfg.pyramid.begin[-1], cfg.pyramid.l[-1]
+    out9 = torch.empty(R * l9, H * c, device=gpu_device, dtype=dtype)
+    ops.attention(qd, out9, R, H, L, b9, l9, scale, lvl_end, holes=holes)
+    want = ref_o.view(R, L, H * c)[:, b9:].reshape(R * l9, H * c)
+    assert (out9.float().cpu() - want).abs().max().item() / want.abs().max().item() < tol
+    # malformed tables are refused
+    with pytest.raises(RuntimeError):
+        ops.attention(qd, out, R, H, L, 0, L, scale, [2, 2, 10], holes=None)
+    with pytest.raises(RuntimeError):
+        ops.attention(qd, out, R, H, L, 0, L, scale, [2, 10], holes=[(0, 0), (0, 5)])       # hole reaches into the level's own tokens
+
+
+# ---------------------------------------------------------------------------------------------------------------- models
+@pytest.mark.parametrize('tag', list(SEPDEC))
+def test_separate_decoding_forward_and_generate_fp32(gpu_device, tag):
+    cfg, seed = SEPDEC[tag]
+    vae, m = make(cfg, F32, gpu_device, seed)
+    g = golden(f'forward_{tag}')
+    gen = torch.Generator().manual_seed(25)
+    x = torch.randn(2, cfg.pyramid.L - cfg.pyramid.first_l, 32, generator=gen).to(gpu_device)
+    with torch.no_grad():
+        logits = m(t(g['labels']), x, t(g['types']), True).cpu()
+    assert (logits[:, ::9, ::31] - t(g['logits_sample'])).abs().max() < 2e-3
+    check_ids(logits.argmax(-1), g['argmax'], g['margin'], 2e-3, f'forward {tag}')
+    gg = golden(f'gen_{tag}_b2')
+    img = m.autoregressive_infer_cfg(2, torch.tensor([3, 7]), g_seed=0, cfg=4.0, top_k=1, cond_type=torch.tensor([0, 1]), _trace=True).cpu()
+    ids = torch.cat(m.last_trace['idx'], dim=1).cpu()
+    assert len(m.last_trace['idx']) == (20 if tag == 'd2s' else 10)                    # two-pass branch: 2 x 10 passes
+    nm = check_ids(ids, gg['ids'], gg['margin'], 2e-3, f'gen {tag}')
+    if nm == 0:
+        assert (img[:, :, 100:116, 60:76] - t(gg['img_crop'])).abs().max() < 2e-3
+        assert (img.mean(dim=(2, 3)) - t(gg['img_mean'])).abs().max() < 2e-4
+    if tag == 'd2si':
+        gc = golden('gen_d2si_cmask')
+        o, c_ids = 0, []
+        for p in PN:
+            c_ids.append(t(gc['c_ids'][:, o:o + p * p]).long())
+            o += p * p
+        img = m.conditional_infer_cfg(2, torch.tensor([5, 6]), g_seed=0, cfg=(4.0, 3.0, 2.0), top_k=1, cond_type=torch.tensor([2, 3]), c_mask=c_ids, _trace=True).cpu()
+        ids = torch.cat(m.last_trace['idx'], dim=1).cpu()
+        nm = check_ids(ids, gc['ids'], gc['margin'], 2e-3, 'conditional d2si')
+        if nm == 0:
+            assert (img[:, :, 100:116, 60:76] - t(gc['img_crop'])).abs().max() < 2e-3
+
+
+def test_separate_decoding_training_step_matches_reference(gpu_device):
+    """loss and every gradient of one step of the separate_decoding + indep model (masked attention backward with holes), fp32 mode"""
+    g = golden('train_step_d2si')
+    cfg, seed = SEPDEC['d2si']
+    vae, m = make(cfg, F32, gpu_device, seed)
+    images, masks = synth_images(2, 256, seed=6).to(gpu_device), synth_images(2, 256, seed=7).to(gpu_device)
+    mi = vae.img_to_idxBl(masks); mh = vae.idxBl_to_h(mi)
+    ii = vae.img_to_idxBl(images); ih = vae.idxBl_to_h(ii)
+    labels = torch.cat([torch.cat((a, b), 1) for a, b in zip(mi, ii)], dim=1)
+    x = torch.cat([torch.cat((a, b), 1) for a, b in zip(mh, ih)], dim=1)
+    assert np.array_equal(labels.cpu().numpy(), g['labels'].astype(np.int64))
+    eng = T.TrainEngine(m, drop_path=False)
+    loss, _ = eng.forward_backward(torch.tensor([17, 403]), x, torch.tensor([2, 0]), labels)
+    assert abs(loss.item() - float(g['loss'])) < 2e-5
+    grads = eng.grads()
+    gn = t(g['gnorms'])
+    for i, n in enumerate(str(k) for k in g['names']):
+        ref_n = gn[i].item()
+        assert abs(grads[n].norm().item() - ref_n) <= 2e-3 * max(ref_n, 1e-3 * float(g['total_norm'])), n
+        ref_slice = t(g['g:' + n])
+        got = grads[n].reshape(-1)[:: max(1, grads[n].numel() // 64)][:64].cpu()
+        assert (got - ref_slice).abs().max() <= 2e-3 * max(ref_slice.abs().max().item(), 1e-5) + 1e-7, n
+
+
+def test_separate_decoding_bf16_runs_and_cache_equals_mask(gpu_device):
+    """throughput mode: both variants generate finite images reproducibly; for indep, the KV-cached decode with the mask rows equals the
+    masked teacher-forced forward on every scale (cfg = 0, forced ids)"""
+    for tag in SEPDEC:
+        cfg, seed = SEPDEC[tag]
+        vae, m = make(cfg, BF16, gpu_device, seed)
+        a = m.autoregressive_infer_cfg(3, torch.tensor([1, 2, 3]), g_seed=5, cfg=3.0, top_k=900, top_p=0.96, cond_type=torch.tensor([0, 1, 2]))
+        b = m.autoregressive_infer_cfg(3, torch.tensor([1, 2, 3]), g_seed=5, cfg=3.0, top_k=900, top_p=0.96, cond_type=torch.tensor([0, 1, 2]))
+        assert torch.equal(a, b) and a.shape == (3, 3, 512, 256) and torch.isfinite(a).all()
+    gen = torch.Generator().manual_seed(3)
+    ids = [torch.randint(0, 4096, (2, 2 * p * p), generator=gen) for p in PN]
+    labels, types = torch.tensor([11, 500]), torch.tensor([1, 3])
+    m.autoregressive_infer_cfg(2, labels, g_seed=0, cfg=0.0, top_k=1, cond_type=types, _force_idx=ids, _trace=True)
+    inf_logits = torch.cat(m.last_trace['logits'], dim=1).float().cpu()
+    h_c = vae.idxBl_to_h([i[:, :p * p].to(gpu_device) for i, p in zip(ids, PN)])
+    h_i = vae.idxBl_to_h([i[:, p * p:].to(gpu_device) for i, p in zip(ids, PN)])
+    x = torch.cat([torch.cat((u, v), dim=1) for u, v in zip(h_c, h_i)], dim=1)
+    with torch.no_grad():
+        fw = m(labels, x, types).float().cpu()
+    assert (fw - inf_logits).abs().max().item() < 3e-2 * fw.abs().max().item()
+
+
+# ---------------------------------------------------------------------------------------------------------------- more_smooth
+def test_soft_embedding_kernel_against_torch(gpu_device):
+    """cvar_cfg_sample's more_smooth output on fixed logits and INJECTED Gumbel noise against the reference's formula evaluated with
+    torch on the same numbers (helpers.py:8-15 mask in place, then helpers.py:29-31 softmax((logits + g) / tau), control_var.py:515 @ E):
+    same inputs on both sides, so the comparison is well conditioned (1e-4), unlike a whole generation."""
+    g = torch.Generator().manual_seed(8)
+    B, nrep, l, V, Cv = 3, 2, 5, 4096, 32
+    logits = torch.randn(nrep * B, l, V, generator=g) * 2.5
+    E = torch.randn(V, Cv, generator=g)
+    coef = [3.0, -2.0]
+    for (top_k, top_p, mul, tau, n_draw) in ((900, 0.96, 1.5, 0.14, 1), (0, 0.9, 1.0, 0.27, 1), (50, 0.0, 2.0, 0.0135, 1)):
+        noise = -torch.empty(n_draw * B, l, V).exponential_(generator=g).log()
+        comb = coef[0] * logits[:B] + coef[1] * logits[B:]
+        masked = var_ref.topk_topp_mask_(comb.clone().repeat(n_draw, 1, 1), top_k, top_p)
+        want = (((masked * mul + noise) / tau).softmax(-1)) @ E
+        idx = torch.empty(n_draw * B, l, device=gpu_device, dtype=torch.int32)
+        soft = torch.empty(n_draw * B, l, Cv, device=gpu_device)
+        ops.cfg_sample(logits.to(gpu_device), B, nrep, l, V, coef, top_k, top_p, 5, 0, n_draw, idx, codebook=E.to(gpu_device), smooth_mul=mul, smooth_tau=tau,
+                       gumbel=noise.to(gpu_device), soft_out=soft)
+        err = (soft.cpu() - want).abs().amax(-1) / want.abs().amax(-1).clamp_min(1e-3)
+        assert (err < 1e-3).float().mean() > 0.9 and err.median() < 1e-4, (top_k, top_p, err.max().item(), err.median().item())
+        assert int(idx.min()) >= 0 and int(idx.max()) < V
+    with pytest.raises(RuntimeError):       # greedy has no soft form: the masked softmax is one-hot (callers use E[idx])
+        ops.cfg_sample(logits.to(gpu_device), B, nrep, l, V, coef, 1, 0.0, 5, 0, 1, idx, codebook=E.to(gpu_device), smooth_mul=1.0, smooth_tau=0.1, soft_out=soft)
+
+
+@pytest.mark.parametrize('case', ['joint', 'greedy', 'two_pass', 'conditional'])
+def test_more_smooth_generation(gpu_device, case):
+    """more_smooth end to end (control_var.py:326-330,459-463,511-515).  The oracle - pinned to the reference's draws by
+    gen_d2_smooth*.npz - exports its Gumbel noise; handed the same noise the HIP path follows it.  tau falls from 0.27 to 0.0135 over the
+    scales and amplifies fp32 summation-order noise ~75x per scale, so the trajectories separate slowly: the first scales' CFG
+    logits must agree to 1 %, the final feature maps only in bulk (correlation).  Greedy must be EXACTLY the hard path (the in-place
+    masked softmax is one-hot)."""
+    cfg, seed = (SEPDEC['d2s'] if case == 'two_pass' else (VarConfig(depth=2), 0))
+    vae, m = make(cfg, F32, gpu_device, seed)
+    sdv, sd = synth_vae_state(VaeConfig(ch=32)), synth_var_state(cfg, seed)
+    msq = MSQuant(sdv, PN, phi_index_map(10))
+    labels, types = torch.tensor([3, 7]), torch.tensor([0, 1])
+    if case == 'greedy':
+        a = m.autoregressive_infer_cfg(2, labels, g_seed=1, cfg=4.0, top_k=1, cond_type=types, more_smooth=True)
+        b = m.autoregressive_infer_cfg(2, labels, g_seed=1, cfg=4.0, top_k=1, cond_type=types, more_smooth=False)
+        assert torch.equal(a, b)
+        return
+    trace = {}
+    kw = dict(top_k=900, top_p=0.96, g_seed=42, cond_type=types, more_smooth=True, trace=trace)
+    with torch.no_grad():
+        if case == 'conditional':
+            ctrl = synth_images(2, 256, seed=4)
+            from oracle import vqvae_ref
+            c_ids = vqvae_ref.img_to_idxBl(sdv, msq, ctrl)
+            f_ref = var_ref.generate(sd, cfg, msq, 2, labels, (4.0, 4.0, 4.0), four_way=True, c_mask=c_ids, **kw)
+        else:
+            f_ref = var_ref.generate(sd, cfg, msq, 2, labels, 4.0, **kw)
+    common = dict(g_seed=42, top_k=900, top_p=0.96, cond_type=types, more_smooth=True, _gumbel=trace['gumbel'], _force_idx=trace['idx'], _trace=True)
+    if case == 'conditional':
+        m.conditional_infer_cfg(2, labels, cfg=(4.0, 4.0, 4.0), c_mask=c_ids, **common)
+    else:
+        m.autoregressive_infer_cfg(2, labels, cfg=4.0, **common)
+    tr = m.last_trace
+    npass = len(trace['logits'])
+    assert len(tr['logits']) == npass == (20 if case == 'two_pass' else 10)
+    for si in range(4 if case != 'two_pass' else 6):
+        ref = trace['logits'][si][:2]
+        assert (tr['logits'][si].cpu() - ref).abs().max() < 1e-2 * ref.abs().max(), (case, si)
+    got = tr['f_hat'].cpu()
+    for half in range(2):
+        a, b = got[:, half].reshape(-1).double(), f_ref[half].reshape(-1).double()
+        corr = torch.corrcoef(torch.stack((a, b)))[0, 1].item()
+        assert corr > 0.9, (case, half, corr)
+    if case == 'joint':       # own noise: reproducible per seed, different across seeds, different from the hard path
+        kw2 = dict(cfg=4.0, top_k=900, top_p=0.96, cond_type=types)
+        a = m.autoregressive_infer_cfg(2, labels, g_seed=5, more_smooth=True, **kw2)
+        b = m.autoregressive_infer_cfg(2, labels, g_seed=5, more_smooth=True, **kw2)
+        c = m.autoregressive_infer_cfg(2, labels, g_seed=6, more_smooth=True, **kw2)
+        d = m.autoregressive_infer_cfg(2, labels, g_seed=5, more_smooth=False, **kw2)
+        assert torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, d) and torch.isfinite(a).all()
