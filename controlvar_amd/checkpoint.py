@@ -34,9 +34,14 @@ def read_state(src: StateLike) -> "OrderedDict[str, torch.Tensor]":
     return OrderedDict((k.replace('module.', ''), v) for k, v in obj.items())
 
 
-def var_to_control_var_state(var_state: Mapping[str, torch.Tensor], patch_nums: Sequence[int], interpos: bool = False
-                             ) -> "OrderedDict[str, torch.Tensor]":
-    """The 'interleave_append' surgery of load_var_weight (:482-521), without separators (out of scope).
+def var_to_control_var_state(var_state: Mapping[str, torch.Tensor], patch_nums: Sequence[int], interpos: bool = False,
+                             separator: bool = False, mpos: bool = False, vocab_size: int = 4096) -> "OrderedDict[str, torch.Tensor]":
+    """The 'interleave_append' surgery of load_var_weight (:482-534).
+
+    separator=True (:504-517,523-533; only reached with interpos=False): per scale the pn^2 position rows are laid down for the control
+    half, a freshly drawn row (trunc_normal, std sqrt(1/(3C)), torch's global generator as upstream) for each separator, and the
+    image half is filled with ``pos * -1 if mpos else 1`` - operator precedence makes that the CONSTANT 1 unless mpos is set (:514);
+    the head grows to V + 18 rows: pretrained rows first, the rest trunc_normal * 0.02 (weight) and 0 (bias).
 
     interpos=False (the default of the training script, :103): pos_1LC' = cat(pos_1LC, pos_1LC) along L (:521).
     interpos=True: per scale, the pn² rows are laid down twice back to back - the [mask | image] order of the
@@ -53,18 +58,41 @@ def var_to_control_var_state(var_state: Mapping[str, torch.Tensor], patch_nums: 
             parts += [rows, rows]
             at += pn * pn
         sd['pos_1LC'] = torch.cat(parts, dim=1)
+    elif separator:
+        import math
+        C = pos.shape[-1]
+        init_std = math.sqrt(1 / C / 3)
+        parts, at = [], 0
+        for i, pn in enumerate(patch_nums):
+            sp = 1 if i != 0 else 0
+            pe = torch.empty((pn * pn + sp) * 2, C)
+            torch.nn.init.trunc_normal_(pe, mean=0, std=init_std)
+            pe[:pn * pn] = pos[0, at:at + pn * pn]
+            pe[pn * pn + sp:pn * pn * 2 + sp] = pos[0, at:at + pn * pn] * -1 if mpos else 1
+            parts.append(pe)
+            at += pn * pn
+        sd['pos_1LC'] = torch.cat(parts, dim=0).unsqueeze(0)
+        n_sp = (len(patch_nums) - 1) * 2
+        weight, bias = torch.empty(vocab_size + n_sp, C), torch.empty(vocab_size + n_sp)
+        torch.nn.init.trunc_normal_(weight, mean=0, std=init_std)
+        torch.nn.init.trunc_normal_(bias, mean=0, std=init_std)
+        weight.mul_(0.02); bias.mul_(0.0)
+        weight[:vocab_size] = sd['head.weight']
+        bias[:vocab_size] = sd['head.bias']
+        sd['head.weight'], sd['head.bias'] = weight, bias
     else:
         sd['pos_1LC'] = torch.cat([pos, pos], dim=1)
     return sd
 
 
-def load_var_weight(var, src: StateLike, interpos: bool = False):
+def load_var_weight(var, src: StateLike, interpos: bool = False, mpos: bool = False):
     """Initialise a ControlVAR from a pretrained VAR file (train_control_var_hpu.py:472-534).  Returns the
     (missing_keys, unexpected_keys) record of the non-strict load: for a published ``var_d*.pth`` the missing keys are
     exactly the three rebuilt tensors plus ``cond_embed.weight``."""
     sd = read_state(src)
     if getattr(var, 'mask_factor', 1) > 1:
-        sd = var_to_control_var_state(sd, var.patch_nums, interpos=interpos)
+        sd = var_to_control_var_state(sd, var.patch_nums, interpos=interpos, separator=bool(getattr(var, 'separator', False)), mpos=mpos,
+                                      vocab_size=var.V)
     return var.load_state_dict(sd, strict=False)
 
 

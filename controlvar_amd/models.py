@@ -441,7 +441,9 @@ class ControlVAR(nn.Module):
     ``separate_decoding`` (control half of a scale decoded before its image half; with ``indep`` the halves are blind to each other):
     masks as (level end, hole) tables of the attention kernels, the two-pass inference branch, and the mask applied at inference for
     ``indep``.  ``indep`` defaults to True as upstream's class does (a no-op without separate_decoding); the factory passes False.
-    ``more_smooth`` = Gumbel-softmax soft code embeddings.  ``separator`` raises: upstream cannot run it either.
+    ``more_smooth`` = Gumbel-softmax soft code embeddings.  ``separator`` (+18 special tokens, head V + 18, special_embed): upstream
+    indexes special_embed with V + k and raises IndexError everywhere (control_var.py:549,606); built with the evidently intended
+    index k for forward() / training and the joint inference branch - including upstream's placement quirks there (:507-509,538).
     """
     _control = True
 
@@ -452,9 +454,10 @@ class ControlVAR(nn.Module):
                  separator=False, type_pos=False, indep=True, multi_cond=False,
                  compute_dtype=None, init_seed: int = 0):
         super().__init__()
-        if separator:
-            raise NotImplementedError('separator (SURVEY.md 8f N4): upstream raises IndexError in forward() and in every inference branch '
-                                      '(special_embed is indexed with V + k, control_var.py:549,606) - not built')
+        if separator and not (self._control and mask_factor == 2):
+            raise NotImplementedError('separator needs the joint (control, image) sequence')
+        if separator and len(patch_nums) != 10:
+            raise NotImplementedError('separator: upstream hard-codes 18 special tokens (control_var.py:543)')
         if separate_decoding and not (self._control and mask_factor == 2):
             raise NotImplementedError('separate_decoding needs the joint (control, image) sequence')
         if bidirectional and not (self._control and mask_factor == 2):
@@ -472,8 +475,9 @@ class ControlVAR(nn.Module):
                              cos_attn=bool(cos_attn), mlp_ratio=mlp_ratio, cond_drop_rate=cond_drop_rate, drop_path_rate=float(drop_path_rate),
                              shared_aln=bool(shared_aln) and not sa_block, type_pos=bool(type_pos), sa_block=sa_block,
                              layer_scale=float(layer_scale) if sa_block else -1.0, bidirectional=bool(bidirectional),
-                             separate_decoding=bool(separate_decoding), indep=bool(indep) and self._control and mask_factor == 2)
-        self.separate_decoding, self.indep, self.separator, self.type_pos = self.cfg.separate_decoding, bool(indep), False, self.cfg.type_pos
+                             separate_decoding=bool(separate_decoding), indep=bool(indep) and self._control and mask_factor == 2,
+                             separator=bool(separator))
+        self.separate_decoding, self.indep, self.separator, self.type_pos = self.cfg.separate_decoding, bool(indep), self.cfg.separator, self.cfg.type_pos
         cfg = self.cfg
         self.bidirectional = cfg.bidirectional
         self.Cvae, self.V = cfg.cvae, cfg.vocab
@@ -560,8 +564,14 @@ class ControlVAR(nn.Module):
         P['w_ada'] = w_all.to(T).contiguous()
         P['b_ada'] = b_all.float().contiguous()
         P['n_ada'] = depth * 6 * C + 2 * C
-        P['w_head'] = sd[head_w].to(T).contiguous()
-        P['b_head'] = sd[head_b].float().contiguous()
+        hw, hb = sd[head_w], sd[head_b].float()
+        if cfg.head_ld != hw.shape[0]:               # separator: V + 18 = 4114 columns -> padded to 4120 (zero weight, -1e30 bias: softmax weight exactly 0)
+            hw = torch.cat((hw, hw.new_zeros(cfg.head_ld - hw.shape[0], hw.shape[1])))
+            hb = torch.cat((hb, hb.new_full((cfg.head_ld - hb.shape[0],), -1e30)))
+        P['w_head'] = hw.to(T).contiguous()
+        P['b_head'] = hb.contiguous()
+        P['special'] = sd['special_embed.weight'].float().contiguous() if cfg.separator else None
+        P['sp_rows'] = {}
         P['w_we'] = sd['word_embed.weight'].float().contiguous()
         P['b_we'] = sd['word_embed.bias'].float().contiguous()
         P['lvl_pos'] = (sd['lvl_embed.weight'][sd['lvl_1L'][0]] + sd['pos_1LC'][0]).float().contiguous()      # (L, C)
@@ -598,11 +608,45 @@ class ControlVAR(nn.Module):
         xv = x[:R * x_rows].view(R, x_rows, C)
         xv[:, :2] = xv[:, :2].flip(1)
 
+    def _special_rows(self, table, positions, rows):
+        """(len(positions), C): special_embed[rows] + table[positions] - the separator tokens as they enter the residual stream"""
+        P = self._pack()
+        key = (table.data_ptr(), tuple(positions), tuple(rows))
+        if key not in P['sp_rows']:
+            P['sp_rows'][key] = (P['special'][list(rows)] + table[list(positions)]).contiguous()
+        return P['sp_rows'][key]
+
+    def _embed_teacher_forced(self, P, tok, x, B: int, table, mask_first: bool):
+        """word_embed of the teacher-forcing tokens into the rows of x behind the first scale (+ level / position / type rows).  With
+        separators the code tokens of every half go to their own row range and the special rows are copied in between
+        (control_var.py:603-620, special_embed indexed by the label offset without V)."""
+        cfg = self.cfg
+        py, C = cfg.pyramid, cfg.C
+        if not cfg.separator:
+            ops.word_embed(tok, P['w_we'], P['b_we'], table, x, B, 1, py.L - py.first_l, cfg.cvae, C, py.L, py.first_l, lvl_off=py.first_l)
+            return
+        mapping = cfg.special_mapping(mask_first)
+        xv = x[:B * py.L].view(B, py.L, C)
+        cur = 0
+        for k in range(1, len(py.patch_nums)):
+            n = py.patch_nums[k] ** 2
+            for h in range(2):
+                row0 = py.begin[k] + h * (n + 1)
+                ops.word_embed(tok[:, cur:cur + n].contiguous(), P['w_we'], P['b_we'], table, x, B, 1, n, cfg.cvae, C, py.L, row0, lvl_off=row0)
+                cur += n
+        pos = [int(p) for p in py.special_positions()]
+        xv[:, pos] = self._special_rows(table, pos, [mapping[i] for i in range(len(pos))])
+
     def _get_arena(self, R: int, Lmax: int):
+        """KV arena [depth][R][Lmax][3C] of the calling stream (generations running concurrently on different streams must not share it)"""
+        sid = torch.cuda.current_stream(self.device).cuda_stream
         key = (R, Lmax, self.compute_dtype)
-        if self._arena is None or self._arena[0] != key:
-            self._arena = (key, torch.empty(self.cfg.depth, R, Lmax, 3 * self.cfg.C, device=self.device, dtype=self.compute_dtype))
-        return self._arena[1]
+        if self._arena is None:
+            self._arena = {}
+        ent = self._arena.get(sid)
+        if ent is None or ent[0] != key:
+            ent = self._arena[sid] = (key, torch.empty(self.cfg.depth, R, Lmax, 3 * self.cfg.C, device=self.device, dtype=self.compute_dtype))
+        return ent[1]
 
     # ---- one pass of all blocks + head over l new tokens per sequence
     def _blocks_and_head(self, x, ada, R: int, l: int, q_off: int, Lmax: int, arena, lvl_end=None, holes=None):
@@ -633,8 +677,8 @@ class ControlVAR(nn.Module):
                      gate_rows=l, residual=x)
         ah = cfg.depth * 6 * C
         ops.ln_modulate(x, ada, ah, ah + C, n_ada, l, u, M, C, cfg.norm_eps)
-        logits = torch.empty(M, cfg.vocab, device=dev, dtype=torch.float32)
-        ops.gemm(u, P['w_head'], logits, M=M, N=cfg.vocab, K=C, bias=P['b_head'])
+        logits = torch.empty(M, cfg.head_ld, device=dev, dtype=torch.float32)
+        ops.gemm(u, P['w_head'], logits, M=M, N=cfg.head_ld, K=C, bias=P['b_head'])
         return logits
 
     def _ada(self, cond: torch.Tensor, R: int):
@@ -701,6 +745,10 @@ class ControlVAR(nn.Module):
             # random.seed(k) before the call reproduces the reference's choice of order
             import random
             mask_first = True if (random.random() < 0.5 or not self.bidirectional) else False
+        if self.cfg.separator and (four_way or more_smooth or (self.cfg.separate_decoding and not self.cfg.indep)):
+            raise NotImplementedError('separator: conditional_infer_cfg ignores the special tokens (control_var.py:270-330), the two-pass branch fails with a '
+                                      'shape error (:481) and more_smooth slices the soft embeddings at shifted positions upstream; only forward(), training '
+                                      'and the joint autoregressive_infer_cfg branch are built')
         if self.cfg.separate_decoding and not self.cfg.indep and not four_way:              # control_var.py:428-485
             return self._generate_two_pass(B, labels_all, types_all, seed, cfg_scale, top_k, top_p, bool(more_smooth), force_idx, trace, mask_first, gumbel)
         return self._generate_core(B, labels_all, types_all, seed, None, cfg_scale, top_k, top_p, four_way, c_mask, c_img, force_idx, trace,
@@ -750,9 +798,10 @@ class ControlVAR(nn.Module):
                 soft = torch.empty(n_draw * B, l, cfg.cvae, device=dev, dtype=torch.float32)
                 ops.cfg_sample(logits, B, nrep, l, cfg.vocab, coef, top_k, top_p, seed, si, n_draw, idx, comb, mg, seed_dev=seed_dev, codebook=Pv['E'],
                                smooth_mul=1.0 + ratio, smooth_tau=max(0.27 * (1 - ratio * 0.95), 0.005),
-                               gumbel=gumbel[si].to(device=dev, dtype=torch.float32).contiguous() if gumbel is not None else None, soft_out=soft)
+                               gumbel=gumbel[si].to(device=dev, dtype=torch.float32).contiguous() if gumbel is not None else None, soft_out=soft,
+                               ldv=cfg.head_ld)
             else:
-                ops.cfg_sample(logits, B, nrep, l, cfg.vocab, coef, top_k, top_p, seed, si, n_draw, idx, comb, mg, seed_dev=seed_dev)
+                ops.cfg_sample(logits, B, nrep, l, cfg.vocab, coef, top_k, top_p, seed, si, n_draw, idx, comb, mg, seed_dev=seed_dev, ldv=cfg.head_ld)
             if trace:
                 tr['idx'].append(idx.clone()); tr['margin'].append(mg); tr['logits'].append(comb)
             if force_idx is not None:
@@ -762,8 +811,23 @@ class ControlVAR(nn.Module):
                     idx[:3 * B, :pn * pn] = c_mask[si].to(device=dev, dtype=torch.int32).repeat(3, 1)
                 if c_img is not None:
                     idx[:3 * B, pn * pn:] = c_img[si].to(device=dev, dtype=torch.int32).repeat(3, 1)
+            if cfg.separator and py.sp(si):
+                # control_var.py:507-509: the ids drawn at the separator positions are dropped from the THIRD scale on; at the second scale
+                # upstream keeps all 10 ids and slices [:pn^2] / [-pn^2:], so the image half becomes ids 6..9 - replicated literally
+                n = pn * pn
+                idx = (torch.cat((idx[:, :n], idx[:, n + 1:2 * n + 1]), dim=1) if si > 1 else torch.cat((idx[:, :n], idx[:, -n:]), dim=1)).contiguous()
             tok = vae._next_input(si, idx, f_hat, nb, mf, True, soft=soft)
-            if si != nstage - 1:
+            if si != nstage - 1 and cfg.separator:
+                # control_var.py:536-552: upstream stacks the two next-scale maps along H and splits the stack at row `pn` (the CURRENT
+                # scale's size) before putting a separator behind each part: the first one lands behind pn * pn' tokens
+                ln, pn2 = py.l[si + 1], py.patch_nums[si + 1]
+                cut, nrep_x = pn * pn2, 2
+                ops.word_embed(tok[:, :cut].contiguous(), P['w_we'], P['b_we'], gen_table, x, nb, nrep_x, cut, cfg.cvae, C, ln, 0, lvl_off=py.end[si])
+                ops.word_embed(tok[:, cut:].contiguous(), P['w_we'], P['b_we'], gen_table, x, nb, nrep_x, 2 * pn2 * pn2 - cut, cfg.cvae, C, ln, cut + 1,
+                               lvl_off=py.end[si] + cut + 1)
+                mapping = cfg.special_mapping(mask_first)
+                x[:R * ln].view(R, ln, C)[:, [cut, ln - 1]] = self._special_rows(gen_table, [py.end[si] + cut, py.end[si] + ln - 1], [mapping[2 * si], mapping[2 * si + 1]])
+            elif si != nstage - 1:
                 ln = py.l[si + 1]
                 ops.word_embed(tok, P['w_we'], P['b_we'], gen_table, x, nb, 1 if four_way else 2, ln,
                                cfg.cvae, C, ln, 0, lvl_off=py.end[si])
@@ -929,12 +993,14 @@ class ControlVAR(nn.Module):
         table = P['lvl_pos_fwd'] if mask_first else P['lvl_pos_fwd_']
         self._first_tokens(P, labels, types, x, cond, B, py.L, table, mask_first)
         tok = x_BLCv_wo_first_l.to(device=dev, dtype=torch.float32).contiguous()
-        ops.word_embed(tok, P['w_we'], P['b_we'], table, x, B, 1, py.L - py.first_l, cfg.cvae, C, py.L, py.first_l, lvl_off=py.first_l)
+        if tok.shape[1] != len(py.code_positions()) - py.first_l:
+            raise AssertionError(f'teacher-forcing input has {tok.shape[1]} tokens, expected {len(py.code_positions()) - py.first_l}')       # control_var.py:617
+        self._embed_teacher_forced(P, tok, x, B, table, mask_first)
         ada = self._ada(cond, B)
         arena = self._get_arena(B, py.L)
         lvl_end, holes = attention_levels(cfg)
         logits = self._blocks_and_head(x, ada, B, py.L, 0, py.L, arena, lvl_end=lvl_end, holes=holes)
-        return logits.view(B, py.L, cfg.vocab)
+        return logits.view(B, py.L, cfg.head_ld)[:, :, :cfg.head_out]
 
 
 class VAR(ControlVAR):

@@ -52,6 +52,7 @@ class Pyramid:
     """
     patch_nums: Tuple[int, ...] = DEFAULT_PATCH_NUMS
     mask_factor: int = 2
+    separator: bool = False                       # one special token behind every half of every scale but the first (control_var.py:58-66)
     l: Tuple[int, ...] = field(init=False)        # tokens per scale
     begin: Tuple[int, ...] = field(init=False)    # first token of scale k
     end: Tuple[int, ...] = field(init=False)      # one past the last token of scale k
@@ -59,7 +60,7 @@ class Pyramid:
     first_l: int = field(init=False)
 
     def __post_init__(self):
-        l = tuple(self.mask_factor * pn * pn for pn in self.patch_nums)
+        l = tuple(self.mask_factor * (pn * pn + (1 if (self.separator and i != 0) else 0)) for i, pn in enumerate(self.patch_nums))
         end = tuple(int(x) for x in np.cumsum(l))
         begin = (0,) + end[:-1]
         object.__setattr__(self, 'l', l)
@@ -71,6 +72,28 @@ class Pyramid:
     @property
     def num_scales(self) -> int:
         return len(self.patch_nums)
+
+    def sp(self, k: int) -> int:
+        """special tokens per half of scale k"""
+        return 1 if (self.separator and k != 0) else 0
+
+    def code_positions(self) -> np.ndarray:
+        """(sum mf*pn^2,) positions of the CODE tokens (everything but the separators) inside the L-long sequence, in order"""
+        out = []
+        for k, (b, pn) in enumerate(zip(self.begin, self.patch_nums)):
+            half = pn * pn + self.sp(k)
+            for h in range(self.mask_factor):
+                out += list(range(b + h * half, b + h * half + pn * pn))
+        return np.asarray(out, dtype=np.int64)
+
+    def special_positions(self) -> np.ndarray:
+        """(n_special,) positions of the separator tokens, in sequence order (= special_embed row order for mask-first sequences)"""
+        out = []
+        for k, (b, pn) in enumerate(zip(self.begin, self.patch_nums)):
+            if self.sp(k):
+                half = pn * pn + 1
+                out += [b + h * half + pn * pn for h in range(self.mask_factor)]
+        return np.asarray(out, dtype=np.int64)
 
     def level_of_token(self) -> np.ndarray:
         """(L,) int64: scale index of every position (lvl_1L, control_var.py:158-166)."""
@@ -106,6 +129,8 @@ class VarConfig:
     separate_decoding: bool = False # N4: per scale the control half is decoded before the image half (control_var.py:170-180,428-485)
     indep: bool = False             # N4: with separate_decoding, the two halves of a scale are blind to each other (control_var.py:182-191);
                                     #     without it the flag only makes inference pass (all-visible) slices of the mask (:283,:497)
+    separator: bool = False         # N4: +18 special tokens / head columns / special_embed rows (control_var.py:58-66,201-210).  Upstream indexes
+                                    #     special_embed with V + k (:549,606) and raises; built with the evidently intended index k
 
     @property
     def C(self) -> int:
@@ -117,7 +142,27 @@ class VarConfig:
 
     @property
     def pyramid(self) -> Pyramid:
-        return Pyramid(self.patch_nums, self.mask_factor)
+        return Pyramid(self.patch_nums, self.mask_factor, bool(self.separator) and self.mask_factor == 2)
+
+    @property
+    def n_special(self) -> int:
+        return (len(self.patch_nums) - 1) * self.mask_factor if self.separator else 0
+
+    @property
+    def head_out(self) -> int:
+        """columns of the head: the V codes + the separator labels (control_var.py:201-204)"""
+        return self.vocab + self.n_special
+
+    @property
+    def head_ld(self) -> int:
+        """head_out rounded up to 8 columns: the packed head / logits buffers carry zero-weight, -1e30-bias padding columns so that the
+        GEMM epilogue stays on its 16-byte path (softmax / CE weight of a padding column is exactly 0)"""
+        return (self.head_out + 7) // 8 * 8
+
+    @staticmethod
+    def special_mapping(mask_first: bool = True):
+        """special_embed row / label offset of the i-th separator in sequence order (control_var.py:543,605; train_control_var_hpu.py:215)"""
+        return list(range(18)) if mask_first else [i + 1 if i % 2 == 0 else i - 1 for i in range(18)]
 
     @property
     def uses_cos_attn(self) -> bool:
@@ -142,7 +187,7 @@ def attention_levels(cfg: VarConfig):
         return list(py.end), None
     ends, holes = [], []
     for b, e in zip(py.begin, py.end):
-        half = (e - b) // 2
+        half = (e - b) // 2                           # pn^2 (+ 1 separator)
         ends += [b + half, e]
         holes += [(0, 0), (b, b + half) if cfg.indep else (0, 0)]
     return ends, (holes if cfg.indep else None)
@@ -222,13 +267,15 @@ def var_state_shapes(cfg: VarConfig) -> "OrderedDict[str, Tuple[Tuple[int, ...],
     if cfg.sa_block:                                 # control_var.py:205-207: MultiInpIdentity + Sequential(norm, Linear)
         sd['head.0.weight'] = ((C,), 'param')
         sd['head.0.bias'] = ((C,), 'param')
-        sd['head.1.weight'] = ((V, C), 'param')
-        sd['head.1.bias'] = ((V,), 'param')
+        sd['head.1.weight'] = ((cfg.head_out, C), 'param')
+        sd['head.1.bias'] = ((cfg.head_out,), 'param')
     else:
         sd['head_nm.ada_lin.1.weight'] = ((2 * C, C), 'param')
         sd['head_nm.ada_lin.1.bias'] = ((2 * C,), 'param')
-        sd['head.weight'] = ((V, C), 'param')
-        sd['head.bias'] = ((V,), 'param')
+        sd['head.weight'] = ((cfg.head_out, C), 'param')
+        sd['head.bias'] = ((cfg.head_out,), 'param')
+    if cfg.separator:
+        sd['special_embed.weight'] = ((cfg.n_special, C), 'param')
     if cfg.control and cfg.multi_cond:
         sd['cond_embed.weight'] = ((NUM_COND_TYPES + 1, C), 'param')
     return sd

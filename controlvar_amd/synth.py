@@ -43,8 +43,8 @@ def synth_var_state(cfg: VarConfig, seed: int = 0, head_gain: float = 4.0) -> Di
         elif key in ('type_1L', 'type_1L_'):
             first = 1 if key == 'type_1L' else 0                     # control half id; the image half gets the other one
             ids = []
-            for pn in py.patch_nums:
-                ids += [first] * (pn * pn) + [1 - first] * (pn * pn)
+            for k, pn in enumerate(py.patch_nums):
+                ids += [first] * (pn * pn + py.sp(k)) + [1 - first] * (pn * pn + py.sp(k))
             out[key] = torch.tensor(ids, dtype=torch.int64).view(1, -1)
         elif key.endswith('gamma1') or key.endswith('gamma2'):
             out[key] = _randn(shape, g, std=0.1, mean=0.35)
@@ -58,7 +58,7 @@ def synth_var_state(cfg: VarConfig, seed: int = 0, head_gain: float = 4.0) -> Di
             out[key] = torch.zeros(shape)
         elif key.endswith('scale_mul_1H11'):
             out[key] = _randn(shape, g, std=0.3, mean=math.log(4.0))
-        elif key in ('pos_start', 'pos_1LC', 'lvl_embed.weight', 'cond_embed.weight', 'type_embed.weight'):
+        elif key in ('pos_start', 'pos_1LC', 'lvl_embed.weight', 'cond_embed.weight', 'type_embed.weight', 'special_embed.weight'):
             out[key] = _randn(shape, g, std=0.5)
         elif key == 'class_emb.weight':
             out[key] = _randn(shape, g, std=1.0)

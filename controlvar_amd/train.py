@@ -124,7 +124,7 @@ class TrainEngine:
             return
         cfg, var = self.cfg, self.var
         dev, T = var.device, var.compute_dtype
-        C, depth, V = cfg.C, cfg.depth, cfg.vocab
+        C, depth, V = cfg.C, cfg.depth, cfg.head_ld          # head columns incl. separator labels, padded to 8 (spec.VarConfig.head_ld)
         L = cfg.pyramid.L
         M = B * L
         hid = round(C * cfg.mlp_ratio)
@@ -154,8 +154,9 @@ class TrainEngine:
         nmax = max(hid, 3 * C, V)
         self.TA = torch.zeros(nmax * self.Mp, **tT)           # zero padding columns stay zero
         self.TB = torch.zeros(nmax * self.Mp, **tT)
-        self.TA32 = torch.zeros(C * _pad8(B * (L - cfg.pyramid.first_l)), **f32)
-        self.TB32 = torch.zeros(cfg.cvae * _pad8(B * (L - cfg.pyramid.first_l)), **f32)
+        self.ncode = len(cfg.pyramid.code_positions()) - cfg.pyramid.first_l         # teacher-forcing tokens per sample (separators excluded)
+        self.TA32 = torch.zeros(C * _pad8(B * self.ncode), **f32)
+        self.TB32 = torch.zeros(cfg.cvae * _pad8(B * self.ncode), **f32)
         self.dada = torch.zeros(B, n_ada, **f32)
         self.ws = torch.empty(max(2 * M + 16 * B * C, 64 * max(hid, 3 * C, V, n_ada), L * C, B * cfg.H * L,
                                   6 * C * C if cfg.shared_aln else 0) + 16, **f32)
@@ -175,6 +176,8 @@ class TrainEngine:
             misc += [('w_shared', 6 * C * C), ('b_shared', 6 * C)]
         if cfg.type_pos:
             misc += [('type', cfg.mask_factor * C)]
+        if cfg.separator:
+            misc += [('special', cfg.n_special * C)]
         self.misc_off = {}
         o = 0
         for name, n in misc:
@@ -188,7 +191,7 @@ class TrainEngine:
     def _transposed_weights(self):
         """W^T copies for the data-gradient GEMMs (refreshed after every optimizer step)."""
         P, cfg = self.var._pack(), self.cfg
-        C, depth, V = cfg.C, cfg.depth, cfg.vocab
+        C, depth, V = cfg.C, cfg.depth, cfg.head_ld
         hid = P['w_fc1'].shape[1]
         T = self.var.compute_dtype
         dev = self.var.device
@@ -205,7 +208,7 @@ class TrainEngine:
     def grads(self) -> Dict[str, torch.Tensor]:
         """state_dict key -> gradient view (fp32)"""
         cfg = self.cfg
-        C, depth, V = cfg.C, cfg.depth, cfg.vocab
+        C, depth, V, Vo = cfg.C, cfg.depth, cfg.head_ld, cfg.head_out
         hid = round(C * cfg.mlp_ratio)
         so = self.slab_off
         g: Dict[str, torch.Tensor] = {}
@@ -241,11 +244,11 @@ class TrainEngine:
         if cfg.sa_block:            # head = Sequential(LayerNorm, Linear) (control_var.py:205-207)
             hb = self.G_ada[n_ada * C:][depth * 6 * C:]
             g['head.0.weight'], g['head.0.bias'] = hb[:C], hb[C:]
-            g['head.1.weight'] = mo('w_head').view(V, C); g['head.1.bias'] = mo('b_head')
+            g['head.1.weight'] = mo('w_head').view(V, C)[:Vo]; g['head.1.bias'] = mo('b_head')[:Vo]
         else:
             g['head_nm.ada_lin.1.weight'] = self.G_ada[:n_ada * C].view(n_ada, C)[depth * 6 * C:]
             g['head_nm.ada_lin.1.bias'] = self.G_ada[n_ada * C:][depth * 6 * C:]
-            g['head.weight'] = mo('w_head').view(V, C); g['head.bias'] = mo('b_head')
+            g['head.weight'] = mo('w_head').view(V, C)[:Vo]; g['head.bias'] = mo('b_head')[:Vo]
         g['word_embed.weight'] = mo('w_we').view(C, cfg.cvae); g['word_embed.bias'] = mo('b_we')
         g['pos_1LC'] = mo('pos').view(1, py.L, C); g['lvl_embed.weight'] = mo('lvl').view(len(cfg.patch_nums), C)
         g['pos_start'] = mo('pos_start').view(1, py.first_l, C)
@@ -256,6 +259,8 @@ class TrainEngine:
             g['shared_ada_lin.1.weight'] = mo('w_shared').view(6 * C, C); g['shared_ada_lin.1.bias'] = mo('b_shared')
         if cfg.type_pos:
             g['type_embed.weight'] = mo('type').view(cfg.mask_factor, C)
+        if cfg.separator:
+            g['special_embed.weight'] = mo('special').view(cfg.n_special, C)
         return g
 
     # ---------------------------------------------------------------- forward + backward
@@ -265,7 +270,7 @@ class TrainEngine:
         """-> (loss scalar tensor, per-token loss (B*L,)); gradients land in self.grads() (overwritten, not accumulated)."""
         self.forward_train(label_B, x_wo_first, cond_type, drop_seed, mask_first)
         dev = self.var.device
-        M, V = self.M, self.cfg.vocab
+        M, V = self.M, self.cfg.head_ld
         tg = targets.to(device=dev, dtype=torch.int32).contiguous().view(-1)
         if ignore_mask is not None:                                  # train_control_var_hpu.py:233-237
             w = ignore_mask.to(device=dev, dtype=torch.float32).contiguous().view(-1)
@@ -283,7 +288,7 @@ class TrainEngine:
         """teacher-forced forward that keeps every block's activations; returns logits (B*L, V) fp32"""
         cfg, var = self.cfg, self.var
         P = var._pack(check=True)
-        py, C, depth, V, H = cfg.pyramid, cfg.C, cfg.depth, cfg.vocab, cfg.H
+        py, C, depth, V, H = cfg.pyramid, cfg.C, cfg.depth, cfg.head_ld, cfg.H
         L, fl = py.L, py.first_l
         dev, T = var.device, var.compute_dtype
         B = x_wo_first.shape[0]
@@ -326,7 +331,9 @@ class TrainEngine:
         table = P['lvl_pos_fwd'] if mask_first else P['lvl_pos_fwd_']
         var._first_tokens(P, labels, types, x0, cond, B, L, table, mask_first)
         tok = x_wo_first.to(device=dev, dtype=torch.float32).contiguous()
-        ops.word_embed(tok, P['w_we'], P['b_we'], table, x0, B, 1, L - fl, cfg.cvae, C, L, fl, lvl_off=fl)
+        if tok.shape[1] != self.ncode:
+            raise AssertionError(f'teacher-forcing input has {tok.shape[1]} tokens, expected {self.ncode}')
+        var._embed_teacher_forced(P, tok, x0, B, table, mask_first)
         cs = torch.empty(B, C, device=dev, dtype=T)
         ops.silu_cast(cond, cs)
         ada = torch.empty(B, n_ada, device=dev, dtype=torch.float32)
@@ -360,7 +367,7 @@ class TrainEngine:
         """backward from self.dlogits (compute dtype, (B*L, V)) through head, blocks, adaLN generator and embeddings"""
         cfg, var = self.cfg, self.var
         P = var._pack()
-        py, C, depth, V, H = cfg.pyramid, cfg.C, cfg.depth, cfg.vocab, cfg.H
+        py, C, depth, V, H = cfg.pyramid, cfg.C, cfg.depth, cfg.head_ld, cfg.H
         L, fl = py.L, py.first_l
         dev, T = var.device, var.compute_dtype
         sv = self._saved
@@ -450,9 +457,17 @@ class TrainEngine:
                 for tid, r0 in (((1, b0), (0, b0 + half)) if self._mask_first else ((0, b0), (1, b0 + half))):
                     ops.colsum(Gm, C, Gm, half, C, ws, accumulate=(k > 0), a_off=mo['pos'][0] + r0 * C, out_off=mo['type'][0] + tid * C)
         Gm[mo['pos_start'][0]:mo['pos_start'][0] + fl * C].copy_(Gm[mo['pos'][0]:mo['pos'][0] + fl * C])
-        Mt = B * (L - fl)
+        Mt = B * self.ncode
         Mtp = _pad8(Mt)
-        self._word_embed_grads(tok, B, L, fl, C, Mt, Mtp)
+        if cfg.separator:           # code rows are interleaved with the separator rows: gather them; the separators' gradient is the batch sum of their rows
+            code = torch.from_numpy(py.code_positions()[fl:]).to(dev)
+            dXw = self.dX.view(B, L, C)[:, code].contiguous()               # (B, ncode, C)
+            self._word_embed_grads(tok, B, self.ncode + fl, fl, C, Mt, Mtp, src=dXw, src_has_first=False)
+            mapping = cfg.special_mapping(self._mask_first)
+            for j, pos in enumerate(int(q) for q in py.special_positions()):
+                ops.colsum(self.dX, L * C, Gm, B, C, ws, a_off=pos * C, out_off=mo['special'][0] + mapping[j] * C)
+        else:
+            self._word_embed_grads(tok, B, L, fl, C, Mt, Mtp)
         cls_o, cnd_o = mo['class_emb'][0], mo['cond_embed'][0]
         Gm[cls_o:cls_o + mo['class_emb'][1]].zero_()
         Gm[cnd_o:cnd_o + mo['cond_embed'][1]].zero_()
@@ -465,16 +480,21 @@ class TrainEngine:
         if self.reducer is not None:
             self.reducer.ready(depth + 1)
 
-    def _word_embed_grads(self, tok, B, L, fl, C, Mt, Mtp):
+    def _word_embed_grads(self, tok, B, L, fl, C, Mt, Mtp, src=None, src_has_first=True):
+        """src: gradient rows of the word-embedded tokens - self.dX with L rows per sample of which the first fl are skipped, or a compact
+        (B, L - fl, C) gather of them (separator models)"""
         cfg = self.cfg
         mo = self.misc_off
         Gm = self.G_misc
-        for b in range(B):      # dX rows of sample b -> columns [b*(L-fl), (b+1)*(L-fl)) of TA32 ([C][Mtp])
-            ops.transpose(self.dX, self.TA32[b * (L - fl):], 1, L - fl, C, C, in_off=(b * L + fl) * C, ld_out=Mtp)
+        src = self.dX if src is None else src
+        rows = L if src_has_first else L - fl
+        skip = fl if src_has_first else 0
+        for b in range(B):      # gradient rows of sample b -> columns [b*(L-fl), (b+1)*(L-fl)) of TA32 ([C][Mtp])
+            ops.transpose(src, self.TA32[b * (L - fl):], 1, L - fl, C, C, in_off=(b * rows + skip) * C, ld_out=Mtp)
         ops.transpose(tok, self.TB32, 1, Mt, cfg.cvae, cfg.cvae, ld_out=Mtp)
         ops.gemm(self.TA32, self.TB32, Gm, M=C, N=cfg.cvae, K=Mtp, c_off=mo['w_we'][0])
         for b in range(B):
-            ops.colsum(self.dX, C, Gm, L - fl, C, self.ws, accumulate=(b > 0), a_off=(b * L + fl) * C, out_off=mo['b_we'][0])
+            ops.colsum(src, C, Gm, L - fl, C, self.ws, accumulate=(b > 0), a_off=(b * rows + skip) * C, out_off=mo['b_we'][0])
 
 
 class BucketReducer:
@@ -642,8 +662,17 @@ class Trainer:
         ii = self.vae.img_to_idxBl(images); ih = self.vae.idxBl_to_h(ii)
         if not mask_first:
             mi, ii, mh, ih = ii, mi, ih, mh
-        labels = torch.cat([torch.cat((a, b), 1) for a, b in zip(mi, ii)], dim=1)
         x = torch.cat([torch.cat((a, b), 1) for a, b in zip(mh, ih)], dim=1)
+        cfg = self.var.cfg
+        if cfg.separator:           # train_control_var_hpu.py:214-224: the label of a separator is V + its special_embed row
+            mapping = cfg.special_mapping(mask_first)
+            parts = [mi[0], ii[0]]
+            for k in range(1, len(mi)):
+                for h, ids in enumerate((mi[k], ii[k])):
+                    parts += [ids, ids.new_full((ids.shape[0], 1), cfg.vocab + mapping[2 * (k - 1) + h])]
+            labels = torch.cat(parts, dim=1)
+        else:
+            labels = torch.cat([torch.cat((a, b), 1) for a, b in zip(mi, ii)], dim=1)
         return x, labels
 
     @torch.no_grad()
@@ -683,12 +712,14 @@ class _TeacherForcedFn(torch.autograd.Function):
         logits = engine.forward_train(label_B, x, cond_type, None, mask_first)
         ctx.engine = engine
         B = x.shape[0]
-        return logits.view(B, -1, logits.shape[-1]).clone()
+        return logits.view(B, -1, logits.shape[-1])[:, :, :engine.cfg.head_out].clone()       # head_ld padding columns are not part of the API
 
     @staticmethod
     def backward(ctx, dlogits):
         eng = ctx.engine
-        eng.dlogits.copy_(dlogits.reshape(eng.M, -1))
+        if eng.cfg.head_ld != eng.cfg.head_out:
+            eng.dlogits.zero_()
+        eng.dlogits[:, :eng.cfg.head_out].copy_(dlogits.reshape(eng.M, -1))
         eng.backward()
         g = eng.grads()
         return (None, None, None, None, None) + tuple(g[n].clone() for n, _ in eng.var.named_parameters())

@@ -70,11 +70,18 @@ def make_cvar(vae, cfg: VarConfig, seed=0):
             m = quiet(build_control_var, vae, depth=cfg.depth, patch_nums=PN, mask_type='interleave_append' if cfg.mask_factor == 2 else 'replace',
                       cond_drop_rate=0.0, multi_cond=cfg.multi_cond, flash_if_available=False, fused_if_available=False,
                       shared_aln=cfg.shared_aln, type_pos=cfg.type_pos, aln=-1 if cfg.sa_block else 1, layer_scale=cfg.layer_scale,
-                      bidirectional=cfg.bidirectional, separate_decoding=cfg.separate_decoding, indep=cfg.indep)
+                      bidirectional=cfg.bidirectional, separate_decoding=cfg.separate_decoding, indep=cfg.indep, separator=cfg.separator)
     else:
         m = quiet(build_var, vae, depth=cfg.depth, patch_nums=PN, flash_if_available=False, fused_if_available=False, shared_aln=cfg.shared_aln)
         m.cond_drop_rate = 0.0
     m.load_state_dict(synth_var_state(cfg, seed), strict=True)
+    if getattr(cfg, 'separator', False):
+        # upstream bug: special_embed (18 rows) is indexed with V + k (control_var.py:549,606) -> IndexError in forward() and inference.
+        # The fixtures are recorded with the evidently intended index k: this wraps the INSTANCE's embedding call, the reference source
+        # runs unmodified otherwise.
+        emb, V = m.special_embed, m.V
+        orig = emb.forward
+        emb.forward = lambda idx: orig(torch.where(idx >= V, idx - V, idx))
     return m.eval()
 
 
@@ -341,6 +348,12 @@ def case_train_step(cfg=None, tag='d2', wseed=0, mask_first=True):
         labels_list = list(chain.from_iterable(zip(img_ids, mask_ids)))
         h_list = list(chain.from_iterable(zip(img_h, mask_h)))
     x = torch.cat(h_list, dim=1)
+    if getattr(cfg, 'separator', False):             # train_control_var_hpu.py:214-224: a separator label behind every half of scales >= 1
+        mapping = [i for i in range(18)] if mask_first else [i + 1 if i % 2 == 0 else i - 1 for i in range(18)]
+        new = [labels_list[0], labels_list[1]]
+        for i, label in enumerate(labels_list[2:]):
+            new.extend([label, label.new_ones(label.shape[0], 1) * (mapping[i] + 4096)])
+        labels_list = new
     labels = torch.cat(labels_list, dim=1)
     logits = m(cls, x, types, mask_first)
     loss_tok = torch.nn.CrossEntropyLoss(reduction='none')(logits.view(-1, logits.size(-1)), labels.view(-1))
@@ -584,7 +597,7 @@ def case_tokenizer_alt():
 
 def _forward_fixture(m, cfg, tag, xseed, labels, types, mask_first=True):
     g = torch.Generator().manual_seed(xseed)
-    x = torch.randn(2, cfg.pyramid.L - cfg.pyramid.first_l, 32, generator=g)
+    x = torch.randn(2, len(cfg.pyramid.code_positions()) - cfg.pyramid.first_l, 32, generator=g)       # code tokens only (no separators)
     with torch.no_grad():
         logits = m(labels, x, types, mask_first)
     t2 = logits.topk(2, dim=-1).values
@@ -631,6 +644,18 @@ def case_more_smooth():
     save('gen_d2s_smooth', **r)
 
 
+def case_separator():
+    """separator=True (18 special tokens, head V + 18, special_embed), recorded with the index shim of make_cvar:
+    teacher-forced logits and the joint inference branch, alone and combined with separate_decoding + indep (the two combinations whose
+    inference runs upstream once the index is fixed; the two-pass branch still fails there with a shape error)."""
+    vae = make_vae(32)
+    for tag, cfg, seed in (('d2p', VarConfig(depth=2, separator=True), 13), ('d2psi', VarConfig(depth=2, separator=True, separate_decoding=True, indep=True), 14)):
+        m = make_cvar(vae, cfg, seed=seed)
+        _forward_fixture(m, cfg, tag, 26, torch.tensor([9, 451]), torch.tensor([0, 2]))
+        r = _run_generate(m, ref_cv, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]))
+        save(f'gen_{tag}_b2', **r)
+
+
 CASES = {
     'interp': case_interp,
     'tok_tiny': lambda: case_tokenizer(32, 3, 'ch32'),
@@ -654,6 +679,8 @@ CASES = {
     'train_sa_block': lambda: case_train_step(VarConfig(depth=2, sa_block=True, layer_scale=0.1), 'd2sa', 7),
     'train_variants': lambda: case_train_step(VarConfig(depth=2, shared_aln=True, type_pos=True), 'd2v', 5),
     'tok_alt': case_tokenizer_alt,
+    'separator': case_separator,
+    'train_separator': lambda: case_train_step(VarConfig(depth=2, separator=True), 'd2p', 13),
     'separate_decoding': case_separate_decoding,
     'more_smooth': case_more_smooth,
     'train_separate_decoding': lambda: case_train_step(VarConfig(depth=2, separate_decoding=True, indep=True), 'd2si', 12),

@@ -133,7 +133,8 @@ def test_state_dict_roundtrip_with_module_prefix():
 # ------------------------------------------------------------------------------ variant flags (host side)
 @pytest.mark.parametrize('fixture,kw', [('forward_d2v', dict(shared_aln=True, type_pos=True)), ('forward_d2sa', dict(aln=-1, layer_scale=0.1)),
                                         ('forward_d2sa0', dict(aln=-1)), ('forward_d2b', dict(bidirectional=True, type_pos=True)),
-                                        ('forward_d2s', dict(separate_decoding=True)), ('forward_d2si', dict(separate_decoding=True, indep=True))])
+                                        ('forward_d2s', dict(separate_decoding=True)), ('forward_d2si', dict(separate_decoding=True, indep=True)),
+                                        ('forward_d2p', dict(separator=True)), ('forward_d2psi', dict(separator=True, separate_decoding=True, indep=True))])
 def test_variant_models_have_the_reference_state_dict_layout(fixture, kw):
     """the module tree built from spec.var_state_shapes yields the reference's state_dict() key order for every built variant"""
     import numpy as np
@@ -147,8 +148,8 @@ def test_variant_models_have_the_reference_state_dict_layout(fixture, kw):
 def test_unbuilt_variant_flags_fail_loudly_and_indep_defaults_follow_upstream():
     from controlvar_amd import models
     vae = models.build_vae(ch=32)
-    with pytest.raises(NotImplementedError):                           # upstream itself raises IndexError for every separator path
-        models.build_control_var(vae, depth=2, mask_type='interleave_append', multi_cond=True, separator=True)
+    with pytest.raises(NotImplementedError):
+        models.build_control_var(vae, depth=2, mask_type='replace', separator=True)
     with pytest.raises(NotImplementedError):
         models.build_control_var(vae, depth=2, mask_type='replace', type_pos=True)
     with pytest.raises(NotImplementedError):

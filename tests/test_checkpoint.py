@@ -158,3 +158,32 @@ def test_save_checkpoint_and_resume(tmp_path):
     raw['model_state_dict'].pop('head.bias')
     with pytest.raises(RuntimeError):
         ckpt.resume(fresh, opt2, raw)
+
+
+def test_separator_surgery_layout():
+    """load_var_weight with separator (train_control_var_hpu.py:504-517,523-533): deterministic parts of the result - control-half position
+    rows copied, image-half rows the constant 1 (upstream's `x * -1 if mpos else 1` precedence), head grown to V + 18 rows with the
+    pretrained rows first and zero bias behind - and the state loads into a separator model with only the rebuilt tensors missing"""
+    import torch
+    from controlvar_amd import checkpoint as ckpt, models
+    from controlvar_amd.spec import DEFAULT_PATCH_NUMS as PN
+    vae = models.build_vae(ch=32)
+    var = models.build_var(vae, depth=2)
+    m = models.build_control_var(vae, depth=2, mask_type='interleave_append', multi_cond=True, separator=True)
+    sd = ckpt.var_to_control_var_state(ckpt.read_state({'model_state_dict': {'module.' + k: v for k, v in var.state_dict().items()}}), PN,
+                                       separator=True, vocab_size=4096)
+    pos, src = sd['pos_1LC'][0], var.state_dict()['pos_1LC'][0]
+    assert pos.shape == (1378, 128) and sd['head.weight'].shape == (4114, 128) and sd['head.bias'].shape == (4114,)
+    at, o = 0, 0
+    for i, pn in enumerate(PN):
+        sp = 1 if i else 0
+        n = pn * pn
+        assert torch.equal(pos[o:o + n], src[at:at + n])
+        assert torch.equal(pos[o + n + sp:o + 2 * n + sp], torch.ones(n, 128))
+        at += n
+        o += 2 * (n + sp)
+    assert torch.equal(sd['head.weight'][:4096], var.state_dict()['head.weight']) and sd['head.bias'][4096:].abs().max() == 0
+    assert 0 < sd['head.weight'][4096:].abs().max() < 0.02 * 6 * (1 / 128 / 3) ** 0.5          # trunc_normal(std) * 0.02 (bounds +-2 are absolute)
+    res = ckpt.load_var_weight(m, {'model_state_dict': var.state_dict()})
+    assert set(res.missing_keys) == {'lvl_1L', 'pos_start', 'attn_bias_for_masking', 'cond_embed.weight', 'special_embed.weight'}
+    assert m.state_dict()['pos_1LC'].shape == (1, 1378, 128)

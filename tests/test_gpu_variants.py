@@ -26,7 +26,7 @@ def t(a):
 def make(cfg, dtype, dev, seed=0):
     vae = models.build_vae(ch=32, compute_dtype=dtype).to(dev)
     m = models.build_control_var(vae, depth=cfg.depth, mask_type='interleave_append', multi_cond=True, compute_dtype=dtype, cond_drop_rate=0.0,
-                                 separate_decoding=cfg.separate_decoding, indep=cfg.indep, init_seed=seed).to(dev).eval()
+                                 separate_decoding=cfg.separate_decoding, indep=cfg.indep, separator=cfg.separator, init_seed=seed).to(dev).eval()
     return vae, m
 
 
@@ -163,6 +163,74 @@ def test_separate_decoding_bf16_runs_and_cache_equals_mask(gpu_device):
     with torch.no_grad():
         fw = m(labels, x, types).float().cpu()
     assert (fw - inf_logits).abs().max().item() < 3e-2 * fw.abs().max().item()
+
+
+# ---------------------------------------------------------------------------------------------------------------- separator
+SEPARATOR = {'d2p': (VarConfig(depth=2, separator=True), 13), 'd2psi': (VarConfig(depth=2, separator=True, separate_decoding=True, indep=True), 14)}
+
+
+@pytest.mark.parametrize('tag', list(SEPARATOR))
+def test_separator_forward_and_generate_fp32(gpu_device, tag):
+    """separator=True: 1378-token sequences, head with V + 18 columns, special_embed rows between the halves.  Fixtures were recorded from the
+    reference with its special_embed index fixed (it adds V and raises IndexError as shipped, control_var.py:549,606); forward() and
+    the joint inference branch - whose separator PLACEMENT differs from forward()'s upstream (:507-509,538) - are compared token for token."""
+    cfg, seed = SEPARATOR[tag]
+    vae, m = make(cfg, F32, gpu_device, seed)
+    g = golden(f'forward_{tag}')
+    py = cfg.pyramid
+    gen = torch.Generator().manual_seed(26)
+    x = torch.randn(2, len(py.code_positions()) - py.first_l, 32, generator=gen).to(gpu_device)
+    with torch.no_grad():
+        logits = m(t(g['labels']), x, t(g['types']), True).cpu()
+    assert logits.shape == (2, 1378, 4114)
+    assert (logits[:, ::9, ::31] - t(g['logits_sample'])).abs().max() < 2e-3
+    check_ids(logits.argmax(-1), g['argmax'], g['margin'], 2e-3, f'forward {tag}')
+    gg = golden(f'gen_{tag}_b2')
+    img = m.autoregressive_infer_cfg(2, torch.tensor([3, 7]), g_seed=0, cfg=4.0, top_k=1, cond_type=torch.tensor([0, 1]), _trace=True).cpu()
+    ids = torch.cat(m.last_trace['idx'], dim=1).cpu()
+    assert ids.shape == (2, 1378)
+    nm = check_ids(ids, gg['ids'], gg['margin'], 2e-3, f'gen {tag}')
+    if nm == 0:
+        assert (img[:, :, 100:116, 60:76] - t(gg['img_crop'])).abs().max() < 2e-3
+        assert (img.mean(dim=(2, 3)) - t(gg['img_mean'])).abs().max() < 2e-4
+    with pytest.raises(NotImplementedError):
+        m.conditional_infer_cfg(2, torch.tensor([3, 7]), cond_type=torch.tensor([0, 1]))
+    with pytest.raises(NotImplementedError):
+        m.autoregressive_infer_cfg(2, torch.tensor([3, 7]), cond_type=torch.tensor([0, 1]), more_smooth=True)
+    with pytest.raises(AssertionError):
+        m(t(g['labels']), torch.zeros(2, 1376, 32, device=gpu_device), t(g['types']))
+
+
+def test_separator_training_step_matches_reference(gpu_device):
+    """tokenise -> labels with the separator labels V + k (train_control_var_hpu.py:214-224) -> forward -> CE over 4114 classes -> backward:
+    loss and every gradient (incl. special_embed and the 18 extra head rows) against train_step_d2p.npz, then one fused AdamW step"""
+    g = golden('train_step_d2p')
+    cfg, seed = SEPARATOR['d2p']
+    vae, m = make(cfg, F32, gpu_device, seed)
+    images, masks = synth_images(2, 256, seed=6).to(gpu_device), synth_images(2, 256, seed=7).to(gpu_device)
+    tr = T.Trainer(m, vae, peak_lr=2e-3, weight_decay=0.05, weight_decay_end=0.01, sche='lin0', warmup_it=20, max_it=1000, clip=2.0, wp0=0.005, wpe=0.01, drop_path=False)
+    x, labels = tr.tokenize(images, masks)
+    assert labels.shape == (2, 1378) and np.array_equal(labels.cpu().numpy(), g['labels'].astype(np.int64))
+    eng = tr.engine
+    loss, _ = eng.forward_backward(torch.tensor([17, 403]), x, torch.tensor([2, 0]), labels)
+    assert abs(loss.item() - float(g['loss'])) < 2e-5
+    grads = eng.grads()
+    gn = t(g['gnorms'])
+    names = [str(k) for k in g['names']]
+    assert 'special_embed.weight' in names and grads['head.weight'].shape == (4114, 128)
+    for i, n in enumerate(names):
+        ref_n = gn[i].item()
+        assert abs(grads[n].norm().item() - ref_n) <= 2e-3 * max(ref_n, 1e-3 * float(g['total_norm'])), n
+        ref_slice = t(g['g:' + n])
+        got = grads[n].reshape(-1)[:: max(1, grads[n].numel() // 64)][:64].cpu()
+        assert (got - ref_slice).abs().max() <= 2e-3 * max(ref_slice.abs().max().item(), 1e-5) + 1e-7, n
+    tr.it = 7
+    tr.step(images, masks, torch.tensor([17, 403]), torch.tensor([2, 0]))
+    sd = m.state_dict()
+    for n in names:
+        ref = t(g['p:' + n])
+        got = sd[n].reshape(-1)[:: max(1, sd[n].numel() // 64)][:64].cpu()
+        assert (got - ref).abs().max() <= 1e-4 * max(1.0, ref.abs().max().item()), n
 
 
 # ---------------------------------------------------------------------------------------------------------------- more_smooth

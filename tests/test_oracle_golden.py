@@ -366,3 +366,27 @@ def test_more_smooth_reproduces_the_reference_draws():
     _gen_check('gen_d2_smooth_cmask', VarConfig(depth=2), 2, torch.tensor([5, 6]), (4.0, 4.0, 4.0), cond_type=torch.tensor([2, 3]), four=True, teach='c_mask',
                top_k=900, top_p=0.96, seed=7, more_smooth=True, id_frac=0.01, **loose)      # 3-term CFG on soft inputs: a few draws flip
     _gen_check('gen_d2s_smooth', SEPDEC['d2s'][0], 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]), top_k=900, top_p=0.96, seed=42, more_smooth=True, wseed=11, **loose)
+
+
+# ---- separator (recorded with the special_embed index shim of make_golden.make_cvar)
+SEPARATOR = {'d2p': (VarConfig(depth=2, separator=True), 13), 'd2psi': (VarConfig(depth=2, separator=True, separate_decoding=True, indep=True), 14)}
+
+
+@pytest.mark.parametrize('tag', list(SEPARATOR))
+def test_separator_state_layout_forward_and_generate(tag):
+    from controlvar_amd.spec import var_state_shapes
+    cfg, seed = SEPARATOR[tag]
+    g = golden(f'forward_{tag}')
+    assert list(var_state_shapes(cfg)) == [str(k) for k in g['keys']]
+    sd = synth_var_state(cfg, seed)
+    py = cfg.pyramid
+    assert py.L == 1378 and sd['head.weight'].shape[0] == 4096 + 18 and sd['special_embed.weight'].shape[0] == 18
+    gen = torch.Generator().manual_seed(26)
+    x = torch.randn(2, len(py.code_positions()) - py.first_l, 32, generator=gen)
+    with torch.no_grad():
+        logits = var_ref.forward_logits(sd, cfg, t(g['labels']), x, t(g['types']))
+    assert logits.shape == (2, 1378, 4114)
+    assert (logits[:, ::9, ::31] - t(g['logits_sample'])).abs().max() < 1e-4
+    mism = logits.argmax(-1).numpy() != g['argmax'].astype(np.int64)
+    assert mism.sum() == 0 or g['margin'][mism].max() < 1e-4
+    _gen_check(f'gen_{tag}_b2', cfg, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]), wseed=seed)
