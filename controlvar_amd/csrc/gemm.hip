@@ -886,6 +886,8 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     // the 8-wave one wins in the model by 1-2 % at every depth (d12 ... d30): twice the waves share the epilogue's loads / stores /
     // GELU and fill each other's DMA-issue bubbles.  Default: 8 waves; tile_cfg 3 selects the 4-wave variant (A/B runs), and the
     // split-K slices of long-K GEMMs (training weight gradients: plain fp32 partial stores) use it as well.
+    // (round 2, measured and removed: a 192x128 tile - 4 waves, 80 KB of LDS, TWO workgroups per CU so that one's epilogue overlaps the
+    //  other's K loop - ran 3-10 % below the 256x256 tile on every d24 shape, proj included: 749 vs 789 TFLOP/s.  gpurun_out/r2_tilecfg4.txt)
     if (sizeof(T) == 2 && (ov == 3 || (ov != 0 && ov != 1 && p.split_tiles > 0)) && (p.M >= 2048 || (p.split_tiles > 0 && p.M > 1024)) && n_ok)
         return launch_cfg<T, 256, 256, 2, 2>(p, batch, st);
     // Partial rounds: a launch of t tiles takes ceil(t / slots) rounds of the chip.  256x256: 256 slots (one workgroup per CU), cost 1

@@ -8,7 +8,7 @@ from controlvar_amd import ops
 from controlvar_amd._lib import ACT_GELU_TANH
 dev = torch.device('cuda:0'); T = torch.bfloat16
 C = 1536
-ARMS = [0, 1, 3]
+ARMS = [int(a) for a in sys.argv[2].split(',')] if len(sys.argv) > 2 else [0, 1, 3]
 Ms = [int(a) for a in sys.argv[1].split(',')] if len(sys.argv) > 1 else [131072, 12800, 4608]
 
 def timeit(fn, iters=8):
