@@ -35,7 +35,8 @@ def parse():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--depth', type=int, default=24)
-    ap.add_argument('--batch', type=int, default=128, help='samples per GPU per step (KV arena: 0.6 GB per sample at d24 bf16)')
+    ap.add_argument('--batch', type=int, default=0, help='samples per GPU per step; 0 = 256 up to d24, 128 above (KV arena: 0.6 GB per sample at d24 bf16 '
+                                                          '-> 154 GB of the 288 GB at 256; larger batches fill the partial tile rounds of the mid scales: +2.5 %% over 128)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--cfg', type=float, default=4.0)
     ap.add_argument('--top_k', type=int, default=900)      # the reference's sampling defaults (train_control_var_hpu.py:338)
@@ -187,7 +188,7 @@ def main():
     t_build = time.time()
     vae = models.build_vae(ch=160, compute_dtype=T).to(dev)
     var = models.build_control_var(vae, depth=a.depth, mask_type='interleave_append', multi_cond=True, compute_dtype=T).to(dev).eval()
-    B = a.batch
+    B = a.batch or (256 if a.depth <= 24 else 128)
     g = torch.Generator().manual_seed(1234 + rank)
     labels = torch.randint(0, 1000, (B,), generator=g).to(dev)
     types = (torch.arange(B) % 4).to(dev)

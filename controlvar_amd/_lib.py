@@ -36,7 +36,7 @@ class GemmDesc(C.Structure):
         ('C', c_p), ('out_dtype', c_i), ('ldc', c_l),
         ('remap_l', c_i), ('remap_L', c_i), ('remap_off', c_i),
         ('pre_act', c_p), ('aux', c_p), ('gate_scale', c_p),
-        ('ws', c_p), ('ws_bytes', c_l), ('tile_cfg', c_i), ('stagger', c_i),
+        ('ws', c_p), ('ws_bytes', c_l), ('tile_cfg', c_i), ('stagger', c_i), ('group_m', c_i),
     ]
 
 

@@ -63,6 +63,7 @@ struct GemmParams {
     unsigned remap_magic, gate_magic; int remap_shift, gate_shift;   // exact m / remap_l and m / gate_rows for 0 <= m < 2^31 (fast_div)
     int split_tiles;          // split-K: K tiles per blockIdx.y slice (0 = no split); partials go to C + blockIdx.y * split_stride
     long split_stride;
+    int group_m;              // row tiles per scheduling group (see launch_cfg)
     int stagger;              // > 0: the first wave of workgroups (one per CU) starts spread over this many shader cycles (see cvar_gemm_kernel)
     int tile_cfg;             // cvar_gemm_desc::tile_cfg (0 = automatic)
 };
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
         const int nblk = gridDim.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7, local = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
-    constexpr int GM = 8;
+    const int GM = p.group_m;             // row tiles per group: the tiles of GM consecutive rows share each W tile out of L2
     const int group_sz = GM * p.tiles_n;
     const int grp = bid / group_sz, first_m = grp * GM;
     const int gm = min(p.tiles_m - first_m, GM);
@@ -799,6 +800,11 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     GemmParams p = gp;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
+    // Group height.  Within a group the A row blocks (GM x BM x K) are re-read once per column tile and the W tile once per group;
+    // each XCD's 4 MB L2 holds neither for the long-K / wide-output GEMMs, the refills come out of the Infinity Cache.  Measured on the
+    // d24 shapes (profiles/r02_gemm_group_ab.txt): 4 rows instead of 8 is +2.4 % for K = 6144 (fc2) and +3 % for the fp32-output head,
+    // neutral or -1 % for the K = 1536 bf16-output GEMMs; 16 loses everywhere.
+    if (p.group_m <= 0) p.group_m = (!p.conv && ((long)p.K * (long)sizeof(T) >= 8192 || p.out_dtype == CVAR_F32)) ? 4 : 8;
     if (p.conv) { const int kt_e = 128 / (int)sizeof(T); p.cv_adv = kt_e / p.Cin; p.cv_rem = kt_e % p.Cin; }
     const size_t lds = NSTAGE * (BM + BN) * 128;
     const int nk_all = (p.K + (128 / (int)sizeof(T)) - 1) / (128 / (int)sizeof(T));
@@ -987,7 +993,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     make_fast_div(p.remap_l, &p.remap_magic, &p.remap_shift);
     make_fast_div(p.gate ? p.gate_rows : 1, &p.gate_magic, &p.gate_shift);
     p.split_tiles = 0; p.split_stride = 0;
-    p.tile_cfg = d->tile_cfg; p.stagger = d->stagger > 0 ? d->stagger : 0;
+    p.tile_cfg = d->tile_cfg; p.stagger = d->stagger > 0 ? d->stagger : 0; p.group_m = d->group_m > 0 ? d->group_m : 0;
     // split-K workspace: part of the call (caller-owned, any stream / device), nothing process-wide
     float* const g_splitk_ws = (d->ws && d->ws_bytes > 0 && (((uintptr_t)d->ws & 15) == 0)) ? (float*)d->ws : nullptr;
     const size_t g_splitk_ws_bytes = g_splitk_ws ? (size_t)d->ws_bytes : 0;

@@ -266,8 +266,10 @@ extern "C" int cvar_first_tokens(const float* class_emb, const float* cond_embed
 // ------------------------------------------------------------------------------------------------
 // VQVAE helpers
 // ------------------------------------------------------------------------------------------------
-// GroupNorm statistics over NHWC: per-(image, pixel-chunk) per-channel sum / sum of squares, reduced in a fixed
-// order (no atomics -> bit-reproducible), then combined over chunks in double by gn_finalize_kernel.
+// GroupNorm statistics over NHWC: per-(image, pixel-chunk) per-channel sum / sum of squares of (x - pivot_c), reduced in a fixed
+// order (no atomics -> bit-reproducible), then combined over chunks in double by gn_finalize_kernel.  pivot_c = x[b][pixel 0][c]:
+// accumulating around a value of the channel's own magnitude removes the cancellation of a raw sum / sum-of-squares pass when
+// |mean| >> std (round-1 limit: 2e-3 .. 7e-2 on degenerate groups); the group statistics are reassembled exactly in double.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ partial, int HW, int C, int pix_per_block) {
     constexpr int VEC = 16 / sizeof(T);
@@ -282,16 +284,29 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
         for (int e = 0; e < VEC; ++e) { s[e] = 0.f; q[e] = 0.f; }
         const int p0 = chunk * pix_per_block;
         const int p1 = min(p0 + pix_per_block, HW);
+        float piv[VEC];
+        {
+            const T* src = x + (long)b * HW * C + cg * VEC;
+            if constexpr (sizeof(T) == 2) {
+                const bf16x8_t v = *(const bf16x8_t*)src;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) piv[e] = bf16_to_f32((bf16_t)v[e]);
+            } else {
+                const f32x4_t v = *(const f32x4_t*)src;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) piv[e] = v[e];
+            }
+        }
         for (int p = p0 + pl; p < p1; p += PL) {
             const T* src = x + ((long)b * HW + p) * C + cg * VEC;
             if constexpr (sizeof(T) == 2) {
                 const bf16x8_t v = *(const bf16x8_t*)src;
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) { const float f = bf16_to_f32((bf16_t)v[e]); s[e] += f; q[e] += f * f; }
+                for (int e = 0; e < VEC; ++e) { const float f = bf16_to_f32((bf16_t)v[e]) - piv[e]; s[e] += f; q[e] += f * f; }
             } else {
                 const f32x4_t v = *(const f32x4_t*)src;
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+                for (int e = 0; e < VEC; ++e) { const float f = v[e] - piv[e]; s[e] += f; q[e] += f * f; }
             }
         }
 #pragma unroll
@@ -310,22 +325,37 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
 
 // per (b, group): one wave reduces the chunk partials of the group's channels in double (fixed shuffle order ->
 // reproducible), then writes a = rstd_g * w_c, d = bias_c - mean_g * rstd_g * w_c for its channels.
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, const float* __restrict__ weight,
+template <typename T>
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nchunk, const T* __restrict__ x, const float* __restrict__ weight,
                                                         const float* __restrict__ bias, float* __restrict__ coef, int HW, int C, int groups, float eps) {
     const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
     const int cpg = C / groups;
-    double s = 0.0, q = 0.0;
+    // pass 1: group mean = sum_c (HW * pivot_c + S_c) / n with S_c = sum of (x - pivot_c) over the channel
+    double s = 0.0;
     const int items = cpg * nchunk;
     for (int it = lane; it < items; it += 64) {
         const int k = it / cpg, cc = g * cpg + it % cpg;
         s += (double)partial[(((long)b * nchunk + k) * C + cc) * 2];
-        q += (double)partial[(((long)b * nchunk + k) * C + cc) * 2 + 1];
     }
+    for (int cc = g * cpg + lane; cc < (g + 1) * cpg; cc += 64) s += (double)HW * (double)Elem<T>::ld(x + (long)b * HW * C + cc);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     const double n = (double)HW * cpg;
     const double mean = s / n;
-    double var = q / n - mean * mean;
+    // pass 2: sum (x - mean)^2 = sum_c [ Q_c + 2 S_c d_c + HW d_c^2 ],  d_c = pivot_c - mean  (exact identity, every term small)
+    double q = 0.0;
+    for (int it = lane; it < items; it += 64) {
+        const int k = it / cpg, cc = g * cpg + it % cpg;
+        const double d = (double)Elem<T>::ld(x + (long)b * HW * C + cc) - mean;
+        q += (double)partial[(((long)b * nchunk + k) * C + cc) * 2 + 1] + 2.0 * d * (double)partial[(((long)b * nchunk + k) * C + cc) * 2];
+    }
+    for (int cc = g * cpg + lane; cc < (g + 1) * cpg; cc += 64) {
+        const double d = (double)Elem<T>::ld(x + (long)b * HW * C + cc) - mean;
+        q += (double)HW * d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    double var = q / n;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     for (int cc = g * cpg + lane; cc < (g + 1) * cpg; cc += 64) {
@@ -387,7 +417,7 @@ static int groupnorm_typed(const T* x, const float* weight, const float* bias, T
     float* coef = partial + (size_t)B * nchunk * C * 2;
     const int PL = 256 / (C / VEC);
     hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(nchunk, B), dim3(256), (size_t)PL * C * 2 * sizeof(float), st, x, partial, HW, C, ppb);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, st, partial, nchunk, weight, bias, coef, HW, C, groups, eps);
+    hipLaunchKernelGGL(gn_finalize_kernel<T>, dim3(groups, B), dim3(64), 0, st, partial, nchunk, x, weight, bias, coef, HW, C, groups, eps);
     const long nvec = (long)B * HW * C / VEC;
     hipLaunchKernelGGL(gn_apply_kernel<T>, dim3((unsigned)min((long)4096, (nvec + 255) / 256)), dim3(256), 0, st, x, coef, out, nvec, HW, C, silu);
     CVAR_CHECK_LAUNCH();

@@ -43,6 +43,7 @@ _SPLITK_WS = {}
 # per-call execution options of cvar_gemm (include/cvar.h): A/B measurement knobs, never needed for correctness
 GEMM_TILE_CFG = 0          # 0 automatic, 1 128x128 only, 2 8-wave 256x256, 3 4-wave 256x256
 GEMM_STAGGER = 0           # start-stagger window in shader cycles (0 = the library's default: off)
+GEMM_GROUP_M = 0           # row tiles per scheduling group (0 = automatic)
 
 
 def ensure_splitk_workspace(device, nbytes: int = 256 << 20) -> torch.Tensor:
@@ -97,7 +98,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
     if ws is None:
         ws = ensure_splitk_workspace(A.device)
     d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
-    d.tile_cfg, d.stagger = GEMM_TILE_CFG, GEMM_STAGGER
+    d.tile_cfg, d.stagger, d.group_m = GEMM_TILE_CFG, GEMM_STAGGER, GEMM_GROUP_M
     if GEMM_PROFILE is None:
         check(_lib.load().cvar_gemm(C.byref(d), _stream()), 'cvar_gemm')
     else:

@@ -81,6 +81,7 @@ typedef struct {
     void* ws; int64_t ws_bytes;
     int tile_cfg;
     int stagger;
+    int group_m;                     /* row tiles per scheduling group; 0 = automatic (4 for long-K / fp32-output GEMMs, else 8).  Never changes results */
 } cvar_gemm_desc;
 int cvar_gemm(const cvar_gemm_desc* d, void* stream);
 

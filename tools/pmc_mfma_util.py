@@ -22,4 +22,4 @@ for fam, d in acc.items():
     out[fam] = {'launches': calls[fam], 'active_cycles_per_xcd': gui, 'mfma_busy_cycles_all_simds': busy,
                 'mfma_utilisation': round(busy / (gui * 1024.0), 4) if gui else None}
 print(json.dumps(out, indent=1))
-json.dump(out, open('gpurun_out/r01_pmc_mfma_util.json', 'w'), indent=1)
+json.dump(out, open(sys.argv[2] if len(sys.argv) > 2 else 'gpurun_out/pmc_mfma_util.json', 'w'), indent=1)
