@@ -77,19 +77,17 @@ def physical_cores() -> int:
     return max(1, len(allowed))
 
 
-def cpu_baseline(depth: int, seed: int = 0, budget_s: float = 20.0, max_threads: int = 0):
+def cpu_baseline(depth: int, seed: int = 0, budget_s: float = 15.0):
     """The oracle (kind 'port': own restatement, pinned to the reference by tests/golden) on the host cores.
     Sample: ONE d{depth} generation with B=1 (2 CFG rows), fp32, greedy - run scale by scale until `budget_s` seconds
     are spent; the rate is extrapolated by the share of the sample's algorithmic FLOPs completed (both VAE decodes
-    are included only if every scale finished inside the budget)."""
+    are included only if every scale finished inside the budget).  Timed with one thread per PHYSICAL core
+    and, when the host has more than 32 of them, also with 32 threads - torch's CPU GEMMs at B=1 do not scale to 128 threads, and
+    the faster of the two is what is reported (`cores` = the threads of the reported run; both are named in `sample`)."""
     from controlvar_amd.spec import DEFAULT_PATCH_NUMS as PN, VAE_DECODE_GFLOP, VaeConfig, VarConfig, phi_index_map
     from controlvar_amd.synth import synth_vae_state, synth_var_state
     from oracle import var_ref
     from oracle.vqvae_ref import MSQuant
-    cores = physical_cores()
-    if max_threads:
-        cores = min(cores, max_threads)
-    torch.set_num_threads(cores)
     cfg = VarConfig(depth=depth)
     py, C, V = cfg.pyramid, cfg.C, cfg.vocab
     per_scale = [2 * (depth * (24 * C * C * l + 4 * C * l * e) + 2 * C * V * l) / 1e9 for l, e in zip(py.l, py.end)]   # 2 CFG rows
@@ -97,24 +95,32 @@ def cpu_baseline(depth: int, seed: int = 0, budget_s: float = 20.0, max_threads:
     sdv = synth_vae_state(VaeConfig(ch=160), seed)
     sd = synth_var_state(cfg, seed)
     msq = MSQuant(sdv, PN, phi_index_map(10))
-    done = {'n': 0}
-    t0 = time.time()
 
-    def hook(si):
-        done['n'] = si + 1
-        return (time.time() - t0) > budget_s
+    def run(threads):
+        torch.set_num_threads(threads)
+        done = {'n': 0}
+        t0 = time.time()
 
-    with torch.no_grad():
-        f = var_ref.generate(sd, cfg, msq, 1, torch.tensor([7]), 4.0, top_k=1, cond_type=torch.tensor([1]), stage_hook=hook)
-        gf = sum(per_scale[:done['n']])
-        if done['n'] == len(per_scale):
-            var_ref.decode_fhat(sdv, f)
-            gf += 2 * VAE_DECODE_GFLOP
-    dt = time.time() - t0
-    return dict(value=(gf / total) / dt, unit='images/s', cores=cores, kind='port',
-                sample=f'd{depth} B=1 (2 CFG rows) fp32 torch-CPU oracle, greedy: {done["n"]}/10 scales'
-                       f'{" + 2 VAE decodes" if done["n"] == 10 else ""} = {100 * gf / total:.1f}% of the per-image FLOPs in {dt:.1f}s '
-                       f'on {cores} threads = physical cores of the host (rate extrapolated by FLOP share)')
+        def hook(si):
+            done['n'] = si + 1
+            return (time.time() - t0) > budget_s
+
+        with torch.no_grad():
+            f = var_ref.generate(sd, cfg, msq, 1, torch.tensor([7]), 4.0, top_k=1, cond_type=torch.tensor([1]), stage_hook=hook)
+            gf = sum(per_scale[:done['n']])
+            if done['n'] == len(per_scale):
+                var_ref.decode_fhat(sdv, f)
+                gf += 2 * VAE_DECODE_GFLOP
+        dt = time.time() - t0
+        return dict(rate=(gf / total) / dt, threads=threads, scales=done['n'], share=gf / total, dt=dt)
+
+    phys = physical_cores()
+    runs = [run(phys)] + ([run(32)] if phys > 32 else [])
+    best = max(runs, key=lambda r: r['rate'])
+    desc = '; '.join(f'{r["threads"]} threads: {r["scales"]}/10 scales{" + 2 VAE decodes" if r["scales"] == 10 else ""} = {100 * r["share"]:.1f}% of the per-image FLOPs in '
+                     f'{r["dt"]:.1f}s -> {r["rate"]:.4f} img/s' for r in runs)
+    return dict(value=best['rate'], unit='images/s', cores=best['threads'], kind='port',
+                sample=f'd{depth} B=1 (2 CFG rows) fp32 torch-CPU oracle, greedy, rate extrapolated by FLOP share; host has {phys} physical cores; {desc}')
 
 
 def main_train(a):
