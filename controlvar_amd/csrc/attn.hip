@@ -259,8 +259,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
-    float m = -INFINITY, lsum = 0.f;
+    float m = -INFINITY;
     const float c2 = p.scale * 1.4426950408889634f;
+#ifdef CVAR_ATTN_MFMA_SUM
+    // (build-time experiment, OFF: -DCVAR_ATTN_MFMA_SUM)  Row sums on the matrix pipe: a third accumulator block whose A operand is
+    // "V^T" with one row of ones gives osum[0] (lanes with hi == 0) = sum_k P[k][q] for query q = lane & 31; 4 extra MFMAs per tile
+    // replace 32 v_add_f32 per lane (166 VGPRs, still 3 waves per SIMD).  Measured 2.5 % SLOWER (599 vs 615 TFLOP/s at the last scale,
+    // profiles/r02_attn_mfma_sum_ab.txt): a wave's MFMA and VALU phases do not overlap each other, so moving work between the pipes
+    // only pays if the total issue time drops.
+    f32x16_t osum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) osum[i] = 0.f;
+    const short one_bf = lrow == 0 ? (short)0x3f80 : (short)0;               // bf16 1.0 in row 0 of the block, zeros elsewhere
+    const bf16x8_t ones = {one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf};
+#else
+    float lsum = 0.f;
+#endif
 
     // One KV tile.  MASK is a compile-time flag: tiles that every query of the wave sees completely (all but the last one at
     // inference, all but the level-boundary ones under the training mask) run without any per-score compare / select - left
@@ -297,7 +311,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const float m_new = fmaxf(m, tmax * c2);            // c2 > 0; finite from the first tile on (key 0 is always visible)
         if (!__all(m_new == m)) {                           // rescale only when some row's running max moved (exact skip)
             const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+#ifdef CVAR_ATTN_MFMA_SUM
+            osum[0] *= alpha;
+#else
             lsum *= alpha;
+#endif
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -313,7 +331,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     pr[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][8 * t + j], c2, -m));
+#ifndef CVAR_ATTN_MFMA_SUM
                     lsum += pr[j];
+#endif
                 }
                 pf[kb][t] = pack_bf16x8(pr);
             }
@@ -330,6 +350,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     const bf16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][t], o[db], 0, 0, 0);
                 }
+#ifdef CVAR_ATTN_MFMA_SUM
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[kb][t], osum, 0, 0, 0);
+#endif
         __syncthreads();
     };
     typedef std::integral_constant<bool, true> MaskOn;
@@ -341,7 +367,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int wg_min_kv = range_full_prefix(p, p.q_off + min((int)blockIdx.x * 128, p.l - 1), p.q_off + min(p.l, (int)(blockIdx.x + 1) * 128) - 1);
     for (; kt0 + KT <= wg_min_kv && kt0 < kv_end; kt0 += KT) tile(kt0, MaskOff{});
     for (; kt0 < kv_end; kt0 += KT) tile(kt0, MaskOn{});
+#ifdef CVAR_ATTN_MFMA_SUM
+    const float lsum = __shfl(osum[0], lrow, 64);            // the sum sits in row 0 of the block: register 0 of the hi == 0 lane of each query
+#else
     lsum += __shfl_xor(lsum, 32, 64);
+#endif
     if (qi < p.l) {
         if (p.lse && hi == 0) p.lse[(r * p.H + h) * (long)p.l + qi] = (m + log2f(lsum)) * 0.6931471805599453f;
         const float inv = 1.0f / lsum;
