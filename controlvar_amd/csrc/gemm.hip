@@ -110,8 +110,13 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     constexpr int KCH = 16 / ES;         // elements per 16-byte chunk
     constexpr int KT = 128 / ES;         // elements of K per tile
     constexpr int A_INSTR = BM / 8, B_INSTR = BN / 8;     // 1 KiB wave-instructions per tile
-    constexpr int A_PER_W = A_INSTR / NW, B_PER_W = B_INSTR / NW;
-    static_assert(A_INSTR % NW == 0 && B_INSTR % NW == 0, "tile / wave mismatch");
+    constexpr int A_PER_W = A_INSTR / NW, B_PER_W = (B_INSTR + NW - 1) / NW;
+    static_assert(A_INSTR % NW == 0, "tile / wave mismatch");
+    // W pieces need not divide among the waves (160 columns = 20 pieces over 8 waves): the surplus slots of the last round re-issue
+    // pieces that another wave issues as well - same source, same LDS destination, identical bytes - so that every wave still issues NL
+    // pieces per K tile and the counted vmcnt stays uniform
+    constexpr int B_DUP = B_PER_W * NW - B_INSTR;
+    static_assert(B_DUP >= 0 && B_DUP < NW, "tile / wave mismatch");
     constexpr int STAGE = (BM + BN) * 128;
     constexpr int SUB_M = BM / WM, SUB_N = BN / WN;
     constexpr int MI = SUB_M / 32, NJ = SUB_N / 32;
@@ -123,6 +128,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    auto w_piece = [&](int jj) { const int j = wave + jj * NW; return j < B_INSTR ? j : j - B_DUP; };
 
     // ---- start stagger.  Tiles of one launch take the same time, so all CUs reach their epilogues together: HBM idles during
     // the K loops (operands come out of L2) and is saturated by 256 simultaneous output bursts (plus residual reads) at the
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     if (FAST) {
 #pragma unroll
         for (int jj = 0; jj < B_PER_W; ++jj) {
-            const int row = (wave + jj * NW) * 8 + lr;
+            const int row = w_piece(jj) * 8 + lr;
             w_off[jj] = (unsigned)min(row, p.N - 1 - n0) * (unsigned)(p.ldw * ES) + (unsigned)((slot ^ ((row >> 1) & 7)) * 16);
         }
     }
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     int w_k0[B_PER_W];
 #pragma unroll
     for (int jj = 0; jj < B_PER_W; ++jj) {
-        const int j = wave + jj * NW;
+        const int j = w_piece(jj);
         const int row = j * 8 + lr;
         const int chunk = slot ^ ((row >> 1) & 7);
         w_k0[jj] = chunk * KCH;
@@ -307,7 +313,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(sbase + (wave + idx * NW) * 1024), 16, (int)a_off[idx], kt * 128, 0, 0);
                 }
             } else
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(sbase + BM * 128 + (wave + (idx - A_PER_W) * NW) * 1024), 16,
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(sbase + BM * 128 + w_piece(idx - A_PER_W) * 1024), 16,
                                                          (int)w_off[idx - A_PER_W], kt * 128, 0, 0);
             return;
         }
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(sbase + j * 1024), 16, 0, 0);
         } else {
             const int jj = idx - A_PER_W;
-            const int j = wave + jj * NW;
+            const int j = w_piece(jj);
             const int k = kt * KT + w_k0[jj];
             const char* src = zero;
             if (w_ptr[jj] != nullptr && k < p.K) src = w_ptr[jj] + (long)kt * 128;
@@ -847,7 +853,7 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
 // cvar_gemm_desc::tile_cfg -> the A/B selector of launch_typed: -1 automatic, 0 128x128 tiles only, 1 the 8-wave 256x256 tile, 3 the
 // 4-wave 256x256 tile (part of the call, not of the process environment)
 static int gemm_cfg_override(const GemmParams& p) {
-    return p.tile_cfg == 1 ? 0 : p.tile_cfg == 2 ? 1 : p.tile_cfg == 3 ? 3 : -1;
+    return p.tile_cfg == 1 ? 0 : p.tile_cfg == 2 ? 1 : p.tile_cfg == 3 ? 3 : p.tile_cfg == 4 ? 4 : -1;
 }
 
 template <typename T>
@@ -876,6 +882,13 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
                 (!p.up || (p.Hout == 2 * p.Hin && p.Wout == 2 * p.Win))) {
                 GemmParams q = p;
                 q.conv_bytes = (unsigned)in_bytes;
+                // Short-K convs (Cin = 160: 22.5 K tiles): with one wave per SIMD the 13 DMA pieces a wave issues per K tile (~60-100 cycles
+                // each) are as long as its 40 MFMAs and nothing hides them; eight waves (two per SIMD, 32x160 each, the 20 W pieces spread
+                // with duplicates - see w_piece) let the partner's MFMAs cover the issue: 160->160 at 256^2 734 -> 783 TFLOP/s, with the
+                // bf16 residual epilogue 628 -> 745; K >= 2880 is neutral and stays on 4 waves (profiles/r02_conv_8wave_ab.txt).
+                // tile_cfg 3 forces the 4-wave tile, 4 the 8-wave tile.  Bit-identical results.
+                const int ovc = gemm_cfg_override(p);
+                if (!p.up && p.stride == 1 && ovc != 3 && (ovc == 4 || (long)p.K * (long)sizeof(T) <= 4096)) return launch_cfg<T, 256, 160, 8, 1, 2, true>(q, batch, st);
                 return p.up ? launch_cfg<T, 256, 160, 4, 1, 2, true, true>(q, batch, st) : launch_cfg<T, 256, 160, 4, 1, 2, true>(q, batch, st);
             }
         }
