@@ -14,24 +14,33 @@ only = [int(x) for x in os.environ.get('FUZZ_ONLY', '').split(',') if x]
 bad = 0
 
 
-def torch_ref(qkv, R, H, Lmax, q_off, l, scale, levels):
+def visible(Lmax, levels, holes):
+    """(Lmax, Lmax) bool: query p sees keys [0, end(level(p))) minus its level's hole - the contract of cvar_attention"""
+    vis = torch.zeros(Lmax, Lmax, dtype=torch.bool)
+    b = 0
+    for k, e in enumerate(levels):
+        vis[b:e, :e] = True
+        if holes and holes[k][1] > holes[k][0]:
+            vis[b:e, holes[k][0]:holes[k][1]] = False
+        b = e
+    return vis
+
+
+def torch_ref(qkv, R, H, Lmax, q_off, l, scale, levels, holes=None):
     """fp32 softmax(q k^T * scale + mask) v over the visible keys"""
     q, k, v = qkv.float().view(R, Lmax, 3, H, 64).permute(2, 0, 3, 1, 4).unbind(0)
     q = q[:, :, q_off:q_off + l]
     nk = q_off + l
     s = torch.matmul(q, k[:, :, :nk].transpose(-1, -2)) * scale
     if levels is not None:
-        lvl = torch.zeros(Lmax, dtype=torch.long, device=qkv.device)
-        for e in levels[:-1]:
-            lvl[e:] += 1
-        s = s.masked_fill(lvl.view(-1, 1) < lvl.view(1, -1), float('-inf'))
+        s = s.masked_fill(~visible(Lmax, levels, holes)[q_off:q_off + l, :nk].to(qkv.device), float('-inf'))
     return torch.matmul(torch.softmax(s, -1), v[:, :, :nk]).transpose(1, 2).reshape(R * l, H * 64)
 
 
 for case in range(n_cases):
     R, H = rng.choice([1, 2, 3, 5]), rng.choice([1, 2, 4, 12])
-    levels = None
-    if rng.random() < 0.5:                                    # inference: queries [q_off, q_off + l) see keys [0, q_off + l)
+    levels, holes = None, None
+    if rng.random() < 0.4:                                    # inference: queries [q_off, q_off + l) see keys [0, q_off + l)
         Lmax = rng.choice([40, 130, 300, 700, 1360])
         l = rng.randint(1, min(Lmax, 520))
         q_off = rng.randint(0, Lmax - l)
@@ -41,6 +50,19 @@ for case in range(n_cases):
         for p in pns:
             acc += 2 * p * p; ends.append(acc)
         Lmax, l, q_off, levels = acc, acc, 0, ends
+        kind = rng.random()
+        if kind < 0.6:                                        # separate_decoding: half-scale levels (+ indep holes), random sub-span of queries
+            lv, hl, b0 = [], [], 0
+            for e in ends:
+                half = (e - b0) // 2
+                lv += [b0 + half, e]
+                hl += [(0, 0), (b0, b0 + half) if kind < 0.35 else (0, 0)]
+                b0 = e
+            levels, holes = lv, (hl if kind < 0.35 else None)
+            if rng.random() < 0.5:                            # KV-cached form with the mask rows (indep inference): one scale's queries
+                k = rng.randrange(len(ends))
+                q_off = 0 if k == 0 else ends[k - 1]
+                l = ends[k] - q_off
     C3 = 3 * H * 64
     g = torch.Generator().manual_seed(case)
     amp = rng.choice([0.3, 1.0, 2.5])
@@ -50,25 +72,31 @@ for case in range(n_cases):
     qkv = buf[pad:pad + qkv_cpu.numel()].view(R, Lmax, C3)
     qkv.copy_(qkv_cpu)
     # keys the queries must not see are poisoned as well (inference: rows >= q_off + l)
-    if levels is None and q_off + l < Lmax:
+    if q_off + l < Lmax:
         qkv[:, q_off + l:, H * 64:] = float('nan')
     scale = rng.choice([0.125, 0.03125, 1.0])
     if only and case not in only:
         continue
     out = torch.empty(R * l, H * 64, device=dev, dtype=T)
     ref = torch.empty(R * l, H * 64, device=dev, dtype=T)
-    ops.attention(qkv, out, R, H, Lmax, q_off, l, scale, levels)
-    ops.attention(qkv, ref, R, H, Lmax, q_off, l, scale, levels, rowwise=True)
+    ops.attention(qkv, out, R, H, Lmax, q_off, l, scale, levels, holes=holes)
+    ops.attention(qkv, ref, R, H, Lmax, q_off, l, scale, levels, rowwise=True, holes=holes)
     a, b = out.float(), ref.float()
     err = ((a - b).abs() / (b.abs() + 0.05 * max(1.0, amp))).max().item() if torch.isfinite(a).all() and torch.isfinite(b).all() else float('nan')
     ok = err == err and err < 0.12          # bf16 P vs exact fp32 softmax; near one-hot rows (scale 1.0, large logits) sit at 0.07-0.09
     # (the floor scales with the value amplitude: at amp 2.5 a one-ulp bf16 flip of an output near 4-8 is 0.031 absolute)
+    if ok and levels is not None and Lmax <= 400:             # common-mode check of both kernels against torch on the masked structures
+        vis0 = qkv.clone(); vis0[~torch.isfinite(vis0)] = 0
+        tt = torch_ref(vis0, R, H, Lmax, q_off, l, scale, levels, holes)
+        e2 = ((b - tt).abs() / (tt.abs() + 0.05 * max(1.0, amp))).max().item()
+        if not (e2 < 0.12):             # the row-wise kernel rounds P to bf16 like the MFMA kernel: same rounding-level floor as above
+            ok, err = False, e2
     if not ok:
         bad += 1
         vis = qkv.clone()
         vis[~torch.isfinite(vis)] = 0
-        t = torch_ref(vis, R, H, Lmax, q_off, l, scale, levels)
-        print('FAIL', case, dict(R=R, H=H, Lmax=Lmax, l=l, q_off=q_off, levels=bool(levels), scale=scale, amp=amp), 'err', err,
+        t = torch_ref(vis, R, H, Lmax, q_off, l, scale, levels, holes)
+        print('FAIL', case, dict(R=R, H=H, Lmax=Lmax, l=l, q_off=q_off, levels=len(levels) if levels else 0, holes=bool(holes), scale=scale, amp=amp), 'err', err,
               '| max abs mfma-rowwise', (a - b).abs().max().item(), 'mfma-fp32', (a - t).abs().max().item(), 'rowwise-fp32', (b - t).abs().max().item(),
               'mean abs mfma-fp32', (a - t).abs().mean().item(), 'rowwise-fp32', (b - t).abs().mean().item(), flush=True)
 print(f'{n_cases - bad}/{n_cases} cases ok')
