@@ -1,4 +1,5 @@
-// Multi-scale KV-cached attention over the qkv arena [R][Lmax][3*H*64].
+// Multi-scale KV-cached attention over the qkv arena [R][Lmax][3*H*64], or over a K/V arena [R][Lmax][2*H*64] with the
+// queries of the call in their own [R][l][H*64] buffer (inference: Q is dead after its scale, so it is not cached).
 //
 // attn_rowwise_kernel: exact-order fp32 row-per-lane kernel (VALU).  It is the parity-mode (CVAR_F32)
 // implementation and the in-library reference the MFMA flash kernel is A/B-checked against.  One lane owns one
@@ -10,7 +11,9 @@
 constexpr int CVAR_ATTN_MAX_LVL = 32;
 
 struct AttnParams {
-    const void* qkv;
+    const void* qkv;     // K / V rows: [R][Lmax][ldkv], K of head h at column k_col + 64 h, V at v_col + 64 h
+    const void* q;       // query rows: [R][q_rows][ldq]; the row of position pos is pos - q_pos0 (packed arena: q == qkv, q_pos0 = 0)
+    int ldkv, k_col, v_col, ldq, q_rows, q_pos0;
     void* out;
     int R, H, Lmax, q_off, l;
     float scale;
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p) {
     const int tid = threadIdx.x;
     const int h = blockIdx.y;
     const long r = blockIdx.z;
-    const int C3 = 3 * p.H * D;
+    const int C3 = p.ldkv;
     const T* base = (const T*)p.qkv + r * (long)p.Lmax * C3;
     const int qi = blockIdx.x * 256 + tid;
     const bool valid = qi < p.l;
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p) {
 
     float q[D], o[D];
     {
-        const T* qp = base + (long)pos * C3 + h * D;
+        const T* qp = (const T*)p.q + (r * p.q_rows + (pos - p.q_pos0)) * (long)p.ldq + h * D;
 #pragma unroll
         for (int d = 0; d < D; ++d) { q[d] = Elem<T>::ld(qp + d) * p.scale; o[d] = 0.f; }
     }
@@ -89,8 +92,8 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p) {
             const int kk = v / (D / VEC), d0 = (v % (D / VEC)) * VEC;
             const int key = kt0 + kk;
             if (key < kv_end) {
-                const T* kp = base + (long)key * C3 + p.H * D + h * D + d0;
-                const T* vp = kp + p.H * D;
+                const T* kp = base + (long)key * C3 + p.k_col + h * D + d0;
+                const T* vp = base + (long)key * C3 + p.v_col + h * D + d0;
 #pragma unroll
                 for (int e = 0; e < VEC; ++e) { Ks[kk][d0 + e] = Elem<T>::ld(kp + e); Vs[kk][d0 + e] = Elem<T>::ld(vp + e); }
             } else {
@@ -168,10 +171,16 @@ static int fill_levels(P& p, const int* lvl_end_host, int n_lvl, const int* hole
     return CVAR_OK;
 }
 
-static int cvar_attention_impl(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
+static int cvar_attention_impl(const void* qkv, const void* q, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
                                const int* lvl_end_host, int n_lvl, const int* hole_host, void* out, float* lse, void* stream, int impl) {
     if (!qkv || !out || R <= 0 || H <= 0 || l <= 0 || q_off < 0 || q_off + l > Lmax) return CVAR_EINVAL;
     AttnParams p;
+    const int C = H * 64;
+    if (q) {            // K/V arena [R][Lmax][2C] + this call's queries [R][l][C]
+        p.q = q; p.ldq = C; p.q_rows = l; p.q_pos0 = q_off; p.ldkv = 2 * C; p.k_col = 0; p.v_col = C;
+    } else {            // packed [R][Lmax][3C] (q | k | v thirds)
+        p.q = qkv; p.ldq = 3 * C; p.q_rows = Lmax; p.q_pos0 = 0; p.ldkv = 3 * C; p.k_col = C; p.v_col = 2 * C;
+    }
     p.qkv = qkv; p.out = out; p.R = R; p.H = H; p.Lmax = Lmax; p.q_off = q_off; p.l = l; p.scale = scale; p.lse = lse;
     { const int rc = fill_levels(p, lvl_end_host, n_lvl, hole_host); if (rc != CVAR_OK) return rc; }
     if (dtype == CVAR_BF16 && impl == 0) {
@@ -210,10 +219,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int lrow = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
     const int h = blockIdx.y;
     const long r = blockIdx.z;
-    const int C3 = 3 * p.H * D;
+    const int C3 = p.ldkv;
     const bf16_t* base = (const bf16_t*)p.qkv + r * (long)p.Lmax * C3;
-    const bf16_t* kbase = base + p.H * D + h * D;
-    const bf16_t* vbase = kbase + p.H * D;
+    const bf16_t* kbase = base + p.k_col + h * D;
+    const bf16_t* vbase = base + p.v_col + h * D;
 
     const int q0 = blockIdx.x * 128 + w * 32;
     const int qi = q0 + lrow;
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
     bf16x8_t qf[4];
     {
-        const bf16_t* qp = base + (long)(p.q_off + qrow) * C3 + h * D;
+        const bf16_t* qp = (const bf16_t*)p.q + (r * p.q_rows + (p.q_off + qrow - p.q_pos0)) * (long)p.ldq + h * D;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qp + (2 * ks + hi) * 8);
     }
@@ -388,13 +397,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
-extern "C" int cvar_attention_rowwise(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
+extern "C" int cvar_attention_rowwise(const void* qkv, const void* q, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
                                       const int* lvl_end_host, int n_lvl, const int* hole_host, void* out, float* lse, void* stream) {
-    return cvar_attention_impl(qkv, dtype, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, hole_host, out, lse, stream, 1);
+    return cvar_attention_impl(qkv, q, dtype, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, hole_host, out, lse, stream, 1);
 }
-extern "C" int cvar_attention(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
+extern "C" int cvar_attention(const void* qkv, const void* q, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
                               const int* lvl_end_host, int n_lvl, const int* hole_host, void* out, float* lse, void* stream) {
-    return cvar_attention_impl(qkv, dtype, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, hole_host, out, lse, stream, 0);
+    return cvar_attention_impl(qkv, q, dtype, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, hole_host, out, lse, stream, 0);
 }
 
 // ================================================================================================

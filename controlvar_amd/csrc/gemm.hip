@@ -57,6 +57,7 @@ struct GemmParams {
     const float* gate_scale;       // optional per-gate-row multiplier (DropPath keep-scale of training)
     int in_dtype;                  // operand dtype (for the split-K epilogue kernel, which is not templated on it)
     int remap_l, remap_L, remap_off;
+    void* Cs; int split_n; long ld_split;       // column split: columns [0, split_n) -> Cs[m][ld_split] (rows not remapped), the rest -> C at column n - split_n
     int tiles_m, tiles_n;
     int cv_adv, cv_rem;       // conv: a K tile advances (tap, ci) by (KT / Cin, KT % Cin) plus one carry
     unsigned conv_bytes;      // conv FAST: bytes of the NHWC input of one batch slice (buffer range: out-of-range offsets read zeros)
@@ -534,7 +535,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     const bool vec_ok = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && ((p.strideC & 7) == 0) && (((uintptr_t)p.C & 15) == 0) &&
                         (!p.residual || (((p.ldr & 7) == 0) && ((p.strideR & 7) == 0) && (((uintptr_t)p.residual & 15) == 0))) &&
                         (!p.gate || (((p.ldg & 3) == 0) && (((uintptr_t)p.gate & 15) == 0))) &&
-                        (!p.bias || (((uintptr_t)p.bias & 15) == 0)) && (!p.C2 || (((uintptr_t)p.C2 & 15) == 0));
+                        (!p.bias || (((uintptr_t)p.bias & 15) == 0)) && (!p.C2 || (((uintptr_t)p.C2 & 15) == 0)) &&
+                        (p.split_n <= 0 || (((p.split_n & 7) == 0) && ((p.ld_split & 7) == 0) && (((uintptr_t)p.Cs & 15) == 0)));
     // per-lane constants of the row-major phase: the column group never changes, so bias is loaded once
     const int n = n0 + wn * SUB_N + ecol;
     const bool lane_on = (erow < RPP) && (n < p.N);
@@ -563,6 +565,13 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             const int mrow = m0 + wm * SUB_M + erow;
             const float* stg_r = stg + erow * EROW + ecol;
             char* c_lane = Cb + (cz + n) * OES;
+            bool in_split = false;
+            if constexpr (remap) {               // qkv GEMM of inference: the q columns go to their own buffer, k | v to the arena
+                if (p.split_n > 0) {
+                    in_split = n < p.split_n;
+                    c_lane = in_split ? (char*)p.Cs + (long)n * OES : Cb + (cz + n - p.split_n) * OES;
+                }
+            }
             const char* r_lane = res ? (const char*)p.residual + (rz + n) * RES_ES : nullptr;
             const float* g_lane = gate ? p.gate + n : nullptr;
             // gate / residual operands are requested one half-pass AHEAD, i.e. before the previous half-pass's stores are issued:
@@ -646,6 +655,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                             orow = (long)sq * p.remap_L + p.remap_off + (m - sq * p.remap_l);
                         }
                         char* cp = c_lane + orow * p.ldc * OES;
+                        if constexpr (remap) { if (in_split) cp = c_lane + (long)m * p.ld_split * OES; }
                         if constexpr (out_bf) {
                             *(bf16x8_t*)cp = pack_bf16x8(v);
                         } else {
@@ -715,6 +725,12 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                 orow = (long)sq * p.remap_L + p.remap_off + (m - sq * p.remap_l);
             }
             const float* grow = p.gate ? p.gate + (long)fast_div(m, p.gate_magic, p.gate_shift) * p.ldg : nullptr;
+            void* Cdst = Cb;
+            long cbase = cz + orow * p.ldc + n;
+            if (p.split_n > 0) {
+                if (n < p.split_n) { Cdst = p.Cs; cbase = (long)m * p.ld_split + n; }
+                else cbase -= p.split_n;
+            }
             if (vec_ok) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += bias8[e];
@@ -751,9 +767,9 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                 if (v[0] == 1.2345e30f)
 #endif
                 if (p.out_dtype == CVAR_BF16) {
-                    *(bf16x8_t*)((bf16_t*)Cb + cz + orow * p.ldc + n) = pack_bf16x8(v);
+                    *(bf16x8_t*)((bf16_t*)Cdst + cbase) = pack_bf16x8(v);
                 } else {
-                    float* cp = (float*)Cb + cz + orow * p.ldc + n;
+                    float* cp = (float*)Cdst + cbase;
                     const f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
                     *(f32x4_t*)cp = o0;
                     *(f32x4_t*)(cp + 4) = o1;
@@ -768,7 +784,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                     else if (p.act == CVAR_ACT_GELU_GRAD) x *= gelu_tanh_grad(ld_any(p.aux, p.out_dtype, cz + (long)m * p.ldc + n + e));
                     if (grow) x *= grow[n + e] * (p.gate_scale ? p.gate_scale[fast_div(m, p.gate_magic, p.gate_shift)] : 1.0f);
                     if (p.residual) x += ld_any(p.residual, p.res_dtype, rz + (long)m * p.ldr + n + e);
-                    st_any(Cb, p.out_dtype, cz + orow * p.ldc + n + e, x);
+                    st_any(Cdst, p.out_dtype, cbase + e, x);
                 }
             }
         }
@@ -960,7 +976,10 @@ __global__ __launch_bounds__(256) void cvar_splitk_epilogue_kernel(const float* 
             else if (p.act == CVAR_ACT_GELU_GRAD) x *= gelu_tanh_grad(ld_any(p.aux, p.out_dtype, (long)m * p.ldc + n + e));
             if (grow) x *= grow[n + e] * (p.gate_scale ? p.gate_scale[fast_div(m, p.gate_magic, p.gate_shift)] : 1.0f);
             if (p.residual) x += ld_any(p.residual, p.res_dtype, (long)m * p.ldr + n + e);
-            st_any(p.C, p.out_dtype, orow * p.ldc + n + e, x);
+            if (p.split_n > 0) {
+                if (n < p.split_n) st_any(p.Cs, p.out_dtype, (long)m * p.ld_split + n + e, x);
+                else st_any(p.C, p.out_dtype, orow * p.ldc + (n - p.split_n) + e, x);
+            } else st_any(p.C, p.out_dtype, orow * p.ldc + n + e, x);
         }
     }
 }
@@ -989,6 +1008,13 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     if (d->pre_act && d->act == CVAR_ACT_GELU_GRAD) return CVAR_EINVAL;
     if (d->gate_scale && !d->gate) return CVAR_EINVAL;
     if ((d->pre_act || d->aux) && d->remap_l > 0) return CVAR_EUNSUPPORTED;
+    if (d->split_n < 0 || d->split_n >= d->N) return CVAR_EINVAL;
+    if (d->split_n > 0) {
+        if (!d->C_split || d->ld_split < d->split_n) return CVAR_EINVAL;
+        // the split rides on the row-remap epilogue (the qkv GEMM is its one user) and moves whole 8-wide vectors
+        if (d->remap_l <= 0 || d->conv || d->batch != 1 || d->residual || d->gate || d->act != CVAR_ACT_NONE) return CVAR_EUNSUPPORTED;
+        if ((d->split_n & 7) || (d->N & 7) || (d->ld_split & 7) || (d->ldc & 7) || ((uintptr_t)d->C_split & 15) || ((uintptr_t)d->C & 15)) return CVAR_EUNSUPPORTED;
+    }
     GemmParams p;
     p.M = d->M; p.N = d->N; p.K = d->K;
     p.A = (const char*)d->A; p.lda = d->lda; p.W = (const char*)d->W; p.ldw = d->ldw;
@@ -1001,6 +1027,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     p.C = d->C; p.out_dtype = d->out_dtype; p.ldc = d->ldc;
     p.C2 = d->pre_act; p.aux = d->aux; p.gate_scale = d->gate_scale; p.in_dtype = d->dtype;
     p.remap_l = d->remap_l; p.remap_L = d->remap_L; p.remap_off = d->remap_off;
+    p.Cs = d->C_split; p.split_n = d->split_n; p.ld_split = d->ld_split;
     p.tiles_m = p.tiles_n = 0;
     p.cv_adv = p.cv_rem = 0; p.conv_bytes = 0;
     make_fast_div(p.remap_l, &p.remap_magic, &p.remap_shift);
@@ -1041,7 +1068,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
         if (splits > 1 && need <= g_splitk_ws_bytes) {
             GemmParams ps = p;
             ps.alpha = 1.0f; ps.bias = nullptr; ps.act = CVAR_ACT_NONE; ps.gate = nullptr; ps.residual = nullptr; ps.C2 = nullptr; ps.aux = nullptr; ps.gate_scale = nullptr;
-            ps.C = g_splitk_ws; ps.out_dtype = CVAR_F32; ps.ldc = d->N; ps.remap_l = 0; ps.strideC = 0;
+            ps.C = g_splitk_ws; ps.out_dtype = CVAR_F32; ps.ldc = d->N; ps.remap_l = 0; ps.split_n = 0; ps.Cs = nullptr; ps.strideC = 0;
             ps.split_tiles = per; ps.split_stride = (long)d->M * d->N;
             const int rc = d->dtype == CVAR_BF16 ? launch_typed<bf16_t>(ps, 1, st) : cvar_gemm_launch_f32(ps, 1, st);
             if (rc != CVAR_OK) return rc;

@@ -120,7 +120,7 @@ extern "C" int cvar_silu_cast(const float* x, void* out, int out_dtype, int64_t 
 // One wave per (sequence, token, head, q|k); lane = channel.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void cos_qk_norm_kernel(T* __restrict__ qkv, int R, int H, int Lmax, int q_off, int l,
+__global__ __launch_bounds__(256) void cos_qk_norm_kernel(T* __restrict__ qkv, T* __restrict__ qs, int R, int H, int Lmax, int q_off, int l,
                                                          const float* __restrict__ scale_mul, float* __restrict__ norms) {
     const int lane = threadIdx.x & 63;
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);     // over R*l*H*2
@@ -131,7 +131,9 @@ __global__ __launch_bounds__(256) void cos_qk_norm_kernel(T* __restrict__ qkv, i
     const long rt = (item >> 1) / H;
     const int t = (int)(rt % l);
     const long r = rt / l;
-    T* p = qkv + ((r * Lmax + q_off + t) * 3 + which) * (long)(H * 64) + h * 64 + lane;
+    T* p;
+    if (qs) p = (which == 0 ? qs + (r * l + t) * (long)(H * 64) : qkv + (r * Lmax + q_off + t) * 2 * (long)(H * 64)) + h * 64 + lane;   // K/V arena + separate queries
+    else p = qkv + ((r * Lmax + q_off + t) * 3 + which) * (long)(H * 64) + h * 64 + lane;
     const float v = Elem<T>::ld(p);
     const float nrm = fmaxf(sqrtf(wave_sum(v * v)), 1e-12f);      // F.normalize eps
     float o = v / nrm;
@@ -140,13 +142,13 @@ __global__ __launch_bounds__(256) void cos_qk_norm_kernel(T* __restrict__ qkv, i
     if (norms && lane == 0) norms[item] = nrm;                     // [R][l][H][q|k], saved for the backward pass
 }
 
-extern "C" int cvar_cos_qk_norm(void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, const float* scale_mul,
+extern "C" int cvar_cos_qk_norm(void* qkv, void* q, int dtype, int R, int H, int Lmax, int q_off, int l, const float* scale_mul,
                                 float* norms, void* stream) {
     if (!qkv || !scale_mul || R <= 0 || H <= 0 || l <= 0) return CVAR_EINVAL;
     const long total = (long)R * l * H * 2;
     dim3 grid(cdiv(total, 4)), block(256);
-    if (dtype == CVAR_BF16) hipLaunchKernelGGL(cos_qk_norm_kernel<bf16_t>, grid, block, 0, as_stream(stream), (bf16_t*)qkv, R, H, Lmax, q_off, l, scale_mul, norms);
-    else if (dtype == CVAR_F32) hipLaunchKernelGGL(cos_qk_norm_kernel<float>, grid, block, 0, as_stream(stream), (float*)qkv, R, H, Lmax, q_off, l, scale_mul, norms);
+    if (dtype == CVAR_BF16) hipLaunchKernelGGL(cos_qk_norm_kernel<bf16_t>, grid, block, 0, as_stream(stream), (bf16_t*)qkv, (bf16_t*)q, R, H, Lmax, q_off, l, scale_mul, norms);
+    else if (dtype == CVAR_F32) hipLaunchKernelGGL(cos_qk_norm_kernel<float>, grid, block, 0, as_stream(stream), (float*)qkv, (float*)q, R, H, Lmax, q_off, l, scale_mul, norms);
     else return CVAR_EUNSUPPORTED;
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;
@@ -610,7 +612,7 @@ extern "C" int cvar_nhwc_to_nchw(const void* in, int dtype, int64_t ld_in, float
     return CVAR_OK;
 }
 
-extern "C" int cvar_abi_version(void) { return 10; }
+extern "C" int cvar_abi_version(void) { return 11; }
 extern "C" const char* cvar_status_str(int status) {
     switch (status) {
         case CVAR_OK: return "ok";

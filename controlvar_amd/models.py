@@ -638,14 +638,16 @@ class ControlVAR(nn.Module):
         xv[:, pos] = self._special_rows(table, pos, [mapping[i] for i in range(len(pos))])
 
     def _get_arena(self, R: int, Lmax: int):
-        """KV arena [depth][R][Lmax][3C] of the calling stream (generations running concurrently on different streams must not share it)"""
+        """KV arena [depth][R][Lmax][2C] (k | v halves; the queries of a scale are dead after its attention and live in a per-call scratch,
+        like the reference's cache of k and v only, basic_var.py:108-111) of the calling stream (generations running concurrently on
+        different streams must not share it)"""
         sid = torch.cuda.current_stream(self.device).cuda_stream
         key = (R, Lmax, self.compute_dtype)
         if self._arena is None:
             self._arena = {}
         ent = self._arena.get(sid)
         if ent is None or ent[0] != key:
-            ent = self._arena[sid] = (key, torch.empty(self.cfg.depth, R, Lmax, 3 * self.cfg.C, device=self.device, dtype=self.compute_dtype))
+            ent = self._arena[sid] = (key, torch.empty(self.cfg.depth, R, Lmax, 2 * self.cfg.C, device=self.device, dtype=self.compute_dtype))
         return ent[1]
 
     # ---- one pass of all blocks + head over l new tokens per sequence
@@ -660,15 +662,17 @@ class ControlVAR(nn.Module):
         u = torch.empty(M, C, device=dev, dtype=T)
         o = torch.empty(M, C, device=dev, dtype=T)
         hbuf = torch.empty(M, hid, device=dev, dtype=T)
-        arena_stride = R * Lmax * 3 * C
+        qs = torch.empty(M, C, device=dev, dtype=T)                 # queries of this pass: (R, l, C)
+        arena_stride = R * Lmax * 2 * C
         for i in range(cfg.depth):
             a0 = i * 6 * C
             ops.ln_modulate(x, ada, a0 + 2 * C, a0 + 4 * C, n_ada, l, u, M, C, cfg.norm_eps)
+            # one GEMM for q | k | v: the q columns land in the scratch, k | v rows straight in their KV-arena slots (row remap)
             ops.gemm(u, P['w_qkv'], arena, M=M, N=3 * C, K=C, w_off=i * 3 * C * C, bias=P['b_qkv'][i], c_off=i * arena_stride,
-                     ldc=3 * C, remap=(l, Lmax, q_off))
+                     ldc=2 * C, remap=(l, Lmax, q_off), split=(qs, C, C))
             if cfg.uses_cos_attn:
-                ops.cos_qk_norm(arena, R, H, Lmax, q_off, l, P['scale_mul'], qkv_off=i * arena_stride, sm_off=i * H)
-            ops.attention(arena, o, R, H, Lmax, q_off, l, float(cfg.attn_scale), lvl_end, qkv_off=i * arena_stride, holes=holes)
+                ops.cos_qk_norm(arena, R, H, Lmax, q_off, l, P['scale_mul'], qkv_off=i * arena_stride, sm_off=i * H, q=qs)
+            ops.attention(arena, o, R, H, Lmax, q_off, l, float(cfg.attn_scale), lvl_end, qkv_off=i * arena_stride, holes=holes, q=qs)
             ops.gemm(o, P['w_proj'], x, M=M, N=C, K=C, w_off=i * C * C, bias=P['b_proj'][i], gate=ada, gate_off=a0, ldg=n_ada, gate_rows=l,
                      residual=x)
             ops.ln_modulate(x, ada, a0 + 3 * C, a0 + 5 * C, n_ada, l, u, M, C, cfg.norm_eps)

@@ -67,8 +67,11 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
          residual: Optional[torch.Tensor] = None, ldr: int = 0,
          remap: Optional[Sequence[int]] = None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0, strideR: int = 0,
          conv: Optional[dict] = None, a_off: int = 0, w_off: int = 0, c_off: int = 0,
-         pre_act: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None, gate_scale: Optional[torch.Tensor] = None):
-    """C = epilogue(A @ W^T).  Offsets (*_off) are in elements of the respective tensor."""
+         pre_act: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None, gate_scale: Optional[torch.Tensor] = None,
+         split: Optional[tuple] = None):
+    """C = epilogue(A @ W^T).  Offsets (*_off) are in elements of the respective tensor.
+    split = (tensor, split_n, ld_split): result columns [0, split_n) go to ``tensor`` (rows not remapped), the rest to ``out`` at
+    column n - split_n (cvar_gemm_desc.C_split; the qkv GEMM of inference: q beside a [R][Lmax][2C] K/V arena)."""
     d = GemmDesc()
     d.M, d.N, d.K, d.dtype = M, N, K, dt(A)
     if W.dtype != A.dtype:
@@ -94,6 +97,11 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
     if remap is not None:
         d.remap_l, d.remap_L, d.remap_off = remap
     d.pre_act, d.aux, d.gate_scale = _ptr(pre_act), _ptr(aux), _ptr(gate_scale)
+    if split is not None:
+        st, d.split_n, d.ld_split = split
+        if st.dtype != out.dtype:
+            raise TypeError('split target and out must share a dtype')
+        d.C_split = _ptr(st)
     ws = _SPLITK_WS.get((A.device.index, _stream()))
     if ws is None:
         ws = ensure_splitk_workspace(A.device)
@@ -138,10 +146,13 @@ def _level_arrays(lvl_end, holes):
 
 def attention(qkv: torch.Tensor, out: torch.Tensor, R: int, H: int, Lmax: int, q_off: int, l: int, scale: float,
               lvl_end: Optional[Sequence[int]] = None, qkv_off: int = 0, rowwise: bool = False, lse: Optional[torch.Tensor] = None,
-              holes: Optional[Sequence[Sequence[int]]] = None):
+              holes: Optional[Sequence[Sequence[int]]] = None, q: Optional[torch.Tensor] = None):
+    """q=None: qkv is the packed arena [R][Lmax][3C]; q given: qkv is a K/V arena [R][Lmax][2C] and q holds the call's queries [R*l][C]"""
     n, arr, harr = _level_arrays(lvl_end, holes)
     fn = _lib.load().cvar_attention_rowwise if rowwise else _lib.load().cvar_attention
-    check(fn(_ptr(qkv) + qkv_off * qkv.element_size(), dt(qkv), R, H, Lmax, q_off, l, scale,
+    if q is not None and (q.dtype != qkv.dtype or q.numel() < R * l * H * 64):
+        raise ValueError('q must hold R*l rows of H*64 elements in the arena dtype')
+    check(fn(_ptr(qkv) + qkv_off * qkv.element_size(), _ptr(q), dt(qkv), R, H, Lmax, q_off, l, scale,
                                      arr, n, harr, _ptr(out), _ptr(lse), _stream()), 'cvar_attention')
     return out
 
@@ -155,8 +166,8 @@ def attention_bwd(qkv, o, dout, lse, dqkv, ws, R, H, Lmax, l, scale, lvl_end=Non
 
 
 def cos_qk_norm(qkv: torch.Tensor, R: int, H: int, Lmax: int, q_off: int, l: int, scale_mul: torch.Tensor,
-                qkv_off: int = 0, sm_off: int = 0, norms: Optional[torch.Tensor] = None):
-    check(_lib.load().cvar_cos_qk_norm(_ptr(qkv) + qkv_off * qkv.element_size(), dt(qkv), R, H, Lmax, q_off, l,
+                qkv_off: int = 0, sm_off: int = 0, norms: Optional[torch.Tensor] = None, q: Optional[torch.Tensor] = None):
+    check(_lib.load().cvar_cos_qk_norm(_ptr(qkv) + qkv_off * qkv.element_size(), _ptr(q), dt(qkv), R, H, Lmax, q_off, l,
                                        _ptr(scale_mul) + 4 * sm_off, _ptr(norms), _stream()), 'cvar_cos_qk_norm')
 
 

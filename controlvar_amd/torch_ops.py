@@ -307,6 +307,26 @@ def _attn_backward(ctx, dout, dlse):
 register_autograd('cvar::attention', _attn_backward, setup_context=_attn_setup)
 
 
+def _attention_kv(kv, q, H, q_off, scale, lvl_end, rowwise=False, holes=()):
+    """inference form: kv = (R, Lmax, 2*H*64) K/V arena (k | v halves), q = (R, l, H*64) queries of positions [q_off, q_off + l)
+    -> out (R*l, H*64).  No autograd (the KV-cached form is inference-only)."""
+    _check_operand(kv, 'attention_kv: kv')
+    _check_operand(q, 'attention_kv: q')
+    if kv.dim() != 3 or kv.shape[2] != 2 * H * 64 or not kv.is_contiguous():
+        raise ValueError(f'attention_kv: arena must be contiguous (R, Lmax, 2*H*64); got {tuple(kv.shape)} for H={H}')
+    R, Lmax, _ = kv.shape
+    if q.dim() != 3 or q.shape[0] != R or q.shape[2] != H * 64 or not q.is_contiguous() or q.dtype != kv.dtype:
+        raise ValueError(f'attention_kv: q must be contiguous (R, l, H*64) in the arena dtype; got {tuple(q.shape)} {q.dtype}')
+    l = q.shape[1]
+    out = torch.empty(R * l, H * 64, device=kv.device, dtype=kv.dtype)
+    K.attention(kv, out, R, H, Lmax, q_off, l, scale, list(lvl_end) or None, rowwise=rowwise or kv.dtype == torch.float32, holes=_holes(list(holes)), q=q)
+    return out
+
+
+_define('attention_kv', '(Tensor kv, Tensor q, int H, int q_off, float scale, int[] lvl_end, bool rowwise=False, int[] holes=[]) -> Tensor', _attention_kv,
+        lambda kv, q, H, q_off, scale, lvl_end, rowwise=False, holes=(): q.new_empty(q.shape[0] * q.shape[1], H * 64))
+
+
 def _cos_qk_norm_(qkv, H, q_off, l, scale_mul):
     R, Lmax, _ = qkv.shape
     K.cos_qk_norm(qkv, R, H, Lmax, q_off, l, scale_mul.float().contiguous())

@@ -41,7 +41,7 @@ const char* cvar_status_str(int status);
  * `stride`=2 is the asymmetric (0,1,0,1)-padded downsample (vae_modules.py:37).
  * Output row remap (remap_l > 0): row(m) = (m / remap_l) * remap_L + remap_off + m % remap_l  - used to write
  * the qkv rows of one scale straight into the per-sequence KV arena [R][Lmax][3C] (replaces torch.cat,
- * basic_var.py:106-108). */
+ * basic_var.py:106-108), or - with the column split below - k | v into a [R][Lmax][2C] arena and q next to it. */
 typedef struct {
     int M, N, K;
     int dtype;                       /* cvar_dtype of A and W */
@@ -82,6 +82,11 @@ typedef struct {
     int tile_cfg;
     int stagger;
     int group_m;                     /* row tiles per scheduling group; 0 = automatic (4 for long-K / fp32-output GEMMs, else 8).  Never changes results */
+    /* column split (ABI 11; split_n = 0: off): result columns [0, split_n) are stored to C_split[m * ld_split + n] (rows NOT
+     * remapped), columns [split_n, N) to C at column n - split_n with the row remap.  The qkv GEMM of inference uses it to put the
+     * queries of a scale into a scratch buffer and only k | v into the KV arena [R][Lmax][2C] (the reference caches k, v only:
+     * basic_var.py:108-111).  Needs remap_l > 0, no activation / gate / residual, split_n, N, ldc, ld_split multiples of 8. */
+    void* C_split; int split_n; int64_t ld_split;
 } cvar_gemm_desc;
 int cvar_gemm(const cvar_gemm_desc* d, void* stream);
 
@@ -104,13 +109,16 @@ int cvar_silu_cast(const float* x, void* out, int out_dtype, int64_t n, void* st
  * attn_bias_for_masking of training (control_var.py:158-168; levels = scales) and of `separate_decoding` (:170-180; levels =
  * half scales: a control token does not see the image half of its own scale).  hole_host (optional, 2*n_lvl ints): per level a key
  * range [lo, hi) in FRONT of the level that its queries do not see (lo >= hi: none) - the `indep` mask (:182-191), where the image
- * half of a scale is blind to the control half of the same scale.  out: [R*l][H*64] of `dtype`. */
-int cvar_attention(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
+ * half of a scale is blind to the control half of the same scale.  out: [R*l][H*64] of `dtype`.
+ * q (optional): when non-NULL, `qkv` is a K/V arena [R][Lmax][2*H*64] (k | v halves) and `q` holds the queries of THIS call,
+ * [R][l][H*64] (row t of sequence r = position q_off + t).  Inference uses this form: the queries of a scale are dead once its
+ * attention has run, so the cache keeps only K and V (the reference caches k, v only as well: basic_var.py:108-111). */
+int cvar_attention(const void* qkv, const void* q, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
                    const int* lvl_end_host, int n_lvl, const int* hole_host, void* out,
                    float* lse /* optional [R][H][l], saved for backward */, void* stream);
 /* same contract, always the exact row-per-lane fp32-math kernel (the parity-mode implementation; also the in-library
  * reference the bf16 MFMA flash kernel is A/B-tested against). */
-int cvar_attention_rowwise(const void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
+int cvar_attention_rowwise(const void* qkv, const void* q, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
                            const int* lvl_end_host, int n_lvl, const int* hole_host, void* out, float* lse, void* stream);
 /* backward of the level-masked attention (training forward, control_var.py:626-639 under autograd): given dO and the saved
  * lse, writes dQ | dK | dV into dqkv with the arena layout [R][Lmax][3*H*64].  ws: R*H*l floats.  q_off must be 0. */
@@ -122,8 +130,9 @@ int cvar_attention_bwd_rowwise(const void* qkv, int dtype, const void* o, const 
                                void* stream);
 
 /* cos-attention pre-pass (basic_var.py:99-104), in place on rows [q_off, q_off+l) of the arena:
- * q = normalize(q) * exp(min(scale_mul[h], log 100)),  k = normalize(k). */
-int cvar_cos_qk_norm(void* qkv, int dtype, int R, int H, int Lmax, int q_off, int l, const float* scale_mul,
+ * q = normalize(q) * exp(min(scale_mul[h], log 100)),  k = normalize(k).  q (optional): as for cvar_attention - K/V arena in
+ * `qkv` + the call's queries [R][l][H*64] in `q`. */
+int cvar_cos_qk_norm(void* qkv, void* q, int dtype, int R, int H, int Lmax, int q_off, int l, const float* scale_mul,
                      float* norms /* optional [R][l][H][2] = |q|, |k|, saved for training */, void* stream);
 /* backward of the pre-pass, in place on dqkv (arena layout, q_off 0): gradients w.r.t. the normalised q, k become gradients
  * w.r.t. the raw projections; dsm_tok[R*l][H] receives d loss / d scale_mul per token (summed over tokens by cvar_colsum). */

@@ -449,3 +449,71 @@ def test_groupnorm_large_mean_small_spread(gpu_device, dtype):
     ref = F.group_norm(xs, G, w.double(), b.double(), 1e-6).permute(0, 2, 1).reshape(B * HW, C)
     err = (out.double().cpu() - ref).abs().max().item()
     assert err < (2e-3 if dtype == torch.float32 else 3e-2), err          # fp32: output rounding of O(1) values scaled by rstd ~ 1e-2; bf16: output storage
+
+
+# ------------------------------------------------------------------------------------------------ K/V arena form (ABI 11)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('R,l,C,K', [(2, 9, 128, 64),        # small-M: split-K path
+                                     (4, 100, 1920, 256),    # d30 width: the q | k boundary (1920) crosses a 256-wide tile
+                                     (8, 256, 768, 768),     # 256x256 tiles, boundary on a tile edge
+                                     (3, 700, 256, 128)])    # ragged M
+def test_gemm_column_split_equals_the_unsplit_remap(gpu_device, dtype, R, l, C, K):
+    """cvar_gemm_desc.C_split: the q columns of the qkv GEMM go to their own (M, C) buffer, k | v into a [R][Lmax][2C] arena -
+    every element BIT-identical to the packed [R][Lmax][3C] result of the same call without the split."""
+    M, N, Lmax, off = R * l, 3 * C, l + 37, 11
+    A, W, b = to_dev(rnd(M, K, seed=1), dtype, gpu_device), to_dev(rnd(N, K, seed=2), dtype, gpu_device), rnd(N, seed=3).to(gpu_device)
+    packed = torch.zeros(R, Lmax, N, device=gpu_device, dtype=dtype)
+    ops.gemm(A, W, packed, M=M, N=N, K=K, bias=b, remap=(l, Lmax, off))
+    kv = torch.full((R, Lmax, 2 * C), float('nan'), device=gpu_device, dtype=dtype)
+    q = torch.full((M, C), float('nan'), device=gpu_device, dtype=dtype)
+    ops.gemm(A, W, kv, M=M, N=N, K=K, bias=b, ldc=2 * C, remap=(l, Lmax, off), split=(q, C, C))
+    assert torch.equal(q.view(R, l, C), packed[:, off:off + l, :C])
+    assert torch.equal(kv[:, off:off + l], packed[:, off:off + l, C:])
+    assert torch.isnan(kv[:, :off]).all() and torch.isnan(kv[:, off + l:]).all()          # rows of other scales untouched
+    ref = A.float().cpu() @ W.float().cpu().t() + b.cpu()
+    assert close(q, ref[:, :C], dtype, 2e-4)
+    from controlvar_amd._lib import CvarError
+    with pytest.raises(CvarError):
+        ops.gemm(A, W, kv, M=M, N=N, K=K, bias=b, ldc=2 * C, split=(q, C, C))                # the split rides on the row remap
+    with pytest.raises(CvarError):
+        ops.gemm(A, W, kv, M=M, N=N, K=K, ldc=2 * C, remap=(l, Lmax, off), split=(q, C + 4, C + 8))   # not a multiple of 8
+
+
+@pytest.mark.parametrize('dtype,rowwise', [(torch.float32, True), (torch.bfloat16, True), (torch.bfloat16, False)])
+@pytest.mark.parametrize('H,Lmax,q_off,l,levels', [(3, 60, 0, 60, (2, 10, 28, 60)), (2, 700, 188, 512, None), (12, 1360, 848, 512, None), (1, 40, 39, 1, None)])
+def test_attention_kv_arena_form_is_bit_identical_to_the_packed_form(gpu_device, dtype, rowwise, H, Lmax, q_off, l, levels):
+    """cvar_attention(qkv = K/V arena [R][Lmax][2C], q = [R][l][C]) == the packed-arena call on the same numbers; the separate
+    query buffer and every key row the queries must not see are surrounded / filled with NaNs."""
+    R, C = 2, H * 64
+    qkv = to_dev(rnd(R, Lmax, 3 * C, seed=5), dtype, gpu_device)
+    want = torch.empty(R * l, C, device=gpu_device, dtype=dtype)
+    ops.attention(qkv, want, R, H, Lmax, q_off, l, 0.125, levels, rowwise=rowwise)
+    kv = qkv[:, :, C:].contiguous()
+    kv[:, q_off + l:] = float('nan')
+    buf = torch.full((R * l * C + 4096,), float('nan'), device=gpu_device, dtype=dtype)
+    q = buf[2048:2048 + R * l * C].view(R, l, C)
+    q.copy_(qkv[:, q_off:q_off + l, :C])
+    got = torch.empty(R * l, C, device=gpu_device, dtype=dtype)
+    lse_a = torch.empty(R, H, l, device=gpu_device, dtype=torch.float32)
+    lse_b = torch.empty_like(lse_a)
+    ops.attention(kv, got, R, H, Lmax, q_off, l, 0.125, levels, rowwise=rowwise, q=q, lse=lse_b)
+    ops.attention(qkv, want, R, H, Lmax, q_off, l, 0.125, levels, rowwise=rowwise, lse=lse_a)
+    assert torch.isfinite(got.float()).all() and torch.equal(got, want) and torch.equal(lse_a, lse_b)
+    # in place: the output may overwrite the query buffer (each (sequence, head, query block) is read and written by one workgroup)
+    ops.attention(kv, q.view(R * l, C), R, H, Lmax, q_off, l, 0.125, levels, rowwise=rowwise, q=q)
+    assert torch.equal(q.view(R * l, C), want)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_cos_qk_norm_kv_arena_form(gpu_device, dtype):
+    R, H, Lmax, q_off, l = 2, 3, 20, 5, 9
+    C = H * 64
+    qkv = to_dev(rnd(R, Lmax, 3 * C, seed=3), dtype, gpu_device)
+    sm = torch.tensor([0.2, 1.4, 5.0], device=gpu_device)
+    kv = qkv[:, :, C:].contiguous()
+    q = qkv[:, q_off:q_off + l, :C].contiguous()
+    kv0 = kv.clone()
+    ops.cos_qk_norm(qkv, R, H, Lmax, q_off, l, sm)
+    ops.cos_qk_norm(kv, R, H, Lmax, q_off, l, sm, q=q)
+    assert torch.equal(q, qkv[:, q_off:q_off + l, :C]) and torch.equal(kv, qkv[:, :, C:])
+    assert torch.equal(kv[:, :q_off], kv0[:, :q_off]) and torch.equal(kv[:, :, C:], kv0[:, :, C:])      # other rows and V untouched

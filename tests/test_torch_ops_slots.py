@@ -47,6 +47,9 @@ def test_fake_kernels_give_shapes_without_a_gpu():
         assert ns.linear(a, w).shape == (3, 5, 128) and ns.linear(a, w, None, 0, None, 1, None, torch.float32).dtype == torch.float32
         o, lse = ns.attention(torch.empty(2, 10, 3 * 2 * 64, device='cuda', dtype=torch.bfloat16), 2, 4, 6, 0.1, [], False)
         assert o.shape == (12, 128) and lse.shape == (2, 2, 6) and lse.dtype == torch.float32
+        o2 = ns.attention_kv(torch.empty(2, 10, 2 * 2 * 64, device='cuda', dtype=torch.bfloat16), torch.empty(2, 6, 128, device='cuda', dtype=torch.bfloat16),
+                             2, 4, 0.1, [], False)
+        assert o2.shape == (12, 128)
         y = ns.ln_modulate(torch.empty(6, 64, device='cuda'), torch.empty(2, 64, device='cuda'), torch.empty(2, 64, device='cuda'), 3, 1e-6, torch.bfloat16)
         assert y.shape == (6, 64) and y.dtype == torch.bfloat16
         assert ns.cfg_sample(torch.empty(4, 7, 4096, device='cuda'), 2, 2, [2.0, -1.0], 900, 0.96, 1, 0, 1).shape == (2, 7)
@@ -244,6 +247,13 @@ def test_misc_ops_against_torch(gpu_device):
     m, v = torch.zeros_like(p), torch.zeros_like(p)
     ns.adamw_(p, gr, m, v, 1e-2, 0.9, 0.95, 1e-8, 0.05, 1, 1.0)
     assert rel_err(p, pt.detach()) < 1e-6
+    # inference form: K/V arena + the call's queries == the packed-arena op on the same numbers
+    qkv = torch.randn(2, 50, 3 * 128, generator=g).to(gpu_device, torch.bfloat16)
+    o_packed, _ = ns.attention(qkv, 2, 30, 20, 0.125, [], False)
+    o_kv = ns.attention_kv(qkv[:, :, 128:].contiguous(), qkv[:, 30:50, :128].contiguous(), 2, 30, 0.125, [], False)
+    assert torch.equal(o_packed, o_kv)
+    with pytest.raises(ValueError):
+        ns.attention_kv(qkv, qkv[:, 30:50, :128].contiguous(), 2, 30, 0.125, [], False)                # a packed arena is not a K/V arena
     # a bad status from the C ABI surfaces as RuntimeError
     with pytest.raises(RuntimeError):
         ns.attention(torch.zeros(1, 4, 3 * 64, device=gpu_device, dtype=torch.bfloat16), 1, 2, 5, 0.1, [], False)      # q_off + l > Lmax

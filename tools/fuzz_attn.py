@@ -81,6 +81,20 @@ for case in range(n_cases):
     ref = torch.empty(R * l, H * 64, device=dev, dtype=T)
     ops.attention(qkv, out, R, H, Lmax, q_off, l, scale, levels, holes=holes)
     ops.attention(qkv, ref, R, H, Lmax, q_off, l, scale, levels, rowwise=True, holes=holes)
+    # K/V-arena form (queries in their own NaN-fenced buffer): must be bit-identical to the packed form
+    Cq = H * 64
+    qbuf = torch.full((R * l * Cq + 2 * pad,), float('nan'), device=dev, dtype=T)
+    qs = qbuf[pad:pad + R * l * Cq].view(R, l, Cq)
+    qs.copy_(qkv[:, q_off:q_off + l, :Cq])
+    kvbuf = torch.full((R * Lmax * 2 * Cq + 2 * pad,), float('nan'), device=dev, dtype=T)
+    kv = kvbuf[pad:pad + R * Lmax * 2 * Cq].view(R, Lmax, 2 * Cq)
+    kv.copy_(qkv[:, :, Cq:])
+    out2 = torch.empty_like(out)
+    ops.attention(kv, out2, R, H, Lmax, q_off, l, scale, levels, holes=holes, q=qs)
+    if not torch.equal(out2, out):
+        bad += 1
+        print('FAIL', case, 'K/V-arena form differs from the packed form', (out2.float() - out.float()).abs().max().item(), flush=True)
+        continue
     a, b = out.float(), ref.float()
     err = ((a - b).abs() / (b.abs() + 0.05 * max(1.0, amp))).max().item() if torch.isfinite(a).all() and torch.isfinite(b).all() else float('nan')
     ok = err == err and err < 0.12          # bf16 P vs exact fp32 softmax; near one-hot rows (scale 1.0, large logits) sit at 0.07-0.09
