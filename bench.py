@@ -35,8 +35,9 @@ def parse():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--depth', type=int, default=24)
-    ap.add_argument('--batch', type=int, default=0, help='samples per GPU per step; 0 = 256 up to d24, 128 above (KV arena: 0.6 GB per sample at d24 bf16 '
-                                                          '-> 154 GB of the 288 GB at 256; larger batches fill the partial tile rounds of the mid scales: +2.5 %% over 128)')
+    ap.add_argument('--batch', type=int, default=0, help='samples per GPU per step; 0 = 384 up to d24, 128 above (K/V arena: 0.4 GB per sample at d24 bf16 '
+                                                          '-> 154 GB at 384, peak allocation 172 GB of the 288 GB; larger batches fill the partial tile rounds of the '
+                                                          'mid scales: 128 -> 256 +2.5 %%, 256 -> 384 +0.8 %%, 384 -> 512 +0.7 %% at 226 GB)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--cfg', type=float, default=4.0)
     ap.add_argument('--top_k', type=int, default=900)      # the reference's sampling defaults (train_control_var_hpu.py:338)
@@ -194,7 +195,7 @@ def main():
     t_build = time.time()
     vae = models.build_vae(ch=160, compute_dtype=T).to(dev)
     var = models.build_control_var(vae, depth=a.depth, mask_type='interleave_append', multi_cond=True, compute_dtype=T).to(dev).eval()
-    B = a.batch or (256 if a.depth <= 24 else 128)
+    B = a.batch or (384 if a.depth <= 24 else 128)
     g = torch.Generator().manual_seed(1234 + rank)
     labels = torch.randint(0, 1000, (B,), generator=g).to(dev)
     types = (torch.arange(B) % 4).to(dev)
@@ -233,6 +234,7 @@ def main():
                        'batch_per_gpu': B, 'global_batch': B * world, 'seq_len': cfg.pyramid.L, 'parallelism': f'dp{world} (sample-sharded, no collective)'},
             'algorithmic_tflop_per_image': round(per_sample_tf, 3),
             'end_to_end_tflops_per_gpu': round(per_sample_tf * B * a.steps / dt, 1),
+            'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
         }
         if prof:
             ms = sum(r[0].elapsed_time(r[1]) for r in prof)
