@@ -1,0 +1,195 @@
+// 3x3 stride-1 convolution over NHWC bf16 with the input tile (plus halo) resident in LDS.
+//
+// The implicit-GEMM conv of gemm.hip fetches every input pixel nine times (once per tap) through `buffer_load ... lds`, and at the
+// VQVAE's N = 160 tile that DMA issue rate (52 per 1 288 MFMA cycles) and the LDS re-reads of a 32x160 wave tile bound the loop
+// (profiles/r02_conv_timing.txt).  Here a workgroup owns a 16x16 pixel tile x 160 output channels:
+//   * per 32-channel chunk the 18x18 halo tile is DMA'd ONCE (21 pieces of 1 KiB) and the nine taps read it at shifted addresses;
+//   * weights stream as [160 couts][32 channels] tiles per (chunk, tap) (10 pieces) through a ring of three;
+//   * 4 waves x (64 pixels x 160 couts) = 20 MFMA 32x32x16 per wave and k-step pair, 7 fragment reads per 10 MFMAs;
+//   * 73 KB of LDS and <= 256 registers: TWO workgroups per CU, so one's barriers / epilogue hide behind the other's MFMAs.
+// K order: chunk-major, then tap (the implicit-GEMM kernel runs tap-major) - fp32 accumulation order differs, same math.
+// vae_modules.py:40-60 (ResnetBlock convs), :28 (Upsample conv after the nearest x2, handled by the caller), NHWC / [Cout][ky][kx][Cin].
+#include "cvar_common.h"
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct ConvHaloParams {
+    const bf16_t* X; const bf16_t* Wt; const float* bias; const bf16_t* res; bf16_t* out;
+    int B, H, W, Cin, Cout, tiles_x, tiles_y, nchunk;
+    int up, Hin, Win;          // up = 1: the conv reads its input through a nearest x2 upsample (Hin = H / 2), vae_modules.py:28
+};
+
+constexpr int CH_HALO_BYTES = 21 * 1024;      // 324 halo pixels x 64 B = 20 736 B, rounded up to whole 1-KiB DMA pieces
+constexpr int CH_W_BYTES = 10 * 1024;         // 160 rows x 64 B
+constexpr int CH_NB = 5;                      // 32-wide cout blocks per tile
+
+// LDS images: 64-byte rows (one pixel / one cout x 32 channels) whose four 16-B chunks are XOR-swizzled by (row >> 2) & 3, so that the
+// 16 lanes of a ds_read_b128 group - 16 consecutive rows, one logical chunk - cover all 64 banks once.
+__global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHaloParams p) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * CH_HALO_BYTES + 3 * CH_W_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, hi = lane >> 5;
+    int t_ = blockIdx.x;
+    const int tx = t_ % p.tiles_x; t_ /= p.tiles_x;
+    const int ty = t_ % p.tiles_y;
+    const int b = t_ / p.tiles_y;
+    const int ty0 = ty * 16, tx0 = tx * 16;
+    const int cout0 = blockIdx.y * (32 * CH_NB);
+    const bf16_t* ximg = p.X + (long)b * p.Hin * p.Win * p.Cin;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ximg, 0, p.Hin * p.Win * p.Cin * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Wt + (long)cout0 * 9 * p.Cin), 0, 32 * CH_NB * 9 * p.Cin * 2, 0x00020000);
+
+    // DMA piece q of an image = 16-B slot q of the LDS image: row q >> 2, physical chunk q & 3 <- logical chunk (q & 3) ^ ((row >> 2) & 3)
+    unsigned h_off[6], w_off[3];
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) {
+        const int q = (wave + 4 * jj) * 64 + lane;
+        const int hp = q >> 2, lc = (q & 3) ^ ((hp >> 2) & 3);
+        const int hy = hp / 18, hx = hp - hy * 18;
+        const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+        const bool ok = hp < 324 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        // out of range -> the DMA writes zeros (the conv's zero padding); upsample: output-grid pixel (gy, gx) reads input (gy >> 1, gx >> 1)
+        const int sy = p.up ? gy >> 1 : gy, sx = p.up ? gx >> 1 : gx;
+        h_off[jj] = ok ? (unsigned)(((sy * p.Win + sx) * p.Cin + lc * 8) * 2) : 0x80000000u;
+    }
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+        const int q = (wave + 4 * jj) * 64 + lane;
+        const int n = q >> 2, lc = (q & 3) ^ ((n >> 2) & 3);
+        w_off[jj] = n < 32 * CH_NB ? (unsigned)((n * 9 * p.Cin + lc * 8) * 2) : 0x80000000u;
+    }
+    auto issue_halo = [&](int c, int jj) -> int {
+        const int j = wave + 4 * jj;
+        if (j >= 21) return 0;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lptr_t)(smem + (c & 1) * CH_HALO_BYTES + j * 1024), 16, (int)h_off[jj], c * 64, 0, 0);
+        return 1;
+    };
+    // weight tiles live in a ring of three: tile (c, t) in slot t % 3 (9 taps per chunk, so the slot does not depend on c)
+    auto issue_w = [&](int c, int t) -> int {
+        int n = 0;
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            const int j = wave + 4 * jj;
+            if (j < 10) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(smem + 2 * CH_HALO_BYTES + (t % 3) * CH_W_BYTES + j * 1024), 16,
+                                                         (int)w_off[jj], (t * p.Cin + c * 32) * 2, 0, 0);
+                ++n;
+            }
+        }
+        return n;
+    };
+    // wait until at most n (wave-uniform, 0..4) of this wave's DMA pieces are outstanding
+    auto wait_vm = [&](int n) {
+        if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    // fragment addressing: pixel of lane = (4 wave + 2 i + (lrow >> 4), lrow & 15) of the tile -> halo row (y + dy) * 18 + (x + dx)
+    const int hpb = (4 * wave + (lrow >> 4)) * 18 + (lrow & 15);
+    const int swb = (lrow >> 2) & 3;
+    const int b_lane = lrow * 64;
+
+    f32x16_t acc[2][CH_NB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < CH_NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int jj = 0; jj < 6; ++jj) issue_halo(0, jj);
+    issue_w(0, 0);
+    if (p.nchunk > 0) issue_w(0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // Step (c, t): issue one halo piece of chunk c + 1 and the weight tile two steps ahead, compute, then wait only for what was issued in
+    // EARLIER steps (vmcnt retires in order): every DMA gets a full step or more to land - the halo pieces come from HBM, and waiting for
+    // them in the step that issued them stalled both resident workgroups at once.
+    for (int c = 0; c < p.nchunk; ++c) {
+        const char* hb = smem + (c & 1) * CH_HALO_BYTES;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            int issued = 0;
+            if (t < 6 && c + 1 < p.nchunk) issued += issue_halo(c + 1, t);
+            {
+                const int c2 = t + 2 >= 9 ? c + 1 : c, t2 = t + 2 >= 9 ? t + 2 - 9 : t + 2;
+                if (c2 < p.nchunk) issued += issue_w(c2, t2);
+            }
+            const char* wb = smem + 2 * CH_HALO_BYTES + (t % 3) * CH_W_BYTES;
+            const int d = (t / 3) * 18 + (t % 3);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t a[2], w[CH_NB];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int hp = hpb + 36 * i + d;
+                    a[i] = *(const bf16x8_t*)(hb + hp * 64 + (((2 * ks + hi) ^ ((hp >> 2) & 3)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < CH_NB; ++j) w[j] = *(const bf16x8_t*)(wb + j * 2048 + b_lane + (((2 * ks + hi) ^ swb) << 4));
+#pragma unroll
+                for (int j = 0; j < CH_NB; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[j], a[i], acc[i][j], 0, 0, 0);
+            }
+            wait_vm(issued);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    // epilogue: lane = pixel, register quad g of block j = couts 32 j + 8 g + 4 hi .. +3 (swapped MFMA operands) -> 8-byte accesses.
+    // All residual loads of a row block are issued before its first store: vmcnt retires in order and counts stores, so a load queued
+    // behind stores would wait for their latency as well (+13 % on the residual convs).  The bias comes straight from global memory (L2
+    // hits): a second static LDS array for it cost 6 % on every shape.
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int yy = 4 * wave + 2 * i + (lrow >> 4), xx = lrow & 15;
+        const long gpix = ((long)b * p.H + ty0 + yy) * p.W + tx0 + xx;
+        bf16_t* op = p.out + gpix * p.Cout + cout0 + 4 * hi;
+        const bf16_t* rp = p.res ? p.res + gpix * p.Cout + cout0 + 4 * hi : nullptr;
+        const float* bp = p.bias ? p.bias + cout0 + 4 * hi : nullptr;
+        bf16x4_t rq[CH_NB][4];
+        if (rp) {
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rq[j][g] = *(const bf16x4_t*)(rp + 32 * j + 8 * g);
+        }
+#pragma unroll
+        for (int j = 0; j < CH_NB; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = 32 * j + 8 * g;
+                f32x4_t bq = {0.f, 0.f, 0.f, 0.f};
+                if (bp) bq = *(const f32x4_t*)(bp + co);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bq[e];
+                if (rp) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += bf16_to_f32((bf16_t)rq[j][g][e]);
+                }
+                *(bf16x4_t*)(op + co) = pack_bf16x4(v);
+            }
+    }
+}
+
+// (H, W: the OUTPUT grid) eligibility is checked by the caller (cvar_gemm): bf16, stride 1, Cin % 32 == 0, Cout % 160 == 0, H % 16 == 0, W % 16 == 0
+int cvar_conv3x3_halo_bf16(const void* X, const void* Wt, const float* bias, const void* residual, void* out, int B, int H, int W, int Cin, int Cout,
+                           int up, hipStream_t st) {
+    ConvHaloParams p;
+    p.X = (const bf16_t*)X; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.res = (const bf16_t*)residual; p.out = (bf16_t*)out;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.tiles_x = W / 16; p.tiles_y = H / 16; p.nchunk = Cin / 32;
+    p.up = up ? 1 : 0; p.Hin = up ? H / 2 : H; p.Win = up ? W / 2 : W;
+    const long tiles = (long)B * p.tiles_x * p.tiles_y;
+    if (tiles <= 0 || tiles > 0x7fffffffL) return CVAR_EINVAL;
+    hipLaunchKernelGGL(conv3x3_halo_bf16_kernel, dim3((unsigned)tiles, Cout / (32 * CH_NB)), dim3(256), 0, st, p);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}

@@ -1078,6 +1078,14 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
             return CVAR_OK;
         }
     }
+    // stride-1 3x3 convs (plain or behind the nearest x2 upsample) over 32-channel multiples with 160-multiple outputs on 16-multiple images (every ResnetBlock conv of the VQVAE
+    // decoder from 16x16 up): the LDS-halo kernel (conv_halo.hip).  tile_cfg 5 keeps them on the implicit-GEMM tiles, 6 forces the halo kernel at any grid size (A/B runs, tests).
+    if (d->conv && d->dtype == CVAR_BF16 && d->out_dtype == CVAR_BF16 && d->stride == 1 && d->batch == 1 && (d->tile_cfg == 0 || d->tile_cfg == 6) &&
+        d->Cin % 32 == 0 && d->N % 160 == 0 && d->Hout % 16 == 0 && d->Wout % 16 == 0 && d->act == CVAR_ACT_NONE && !d->gate && d->alpha == 1.0f &&
+        d->ldc == d->N && (!d->residual || (d->res_dtype == CVAR_BF16 && d->ldr == d->N && (((uintptr_t)d->residual & 7) == 0))) &&
+        (((uintptr_t)d->C & 7) == 0) && (!d->bias || (((uintptr_t)d->bias & 15) == 0)) && (long)d->Hin * d->Win * d->Cin * 2 < 0x7fffffffL &&
+        ((long)(d->M / 256) * (d->N / 160) >= 512 || d->tile_cfg == 6))   // two workgroups per CU or the implicit-GEMM tiles win (640->640 at 16x16); 6 forces it
+        return cvar_conv3x3_halo_bf16(d->A, d->W, d->bias, d->residual, d->C, d->M / (d->Hout * d->Wout), d->Hout, d->Wout, d->Cin, d->N, d->up, st);
     if (d->dtype == CVAR_BF16) return d->conv ? cvar_gemm_launch_conv_bf16(p, d->batch, st) : launch_typed<bf16_t>(p, d->batch, st);
     return cvar_gemm_launch_f32(p, d->batch, st);
 }

@@ -526,3 +526,45 @@ def test_cos_qk_norm_kv_arena_form(gpu_device, dtype):
     ops.cos_qk_norm(kv, R, H, Lmax, q_off, l, sm, q=q)
     assert torch.equal(q, qkv[:, q_off:q_off + l, :C]) and torch.equal(kv, qkv[:, :, C:])
     assert torch.equal(kv[:, :q_off], kv0[:, :q_off]) and torch.equal(kv[:, :, C:], kv0[:, :, C:])      # other rows and V untouched
+
+
+# ------------------------------------------------------------------------------------------------ LDS-halo 3x3 conv (conv_halo.hip)
+@pytest.mark.parametrize('B,H,W,cin,cout,res,up', [(3, 32, 48, 32, 160, False, 0),      # one channel chunk, non-square, image borders everywhere
+                                                   (2, 16, 16, 96, 320, True, 0),       # one tile per image, two cout tiles, residual
+                                                   (2, 64, 32, 160, 160, True, 0),
+                                                   (2, 32, 32, 64, 160, False, 1),      # behind the nearest x2 upsample (input 16x16)
+                                                   (1, 48, 16, 320, 160, True, 1)])
+def test_conv3x3_halo_kernel_against_torch_and_the_implicit_gemm(gpu_device, B, H, W, cin, cout, res, up):
+    """conv_halo.hip (forced with tile_cfg 6) against torch's fp32 conv2d of the bf16-rounded operands and against the implicit-GEMM
+    tiles (tile_cfg 5).  The images in front of and behind the batch are NaN: a tap that leaves its image must read the zero padding."""
+    T = torch.bfloat16
+    hin, win = (H // 2, W // 2) if up else (H, W)
+    g = torch.Generator().manual_seed(B * 1000 + H + cin)
+    xs = torch.randn(B + 2, hin, win, cin, generator=g)
+    xs[0] = float('nan'); xs[-1] = float('nan')
+    buf = xs.to(T).to(gpu_device)
+    x = buf[1:B + 1].reshape(-1, cin)                                   # a view: NaN images on both sides in memory
+    w = (torch.randn(cout, 3, 3, cin, generator=g) / (9 * cin) ** 0.5).to(T)
+    bias = torch.randn(cout, generator=g)
+    r = torch.randn(B * H * W, cout, generator=g).to(T) if res else None
+    xin = x.float().cpu().view(B, hin, win, cin).permute(0, 3, 1, 2)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2, mode='nearest')
+    ref = F.conv2d(xin, w.float().permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1).reshape(B * H * W, cout)
+    if res:
+        ref = ref + r.float()
+    outs = {}
+    for cfg in (6, 5):
+        out = torch.full((B * H * W + 64, cout), float('nan'), device=gpu_device, dtype=T)
+        ops.GEMM_TILE_CFG = cfg
+        try:
+            ops.gemm(x, w.reshape(cout, 9 * cin).to(gpu_device), out, M=B * H * W, N=cout, K=9 * cin, bias=bias.to(gpu_device),
+                     residual=r.to(gpu_device) if res else None, conv=dict(Hin=hin, Win=win, Cin=cin, Hout=H, Wout=W, up=up))
+        finally:
+            ops.GEMM_TILE_CFG = 0
+        assert torch.isnan(out[B * H * W:].float()).all()               # nothing written behind the tensor
+        outs[cfg] = out[:B * H * W].float().cpu()
+        assert torch.isfinite(outs[cfg]).all()
+        assert close(outs[cfg], ref, T, bf16_rel=1e-2), (cfg, (outs[cfg] - ref).abs().max().item())
+    # both kernels round the same fp32 sums (different summation order) to bf16: at most one bf16 step apart
+    assert ((outs[6] - outs[5]).abs() <= 2.0 ** -7 * (ref.abs() + 1)).all()
