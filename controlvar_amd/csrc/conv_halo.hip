@@ -109,10 +109,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
     __builtin_amdgcn_s_barrier();
 
     // Step (c, t): issue one halo piece of chunk c + 1 and the weight tile two steps ahead, compute, then wait only for what was issued in
-    // EARLIER steps (vmcnt retires in order): every DMA gets a full step or more to land - the halo pieces come from HBM, and waiting for
-    // them in the step that issued them stalled both resident workgroups at once.
+    // EARLIER steps (vmcnt retires in order): every DMA gets a full step or more to land.  (Measured and rejected: a dedicated halo-DMA wave
+    // that waits once per chunk while three waves stream the weights: -3 %.)
+    // A fragments (halo reads) of a tap are fetched one step ahead - the halo buffer does not change inside a chunk, and the next chunk's has
+    // landed by tap 6 - so a step starts its MFMAs as soon as the first weight fragment is back from LDS (+1-3 %).  af[set][i][ks]
+    bf16x8_t af[2][2][2];
+    auto read_a = [&](int set, const char* hbuf, int d) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int hp = hpb + 36 * i + d;
+            const char* ap = hbuf + hp * 64;
+            const int sw = (hp >> 2) & 3;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[set][i][ks] = *(const bf16x8_t*)(ap + (((2 * ks + hi) ^ sw) << 4));
+        }
+    };
+    read_a(0, smem, 0);
     for (int c = 0; c < p.nchunk; ++c) {
         const char* hb = smem + (c & 1) * CH_HALO_BYTES;
+        const char* hb_next = smem + ((c + 1) & 1) * CH_HALO_BYTES;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             int issued = 0;
@@ -121,26 +136,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
                 const int c2 = t + 2 >= 9 ? c + 1 : c, t2 = t + 2 >= 9 ? t + 2 - 9 : t + 2;
                 if (c2 < p.nchunk) issued += issue_w(c2, t2);
             }
-            const char* wb = smem + 2 * CH_HALO_BYTES + (t % 3) * CH_W_BYTES;
-            const int d = (t / 3) * 18 + (t % 3);
+            const char* wb = smem + 2 * CH_HALO_BYTES + (t % 3) * CH_W_BYTES + b_lane;
+            bf16x8_t w[2][CH_NB];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8_t a[2], w[CH_NB];
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int hp = hpb + 36 * i + d;
-                    a[i] = *(const bf16x8_t*)(hb + hp * 64 + (((2 * ks + hi) ^ ((hp >> 2) & 3)) << 4));
-                }
+                for (int j = 0; j < CH_NB; ++j) w[ks][j] = *(const bf16x8_t*)(wb + j * 2048 + (((2 * ks + hi) ^ swb) << 4));
+            // next tap's A fragments (tap 0 of the next chunk after tap 8; past the last chunk the read is harmless and unused)
+            if (t < 8) read_a((t + 1) & 1, hb, ((t + 1) / 3) * 18 + ((t + 1) % 3));
+            else read_a(1, hb_next, 0);
 #pragma unroll
-                for (int j = 0; j < CH_NB; ++j) w[j] = *(const bf16x8_t*)(wb + j * 2048 + b_lane + (((2 * ks + hi) ^ swb) << 4));
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int j = 0; j < CH_NB; ++j)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[j], a[i], acc[i][j], 0, 0, 0);
-            }
+                    for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][j], af[t & 1][i][ks], acc[i][j], 0, 0, 0);
             wait_vm(issued);
             __builtin_amdgcn_s_barrier();
         }
+        // nine taps per chunk: the prefetched set is 1 after tap 8 - move it to set 0 so that every chunk starts alike
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) af[0][i][ks] = af[1][i][ks];
     }
 
     // epilogue: lane = pixel, register quad g of block j = couts 32 j + 8 g + 4 hi .. +3 (swapped MFMA operands) -> 8-byte accesses.
