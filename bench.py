@@ -248,7 +248,7 @@ def main():
                     traffic = json.load(open(tpath)).get('bytes_per_launch')
                 except Exception:
                     traffic = None
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'cvar_gemm_kernel (all GEMM + implicit-conv launches)',
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'cvar_gemm_kernel + conv3x3_halo_bf16_kernel (every cvar_gemm launch: GEMMs and 3x3 convs)',
                                'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                                'traffic': traffic, 'launches': len(prof), 'avg_launch_ms': round(ms / len(prof), 4),
                                'gemm_share_of_step': round(ms * 1e-3 / dt, 3)}

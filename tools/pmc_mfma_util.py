@@ -11,6 +11,7 @@ for f in glob.glob(src + '/**/*counter_collection.csv', recursive=True):
         fam = ('cvar_gemm_kernel 256x256' if 'cvar_gemm_kernel' in name and ', 256, 256,' in name else
                'cvar_gemm_kernel conv 256x160' if 'cvar_gemm_kernel' in name and ', 256, 160,' in name else
                'cvar_gemm_kernel other' if 'cvar_gemm_kernel' in name else
+               'conv3x3_halo_bf16_kernel' if 'conv3x3_halo' in name else
                'attn_mfma_bf16_kernel' if 'attn_mfma_bf16' in name else 'other')
         acc[fam][r['Counter_Name']] += float(r['Counter_Value'])
         if r['Counter_Name'] == 'GRBM_GUI_ACTIVE':
