@@ -38,6 +38,9 @@ __device__ __forceinline__ Vis vis_of(const P& p, int pos) {
     return v;
 }
 __device__ __forceinline__ bool vis_key(const Vis& v, int key) { return key < v.kvlen && !(key >= v.hlo && key < v.hhi); }
+// HOLES = false: the launch has no level with a hole (every default model) - the test and its operands compile away
+template <bool HOLES>
+__device__ __forceinline__ bool vis_key_t(const Vis& v, int key) { return key < v.kvlen && (!HOLES || !(key >= v.hlo && key < v.hhi)); }
 __device__ __forceinline__ int vis_full_prefix(const Vis& v) { return min(v.kvlen, v.hlo); }       // keys below this are all visible
 
 // keys below the returned bound are visible to EVERY query at positions [pos_lo, pos_hi]: the minimum of min(end, hole start) over the
@@ -147,7 +150,8 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p) {
     }
 }
 
-__global__ void attn_mfma_bf16_kernel(const AttnParams p);
+// (a template takes its launch bounds from the FIRST declaration: without them here the kernels are compiled for 1024-thread groups, 128 VGPRs)
+template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_mfma_bf16_kernel(const AttnParams p);
 
 // impl: 0 = auto (MFMA flash kernel for bf16, row-wise exact kernel for fp32), 1 = row-wise
 template <typename P>
@@ -184,7 +188,10 @@ static int cvar_attention_impl(const void* qkv, const void* q, int dtype, int R,
     p.qkv = qkv; p.out = out; p.R = R; p.H = H; p.Lmax = Lmax; p.q_off = q_off; p.l = l; p.scale = scale; p.lse = lse;
     { const int rc = fill_levels(p, lvl_end_host, n_lvl, hole_host); if (rc != CVAR_OK) return rc; }
     if (dtype == CVAR_BF16 && impl == 0) {
-        hipLaunchKernelGGL(attn_mfma_bf16_kernel, dim3(cdiv(l, 128), H, R), dim3(256), 0, as_stream(stream), p);
+        bool holes = false;
+        for (int i = 0; i < p.n_lvl; ++i) holes = holes || p.hole_lo[i] < p.hole_hi[i];
+        if (holes) hipLaunchKernelGGL(attn_mfma_bf16_kernel<true>, dim3(cdiv(l, 128), H, R), dim3(256), 0, as_stream(stream), p);
+        else hipLaunchKernelGGL(attn_mfma_bf16_kernel<false>, dim3(cdiv(l, 128), H, R), dim3(256), 0, as_stream(stream), p);
         CVAR_CHECK_LAUNCH();
         return CVAR_OK;
     }
@@ -211,6 +218,7 @@ static int cvar_attention_impl(const void* qkv, const void* q, int dtype, int R,
 constexpr int FA_VT_STRIDE = 68;      // elements per V^T row (64 keys + pad): 136 B, 8-B aligned, 2-way-free writes
 
 // 3 waves per SIMD (<= 168 VGPRs): the softmax phase of one wave overlaps the MFMA phases of the other two (+10 % over 2)
+template <bool HOLES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_mfma_bf16_kernel(const AttnParams p) {
     constexpr int D = 64, KT = 64;
     __shared__ __attribute__((aligned(16))) char Ks[KT * 128];
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int i = 0; i < 16; ++i) {
                 if constexpr (decltype(MASK)::value) {
                     const int key = kt0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hi;
-                    if (!vis_key(vis, key)) s[kb][i] = -INFINITY;
+                    if (!vis_key_t<HOLES>(vis, key)) s[kb][i] = -INFINITY;
                 }
                 tmax = fmaxf(tmax, s[kb][i]);
             }
@@ -593,8 +601,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
     }
 }
 
-__global__ void attn_bwd_dq_mfma_kernel(const AttnBwdParams p);
-__global__ void attn_bwd_dkv_mfma_kernel(const AttnBwdParams p);
+template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_dq_mfma_kernel(const AttnBwdParams p);
+template <bool HOLES> __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdParams p);
 
 // ws: R*H*l floats (D = rowsum(dO * O)).  impl: 0 = auto (MFMA kernels for bf16, row-wise exact kernels for fp32), 1 = row-wise
 static int cvar_attention_bwd_impl(const void* qkv, int dtype, const void* o, const void* dout, const float* lse, int R, int H, int Lmax,
@@ -610,8 +618,15 @@ static int cvar_attention_bwd_impl(const void* qkv, int dtype, const void* o, co
     if (dtype == CVAR_BF16) {
         hipLaunchKernelGGL(attn_bwd_prep_kernel<bf16_t>, dim3(cdiv(tot, 256)), dim3(256), 0, st, p);
         if (impl == 0) {
-            hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, dim3(cdiv(l, 128), H, R), dim3(256), 0, st, p);
-            hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, dim3(cdiv(l, 128), H, R), dim3(256), 0, st, p);
+            bool holes = false;
+            for (int i = 0; i < p.n_lvl; ++i) holes = holes || p.hole_lo[i] < p.hole_hi[i];
+            if (holes) {
+                hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<true>, dim3(cdiv(l, 128), H, R), dim3(256), 0, st, p);
+                hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, dim3(cdiv(l, 128), H, R), dim3(256), 0, st, p);
+            } else {
+                hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<false>, dim3(cdiv(l, 128), H, R), dim3(256), 0, st, p);
+                hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<false>, dim3(cdiv(l, 128), H, R), dim3(256), 0, st, p);
+            }
         } else {
             hipLaunchKernelGGL(attn_bwd_dq_kernel<bf16_t>, dim3(cdiv(l, 256), H, R), dim3(256), 0, st, p);
             hipLaunchKernelGGL(attn_bwd_dkv_kernel<bf16_t>, dim3(cdiv(l, 256), H, R), dim3(256), 0, st, p);
@@ -668,6 +683,7 @@ __device__ __forceinline__ bf16x8_t bw_read_tfrag(const bf16_t* T, int row, int 
     return f;
 }
 
+template <bool HOLES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_dq_mfma_kernel(const AttnBwdParams p) {   // 162 VGPRs, no spills
     constexpr int D = 64, KT = 64;
     __shared__ __attribute__((aligned(16))) char Ks[KT * 128];
@@ -735,7 +751,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], c2, -lse2));
                     if (need_mask) {
                         const int key = kt0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hi;
-                        if (!vis_key(vis, key)) pr = 0.f;
+                        if (!vis_key_t<HOLES>(vis, key)) pr = 0.f;
                     }
                     ds[j] = pr * (dp[kb][i] - Dq);
                 }
@@ -764,6 +780,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+template <bool HOLES>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdParams p) {
     constexpr int D = 64, QT = 64;
     __shared__ __attribute__((aligned(16))) char Qs[QT * 128];
@@ -812,7 +829,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdPar
             Ls[tid] = ok ? p.lse[(r * p.H + h) * (long)p.l + qi] * 1.4426950408889634f : 0.f;
             Dsum[tid] = ok ? p.dsum[(r * p.H + h) * (long)p.l + qi] : 0.f;
             const Vis vq = vis_of(p, p.q_off + (ok ? qi : 0));
-            Kv[tid] = ok ? vq.kvlen : 0; Hlo[tid] = vq.hlo; Hhi[tid] = vq.hhi;
+            Kv[tid] = ok ? vq.kvlen : 0;
+            if constexpr (HOLES) { Hlo[tid] = vq.hlo; Hhi[tid] = vq.hhi; }
         }
         __syncthreads();
 #pragma unroll
@@ -839,15 +857,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdPar
                     const f32x4_t l4 = *(const f32x4_t*)&Ls[qloc];
                     const f32x4_t d4 = *(const f32x4_t*)&Dsum[qloc];
                     const int4 k4 = *(const int4*)&Kv[qloc];
-                    const int4 l4i = *(const int4*)&Hlo[qloc];
-                    const int4 h4i = *(const int4*)&Hhi[qloc];
                     const int kvl[4] = {k4.x, k4.y, k4.z, k4.w};
-                    const int hlo4[4] = {l4i.x, l4i.y, l4i.z, l4i.w}, hhi4[4] = {h4i.x, h4i.y, h4i.z, h4i.w};
+                    int hlo4[4] = {0, 0, 0, 0}, hhi4[4] = {0, 0, 0, 0};
+                    if constexpr (HOLES) {
+                        const int4 l4i = *(const int4*)&Hlo[qloc];
+                        const int4 h4i = *(const int4*)&Hhi[qloc];
+                        hlo4[0] = l4i.x; hlo4[1] = l4i.y; hlo4[2] = l4i.z; hlo4[3] = l4i.w;
+                        hhi4[0] = h4i.x; hhi4[1] = h4i.y; hhi4[2] = h4i.z; hhi4[3] = h4i.w;
+                    }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int i = 4 * g + e;
                         float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c2, -l4[e]));
-                        if (krow >= kvl[e] || (krow >= hlo4[e] && krow < hhi4[e])) pr = 0.f;
+                        if (krow >= kvl[e] || (HOLES && krow >= hlo4[e] && krow < hhi4[e])) pr = 0.f;
                         pv[4 * g2 + e] = pr;
                         dsv[4 * g2 + e] = pr * (dp[i] - d4[e]);
                     }
