@@ -120,6 +120,9 @@ __device__ __forceinline__ TV block_excl_scan(TV v, TV* wsum /*[4]*/, TV& total)
     return base + inc - v;
 }
 
+// SOFT = false (every launch without more_smooth): the soft-embedding block and its registers compile away (146 -> ~90 VGPRs: the kernel is
+// bound by memory and LDS latency, and went 44 % slower when the block cost it two of its five waves per SIMD)
+template <bool SOFT>
 __global__ __launch_bounds__(256) void cfg_sample_kernel(const SampleParams p) {
     constexpr int EPT = 16;
     typedef unsigned long long u64;
@@ -269,6 +272,7 @@ __global__ __launch_bounds__(256) void cfg_sample_kernel(const SampleParams p) {
             p.idx_out[((long)d * p.B + b) * p.l + t] = pick;
         }
     }
+    if constexpr (SOFT) {
     if (p.soft_out) {
         // Gumbel-softmax over the KEPT logits (the reference masks `logits` in place before it calls gumbel_softmax_with_rng), then the
         // expectation of the code vectors under it.  One pass per draw row: the reference draws fresh noise for every replicated row.
@@ -333,6 +337,7 @@ __global__ __launch_bounds__(256) void cfg_sample_kernel(const SampleParams p) {
             }
         }
     }
+    }
 }
 
 extern "C" int cvar_cfg_sample(const float* logits, int B, int nrep, int l, int V, const float* coef_host,
@@ -354,7 +359,8 @@ extern "C" int cvar_cfg_sample(const float* logits, int B, int nrep, int l, int 
     p.idx_out = idx_out; p.combined = combined; p.margin = margin; p.kept = kept;
     dim3 grid((unsigned)((long)B * l)), block(256);
     if (top_k == 1) hipLaunchKernelGGL(cfg_greedy_kernel, grid, block, 0, as_stream(stream), p);
-    else hipLaunchKernelGGL(cfg_sample_kernel, grid, block, 0, as_stream(stream), p);
+    else if (soft_out) hipLaunchKernelGGL(cfg_sample_kernel<true>, grid, block, 0, as_stream(stream), p);
+    else hipLaunchKernelGGL(cfg_sample_kernel<false>, grid, block, 0, as_stream(stream), p);
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;
 }
