@@ -3,10 +3,10 @@
 // The implicit-GEMM conv of gemm.hip fetches every input pixel nine times (once per tap) through `buffer_load ... lds`, and at the
 // VQVAE's N = 160 tile that DMA issue rate (52 per 1 288 MFMA cycles) and the LDS re-reads of a 32x160 wave tile bound the loop
 // (profiles/r02_conv_timing.txt).  Here a workgroup owns a 16x16 pixel tile x 160 output channels:
-//   * per 32-channel chunk the 18x18 halo tile is DMA'd ONCE (21 pieces of 1 KiB) and the nine taps read it at shifted addresses;
+//   * per 32-channel chunk the 18x18 halo tile is DMA'd ONCE (23 pieces of 1 KiB, rows padded to 20 pixels) and the nine taps read it at shifted addresses;
 //   * weights stream as [160 couts][32 channels] tiles per (chunk, tap) (10 pieces) through a ring of three;
 //   * 4 waves x (64 pixels x 160 couts) = 20 MFMA 32x32x16 per wave and k-step pair, 7 fragment reads per 10 MFMAs;
-//   * 73 KB of LDS and <= 256 registers: TWO workgroups per CU, so one's barriers / epilogue hide behind the other's MFMAs.
+//   * 76 KB of LDS and <= 256 registers: TWO workgroups per CU, so one's barriers / epilogue hide behind the other's MFMAs.
 // K order: chunk-major, then tap (the implicit-GEMM kernel runs tap-major) - fp32 accumulation order differs, same math.
 // vae_modules.py:40-60 (ResnetBlock convs), :28 (Upsample conv after the nearest x2, handled by the caller), NHWC / [Cout][ky][kx][Cin].
 #include "cvar_common.h"
@@ -19,12 +19,19 @@ struct ConvHaloParams {
     int up, Hin, Win;          // up = 1: the conv reads its input through a nearest x2 upsample (Hin = H / 2), vae_modules.py:28
 };
 
-constexpr int CH_HALO_BYTES = 21 * 1024;      // 324 halo pixels x 64 B = 20 736 B, rounded up to whole 1-KiB DMA pieces
+constexpr int CH_HROW = 20;                   // halo row stride in pixels (18 used): a multiple of 4, so that the bank slot depends on the column only
+constexpr int CH_HALO_PIECES = 23;            // 18 rows x 20 pixels x 64 B = 23 040 B -> 23 DMA pieces of 1 KiB
+constexpr int CH_HALO_BYTES = CH_HALO_PIECES * 1024;
 constexpr int CH_W_BYTES = 10 * 1024;         // 160 rows x 64 B
 constexpr int CH_NB = 5;                      // 32-wide cout blocks per tile
 
-// LDS images: 64-byte rows (one pixel / one cout x 32 channels) whose four 16-B chunks are XOR-swizzled by (row >> 2) & 3, so that the
-// 16 lanes of a ds_read_b128 group - 16 consecutive rows, one logical chunk - cover all 64 banks once.
+// LDS images: 64-byte rows (one pixel / one cout x 32 channels) whose four 16-B chunks are XOR-swizzled so that every lane group of a
+// ds_read_b128 covers all 64 banks once.  The hardware's groups are NOT 16 consecutive lanes: group 0 = lanes {0-3, 12-15, 20-27} etc.
+// (MI355X_MICROARCH.md).  Weights: lane = row, swizzle (row >> 2) & 3 - any 16 rows that are distinct mod 16 are conflict-free.  Halo: a
+// group holds columns {0-3, 12-15} of one image row and {4-11} of the next, so the slot must depend on the COLUMN only: rows are padded to 20
+// pixels (20 mod 4 = 0) and the swizzle is ((column) >> 2) & 3 - then the group's 16 distinct columns (mod 16, for every tap shift) hit 16
+// distinct slots.  (With 18-pixel rows and a swizzle of the linear index two lanes of every group collided; fixing it measured +0.3 % -
+// the halo reads are 4 of the 14 fragment reads of a step - but it also freed 33 VGPRs of address state.)
 __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHaloParams p) {
     __shared__ __attribute__((aligned(1024))) char smem[2 * CH_HALO_BYTES + 3 * CH_W_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -45,10 +52,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
 #pragma unroll
     for (int jj = 0; jj < 6; ++jj) {
         const int q = (wave + 4 * jj) * 64 + lane;
-        const int hp = q >> 2, lc = (q & 3) ^ ((hp >> 2) & 3);
-        const int hy = hp / 18, hx = hp - hy * 18;
+        const int hp = q >> 2;
+        const int hy = hp / CH_HROW, hx = hp - hy * CH_HROW;
+        const int lc = (q & 3) ^ ((hx >> 2) & 3);
         const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-        const bool ok = hp < 324 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const bool ok = hy < 18 && hx < 18 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         // out of range -> the DMA writes zeros (the conv's zero padding); upsample: output-grid pixel (gy, gx) reads input (gy >> 1, gx >> 1)
         const int sy = p.up ? gy >> 1 : gy, sx = p.up ? gx >> 1 : gx;
         h_off[jj] = ok ? (unsigned)(((sy * p.Win + sx) * p.Cin + lc * 8) * 2) : 0x80000000u;
@@ -61,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
     }
     auto issue_halo = [&](int c, int jj) -> int {
         const int j = wave + 4 * jj;
-        if (j >= 21) return 0;
+        if (j >= CH_HALO_PIECES) return 0;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lptr_t)(smem + (c & 1) * CH_HALO_BYTES + j * 1024), 16, (int)h_off[jj], c * 64, 0, 0);
         return 1;
     };
@@ -89,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
     };
 
     // fragment addressing: pixel of lane = (4 wave + 2 i + (lrow >> 4), lrow & 15) of the tile -> halo row (y + dy) * 18 + (x + dx)
-    const int hpb = (4 * wave + (lrow >> 4)) * 18 + (lrow & 15);
+    const int hpb = (4 * wave + (lrow >> 4)) * CH_HROW + (lrow & 15);
     const int swb = (lrow >> 2) & 3;
     const int b_lane = lrow * 64;
 
@@ -115,11 +123,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
     // landed by tap 6 - so a step starts its MFMAs as soon as the first weight fragment is back from LDS (+1-3 %).  af[set][i][ks]
     bf16x8_t af[2][2][2];
     auto read_a = [&](int set, const char* hbuf, int d) {
+        const int sw = (((lrow & 15) + d % CH_HROW) >> 2) & 3;          // column of the lane's pixel + the tap's column shift
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int hp = hpb + 36 * i + d;
+            const int hp = hpb + 2 * CH_HROW * i + d;
             const char* ap = hbuf + hp * 64;
-            const int sw = (hp >> 2) & 3;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) af[set][i][ks] = *(const bf16x8_t*)(ap + (((2 * ks + hi) ^ sw) << 4));
         }
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
 #pragma unroll
                 for (int j = 0; j < CH_NB; ++j) w[ks][j] = *(const bf16x8_t*)(wb + j * 2048 + (((2 * ks + hi) ^ swb) << 4));
             // next tap's A fragments (tap 0 of the next chunk after tap 8; past the last chunk the read is harmless and unused)
-            if (t < 8) read_a((t + 1) & 1, hb, ((t + 1) / 3) * 18 + ((t + 1) % 3));
+            if (t < 8) read_a((t + 1) & 1, hb, ((t + 1) / 3) * CH_HROW + ((t + 1) % 3));
             else read_a(1, hb_next, 0);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
