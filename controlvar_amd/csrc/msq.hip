@@ -320,3 +320,59 @@ extern "C" int cvar_ms_encode(const float* f, const float* codebook, int V, cons
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Helpers of the low-resolution reconstruction path embed_to_fhat(all_to_max_scale=False) (quant.py:171-180; idxBl_to_img(same_shape=
+// False), vqvae.py:97-104: upstream's visualisation of the pyramid at each scale's own resolution).  Tiny tensors (<= 16x16x32).
+//   embed_rows   : out[n][:] = codebook[idx[n]][:]                                       (nn.Embedding lookup, vqvae.py:103)
+//   resample_sep : out[b][y][x][c] = sum_i sum_j wy[y][i] * wx[x][j] * in[b][i][j][c]     (F.interpolate as two dense matrices, NHWC fp32)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_rows_kernel(const int32_t* __restrict__ idx, const float* __restrict__ E, float* __restrict__ out,
+                                                        long n, int C, int V) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n * C; i += (long)gridDim.x * 256) {
+        const long r = i / C;
+        const int c = (int)(i - r * C);
+        const int v = min(max(idx[r], 0), V - 1);
+        out[i] = E[(long)v * C + c];
+    }
+}
+
+extern "C" int cvar_embed_rows(const int32_t* idx, const float* codebook, int V, float* out, int64_t n, int C, void* stream) {
+    if (!idx || !codebook || !out || n <= 0 || C <= 0 || V <= 0) return CVAR_EINVAL;
+    hipLaunchKernelGGL(embed_rows_kernel, dim3((unsigned)min((int64_t)1024, (n * C + 255) / 256)), dim3(256), 0, as_stream(stream), idx, codebook, out,
+                       (long)n, C, V);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+__global__ __launch_bounds__(256) void resample_sep_kernel(const float* __restrict__ in, const float* __restrict__ wy, const float* __restrict__ wx,
+                                                          float* __restrict__ out, int B, int h, int w, int H, int W, int C) {
+    const long total = (long)B * H * W * C;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < total; o += (long)gridDim.x * 256) {
+        const int c = (int)(o % C);
+        const int x = (int)((o / C) % W);
+        const int y = (int)((o / ((long)C * W)) % H);
+        const long b = o / ((long)C * W * H);
+        float acc = 0.f;
+        for (int i = 0; i < h; ++i) {
+            const float a = wy[y * h + i];
+            if (a == 0.f) continue;
+            float row = 0.f;
+            for (int j = 0; j < w; ++j) {
+                const float bq = wx[x * w + j];
+                if (bq != 0.f) row += bq * in[((b * h + i) * w + j) * C + c];
+            }
+            acc += a * row;
+        }
+        out[o] = acc;
+    }
+}
+
+extern "C" int cvar_resample_sep(const float* in, const float* wy, const float* wx, float* out, int B, int h, int w, int H, int W, int C, void* stream) {
+    if (!in || !wy || !wx || !out || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || C <= 0) return CVAR_EINVAL;
+    const long total = (long)B * H * W * C;
+    hipLaunchKernelGGL(resample_sep_kernel, dim3((unsigned)min((long)2048, (total + 255) / 256)), dim3(256), 0, as_stream(stream), in, wy, wx, out, B, h, w,
+                       H, W, C);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}

@@ -153,6 +153,13 @@ class VQVAE(nn.Module):
         pw = torch.stack([sd[f'quantize.quant_resi.qresi_ls.{k}.weight'] for k in range(nphi)])      # (k, co, ci, 3, 3)
         P['phi_w'] = pw.permute(0, 2, 3, 4, 1).reshape(nphi, self.Cvae, 9, self.Cvae).float().contiguous()   # [k][ci][tap][co]
         P['phi_b'] = torch.stack([sd[f'quantize.quant_resi.qresi_ls.{k}.bias'] for k in range(nphi)]).float().contiguous()
+        # Phi as ONE conv for the generic conv path (low-resolution reconstructions): h (1 - r) + (conv(h) + b) r = conv'(h) + b r with the
+        # identity folded into the centre tap, W' = r W + (1 - r) I  (quant.py:263-270)
+        r = float(self.cfg.quant_resi)
+        pf = pw.float() * r                                                                       # (k, co, ci, 3, 3)
+        pf[:, torch.arange(self.Cvae), torch.arange(self.Cvae), 1, 1] += 1.0 - r
+        P['phi_fold_w'] = pf.permute(0, 1, 3, 4, 2).reshape(nphi, self.Cvae, 9 * self.Cvae).contiguous()   # [k][co][tap][ci]
+        P['phi_fold_b'] = (P['phi_b'] * r).contiguous()
         up, down, offs = packed_tables(self.cfg.patch_nums)
         P['up'] = torch.from_numpy(up).to(dev)
         P['down'] = torch.from_numpy(down).to(dev)
@@ -198,15 +205,21 @@ class VQVAE(nn.Module):
         T = x.dtype
         n = self._gn(x, name + '.norm', B, HW, C, silu=False)
         qkv, _, _ = self._conv(n, name + '.qkv', B, HW, 1)                     # (B*HW, 3C): q | k | v
-        vT = torch.empty(B, C, HW, device=x.device, dtype=T)
-        ops.transpose(qkv, vT, B, HW, C, 3 * C, in_off=2 * C)
+        kch = 16 // x.element_size()
+        HWp = -(-HW // kch) * kch               # the GEMM's K dimension moves 16-byte chunks: pad the key axis of P and V^T with zeros
+        vT = torch.empty(B, C, HW, device=x.device, dtype=T) if HWp == HW else torch.zeros(B, C, HWp, device=x.device, dtype=T)
+        ops.transpose(qkv, vT, B, HW, C, 3 * C, in_off=2 * C, ld_out=HWp)
         s = torch.empty(B, HW, HW, device=x.device, dtype=torch.float32)
         ops.gemm(qkv, qkv, s, M=HW, N=HW, K=C, lda=3 * C, ldw=3 * C, w_off=C, alpha=float(int(C) ** -0.5), batch=B,
                  strideA=HW * 3 * C, strideW=HW * 3 * C, strideC=HW * HW)
         p = torch.empty(B, HW, HW, device=x.device, dtype=T)
         ops.softmax_rows(s, p, B * HW, HW)
+        if HWp != HW:                           # latent sizes other than 16x16 (low-resolution reconstructions, vqvae.py:97-104 same_shape=False)
+            pp = torch.zeros(B, HW, HWp, device=x.device, dtype=T)
+            pp[:, :, :HW] = p
+            p = pp
         o = torch.empty(B * HW, C, device=x.device, dtype=T)
-        ops.gemm(p, vT, o, M=HW, N=C, K=HW, batch=B, strideA=HW * HW, strideW=C * HW, strideC=HW * C)
+        ops.gemm(p, vT, o, M=HW, N=C, K=HWp, batch=B, strideA=HW * HWp, strideW=C * HWp, strideC=HW * C)
         y, _, _ = self._conv(o, name + '.proj_out', B, HW, 1, residual=x)
         return y
 
@@ -387,10 +400,12 @@ class VQVAE(nn.Module):
 
     @torch.no_grad()
     def idxBl_to_img(self, ms_idx_Bl: List[torch.Tensor], same_shape: bool = True, last_one: bool = False):
-        """vqvae.py:97-104 (same_shape=True path)"""
+        """vqvae.py:97-104; same_shape=False decodes every scale at its own resolution (images of 16 pn x 16 pn)"""
         self._pack(check=True)
-        if not same_shape:
-            raise NotImplementedError('all_to_max_scale=False is an experimental visualisation path upstream (quant.py:171-180)')
+        if not same_shape:                                   # every scale at its own resolution (quant.py:171-180)
+            rows = [self._embed(idx) for idx in ms_idx_Bl]
+            fh = self._lowres_fhats(rows, ms_idx_Bl[0].shape[0], last_one)
+            return self._decode(fh) if last_one else [self._decode(f) for f in fh]
         if last_one:
             return self._decode(self._idx_to_fhat(ms_idx_Bl))
         B = ms_idx_Bl[0].shape[0]
@@ -401,6 +416,67 @@ class VQVAE(nn.Module):
             self._next_input(si, ms_idx_Bl[si].to(torch.int32).contiguous(), f_hat, B, 1, False)
             outs.append(self._decode(f_hat[:, 0]))
         return outs
+
+    def _embed(self, idx_Bl: torch.Tensor) -> torch.Tensor:
+        """quantize.embedding(idx) -> (B * l, Cvae) fp32 rows (vqvae.py:103)"""
+        P = self._pack()
+        _check_index_range(idx_Bl, 0, self.V, 'token ids')
+        out = torch.empty(idx_Bl.numel(), self.Cvae, device=idx_Bl.device, dtype=torch.float32)
+        return ops.embed_rows(idx_Bl.to(torch.int32).contiguous(), P['E'], out)
+
+    def _lowres_fhats(self, ms_rows: List[torch.Tensor], B: int, last_one: bool):
+        """embed_to_fhat(all_to_max_scale=False) (quant.py:171-180): f_hat starts at the first scale's size, is bicubic-resized to every next
+        scale's size and receives phi_k(h_k) computed at THAT resolution.  ms_rows: per scale (B * pn * pn, Cvae) fp32 NHWC rows.
+        Returns (B, Cvae, pn, pn) fp32 maps - the last one, or one per scale."""
+        from .pyramid import bicubic_matrix
+        P = self._pack()
+        pns, C, dev = self.cfg.patch_nums, self.Cvae, ms_rows[0].device
+        if len(ms_rows) != len(pns):
+            raise ValueError(f'expected {len(pns)} scales, got {len(ms_rows)}')
+        mats = P.setdefault('lowres_mats', {})
+        f, prev, outs = None, None, []
+        for si, pn in enumerate(pns):
+            n = B * pn * pn
+            h = ms_rows[si].reshape(n, C).float().contiguous()
+            base = torch.zeros(n, C, device=dev, dtype=torch.float32)
+            if f is not None:
+                if (prev, pn) not in mats:
+                    mats[(prev, pn)] = torch.from_numpy(bicubic_matrix(prev, pn).astype('float32')).to(dev)
+                m = mats[(prev, pn)]
+                ops.resample_sep(f, m, m, base, B, prev, prev, pn, pn, C)
+            k = P['phi_map'][si]
+            f = torch.empty(n, C, device=dev, dtype=torch.float32)
+            ops.gemm(h, P['phi_fold_w'], f, M=n, N=C, K=9 * C, w_off=k * C * 9 * C, bias=P['phi_fold_b'][k], residual=base,
+                     conv=dict(Hin=pn, Win=pn, Cin=C, Hout=pn, Wout=pn))
+            prev = pn
+            if not last_one or si == len(pns) - 1:
+                o = torch.empty(B, C, pn, pn, device=dev, dtype=torch.float32)
+                ops.nhwc_to_nchw(f, C, o, B, C, pn * pn)
+                outs.append(o)
+        return outs[-1] if last_one else outs
+
+    @torch.no_grad()
+    def embed_to_fhat(self, ms_h_BChw: List[torch.Tensor], all_to_max_scale: bool = True, last_one: bool = False):
+        """quant.py:156-182: multi-scale embeddings (B, Cvae, pn, pn) -> f_hat (the last, or after every scale)"""
+        self._pack(check=True)
+        B = ms_h_BChw[0].shape[0]
+        rows = [h.float().permute(0, 2, 3, 1).reshape(B * h.shape[2] * h.shape[3], self.Cvae).contiguous() for h in ms_h_BChw]
+        if not all_to_max_scale:
+            return self._lowres_fhats(rows, B, last_one)
+        S = self.cfg.patch_nums[-1]
+        f_hat = torch.zeros(B, 1, self.Cvae, S, S, device=rows[0].device, dtype=torch.float32)
+        outs = []
+        for si in range(len(self.cfg.patch_nums)):
+            self._next_input(si, None, f_hat, B, 1, False, soft=rows[si].view(B, -1, self.Cvae))
+            if not last_one:
+                outs.append(f_hat[:, 0].clone())
+        return f_hat[:, 0] if last_one else outs
+
+    @torch.no_grad()
+    def embed_to_img(self, ms_h_BChw: List[torch.Tensor], all_to_max_scale: bool, last_one: bool = False):
+        """vqvae.py:91-95"""
+        fh = self.embed_to_fhat(ms_h_BChw, all_to_max_scale=all_to_max_scale, last_one=last_one)
+        return self._decode(fh) if last_one else [self._decode(f) for f in fh]
 
     @torch.no_grad()
     def img_to_recon(self, x, v_patch_nums=None, last_one=False):

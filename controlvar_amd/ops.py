@@ -246,6 +246,18 @@ def nhwc_to_nchw(inp, ld_in, out, B, Cdim, HW, lo=-3.0e38, hi=3.0e38, mul=1.0, a
     return out
 
 
+def embed_rows(idx: torch.Tensor, codebook: torch.Tensor, out: torch.Tensor):
+    """out[n] = codebook[idx[n]] (int32 ids, fp32 rows)"""
+    check(_lib.load().cvar_embed_rows(_ptr(idx), _ptr(codebook), codebook.shape[0], _ptr(out), idx.numel(), codebook.shape[1], _stream()), 'cvar_embed_rows')
+    return out
+
+
+def resample_sep(inp: torch.Tensor, wy: torch.Tensor, wx: torch.Tensor, out: torch.Tensor, B: int, h: int, w: int, H: int, W: int, Cdim: int):
+    """NHWC fp32 separable resample with dense (H x h), (W x w) matrices"""
+    check(_lib.load().cvar_resample_sep(_ptr(inp), _ptr(wy), _ptr(wx), _ptr(out), B, h, w, H, W, Cdim, _stream()), 'cvar_resample_sep')
+    return out
+
+
 # ------------------------------------------------------------------------------------------ training step
 def gate_residual(x, f, gate, gate_off, ldg, gate_rows, rowscale, M, Cdim):
     check(_lib.load().cvar_gate_residual(_ptr(x), _ptr(f), dt(f), _ptr(gate) + 4 * gate_off, ldg, gate_rows, _ptr(rowscale), M, Cdim, _stream()), 'cvar_gate_residual')

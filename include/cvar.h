@@ -209,6 +209,13 @@ int cvar_nchw_to_nhwc(const float* in, void* out, int dtype, int B, int C, int H
 int cvar_nhwc_to_nchw(const void* in, int dtype, int64_t ld_in, float* out, int B, int C, int HW,
                       float lo, float hi, float mul, float add, void* stream);
 
+/* Low-resolution pyramid reconstruction, embed_to_fhat(all_to_max_scale=False) (quant.py:171-180; idxBl_to_img(same_shape=False),
+ * vqvae.py:97-104) - ABI 12.  embed_rows: out[n][:] = codebook[idx[n]][:] (the nn.Embedding lookup, vqvae.py:103; ids clamped to [0, V)).
+ * resample_sep: NHWC fp32 out[b][y][x][c] = sum_ij wy[y][i] wx[x][j] in[b][i][j][c] with dense (H x h), (W x w) matrices - F.interpolate
+ * (bicubic / area) as the host tables of controlvar_amd/pyramid.py state it. */
+int cvar_embed_rows(const int32_t* idx, const float* codebook, int V, float* out, int64_t n, int C, void* stream);
+int cvar_resample_sep(const float* in, const float* wy, const float* wx, float* out, int B, int h, int w, int H, int W, int C, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Training step (train_control_var_hpu.py:207-250 under autograd; SURVEY.md 8a A5 backward / A20).  The backward
  * GEMMs reuse cvar_gemm on transposed operands; these are the remaining pieces.  All reductions have a fixed order.

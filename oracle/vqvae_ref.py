@@ -225,6 +225,27 @@ class MSQuant:
         return f_hat
 
 
+def embed_to_fhat_lowres(msq: MSQuant, ms_h: List[torch.Tensor]) -> List[torch.Tensor]:
+    """quantize.embed_to_fhat(all_to_max_scale=False, last_one=False) (quant.py:171-180): f_hat grows with the scales - bicubic-resized to
+    each scale's size, then phi_k(h_k) added at that resolution.  Returns the list of f_hat after every scale."""
+    B, C = ms_h[0].shape[:2]
+    f_hat = torch.zeros(B, C, msq.pn[0], msq.pn[0])
+    outs = []
+    for si, p in enumerate(msq.pn):
+        if f_hat.shape[-1] != p:
+            M = torch.from_numpy(bicubic_matrix(f_hat.shape[-1], p)).float()
+            f_hat = torch.einsum('ih,bchw,jw->bcij', M, f_hat, M)
+        f_hat = f_hat + msq.phi(si, ms_h[si])
+        outs.append(f_hat)
+    return outs
+
+
+def idxBl_to_img_lowres(sd: SD, msq: MSQuant, ms_idx, prec: Prec = FP32) -> List[torch.Tensor]:
+    """VQVAE.idxBl_to_img(same_shape=False, last_one=False) (vqvae.py:97-104): one image per scale, 16 pn pixels wide"""
+    ms_h = [msq.embed(idx, p) for idx, p in zip(ms_idx, msq.pn)]
+    return [fhat_to_img(sd, f, prec) for f in embed_to_fhat_lowres(msq, ms_h)]
+
+
 def img_to_idxBl(sd: SD, msq: MSQuant, img, prec: Prec = FP32):
     """VQVAE.img_to_idxBl (vqvae.py:73-75)."""
     return msq.f_to_idx(img_to_f(sd, img, prec))

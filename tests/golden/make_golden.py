@@ -595,6 +595,30 @@ def case_tokenizer_alt():
     save('tokenizer_alt', **out)
 
 
+def case_lowres():
+    """vqvae.py:91-104 / quant.py:156-182 with all_to_max_scale / same_shape = False: the reference's own per-scale f_hat list (each scale at
+    its own resolution) and the images decoded from it (tiny VQVAE, B=2), plus embed_to_fhat(all_to_max_scale=True) for the same embeddings."""
+    vae = make_vae(32)
+    img = synth_images(2, 256, seed=5)
+    with torch.no_grad():
+        ids = vae.img_to_idxBl(img, v_patch_nums=PN)
+        ms_h = [vae.quantize.embedding(i).transpose(1, 2).view(2, 32, pn, pn) for i, pn in zip(ids, PN)]
+        low = vae.quantize.embed_to_fhat(ms_h, all_to_max_scale=False, last_one=False)
+        full = vae.quantize.embed_to_fhat(ms_h, all_to_max_scale=True, last_one=False)
+        imgs = vae.idxBl_to_img(ids, same_shape=False, last_one=False)
+        last = vae.idxBl_to_img(ids, same_shape=False, last_one=True)
+    out = dict(ids=torch.cat(ids, dim=1).to(torch.int16))
+    for si, pn in enumerate(PN):
+        assert low[si].shape == (2, 32, pn, pn) and imgs[si].shape == (2, 3, 16 * pn, 16 * pn)
+        out[f'low_{si}'] = low[si].clone()
+        out[f'img_mean_{si}'] = imgs[si].mean(dim=(2, 3))
+        out[f'img_crop_{si}'] = imgs[si][:, :, :16, :16].clone()               # the top-left 16x16 of every scale's image
+        out[f'full_mean_{si}'] = full[si].mean(dim=(2, 3))
+    out['full_last'] = full[-1].clone()
+    assert torch.equal(last, imgs[-1])
+    save('lowres', **out)
+
+
 def _forward_fixture(m, cfg, tag, xseed, labels, types, mask_first=True):
     g = torch.Generator().manual_seed(xseed)
     x = torch.randn(2, len(cfg.pyramid.code_positions()) - cfg.pyramid.first_l, 32, generator=g)       # code tokens only (no separators)
@@ -679,6 +703,7 @@ CASES = {
     'train_sa_block': lambda: case_train_step(VarConfig(depth=2, sa_block=True, layer_scale=0.1), 'd2sa', 7),
     'train_variants': lambda: case_train_step(VarConfig(depth=2, shared_aln=True, type_pos=True), 'd2v', 5),
     'tok_alt': case_tokenizer_alt,
+    'lowres': case_lowres,
     'separator': case_separator,
     'train_separator': lambda: case_train_step(VarConfig(depth=2, separator=True), 'd2p', 13),
     'separate_decoding': case_separate_decoding,

@@ -115,6 +115,37 @@ def test_tokenizer_with_caller_chosen_scale_lists(gpu_device):
     assert all(torch.equal(a, b) for a, b in zip(vae.img_to_idxBl(img, v_patch_nums=PN), vae.img_to_idxBl(img)))
 
 
+def test_lowres_reconstruction_against_the_reference(gpu_device):
+    """A18: embed_to_fhat(all_to_max_scale=False) (quant.py:171-180) and idxBl_to_img(same_shape=False) / embed_to_img (vqvae.py:91-104):
+    per-scale f_hat at each scale's own resolution and the images decoded from it, against the reference's own outputs (lowres.npz);
+    embed_to_fhat(all_to_max_scale=True) for the same embeddings as well."""
+    g = golden('lowres')
+    vae = make_vae(32, F32, gpu_device)
+    sd = synth_vae_state(VaeConfig(ch=32))
+    E = sd['quantize.embedding.weight']
+    ids, o = [], 0
+    for pn in PN:
+        ids.append(t(g['ids'][:, o:o + pn * pn]).long().to(gpu_device)); o += pn * pn
+    ms_h = [E[i.cpu()].transpose(1, 2).reshape(2, 32, pn, pn).to(gpu_device) for i, pn in zip(ids, PN)]
+    low = vae.embed_to_fhat(ms_h, all_to_max_scale=False, last_one=False)
+    for si, pn in enumerate(PN):
+        assert low[si].shape == (2, 32, pn, pn)
+        assert (low[si].cpu() - t(g[f'low_{si}'])).abs().max() < 2e-5, si
+    assert torch.equal(vae.embed_to_fhat(ms_h, all_to_max_scale=False, last_one=True), low[-1])
+    imgs = vae.idxBl_to_img(ids, same_shape=False, last_one=False)
+    for si, pn in enumerate(PN):
+        assert imgs[si].shape == (2, 3, 16 * pn, 16 * pn)
+        assert (imgs[si][:, :, :16, :16].cpu() - t(g[f'img_crop_{si}'])).abs().max() < 2e-3, si
+        assert (imgs[si].mean(dim=(2, 3)).cpu() - t(g[f'img_mean_{si}'])).abs().max() < 3e-4, si
+    assert torch.equal(vae.idxBl_to_img(ids, same_shape=False, last_one=True), imgs[-1])
+    assert torch.equal(vae.embed_to_img(ms_h, all_to_max_scale=False, last_one=True), imgs[-1])
+    full = vae.embed_to_fhat(ms_h, all_to_max_scale=True, last_one=False)
+    for si in range(len(PN)):
+        assert (full[si].mean(dim=(2, 3)).cpu() - t(g[f'full_mean_{si}'])).abs().max() < 1e-5, si
+    assert (full[-1].cpu() - t(g['full_last'])).abs().max() < 2e-5
+    assert (vae.embed_to_fhat(ms_h, all_to_max_scale=True, last_one=True).cpu() - t(g['full_last'])).abs().max() < 2e-5
+
+
 def test_next_input_all_scales(gpu_device):
     """A14: get_next_autoregressive_input for every scale against the reference fixture (<= 2e-5)."""
     g = golden('next_input')

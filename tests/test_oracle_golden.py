@@ -390,3 +390,21 @@ def test_separator_state_layout_forward_and_generate(tag):
     mism = logits.argmax(-1).numpy() != g['argmax'].astype(np.int64)
     assert mism.sum() == 0 or g['margin'][mism].max() < 1e-4
     _gen_check(f'gen_{tag}_b2', cfg, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]), wseed=seed)
+
+
+def test_lowres_reconstruction_matches_the_reference(vae32):
+    """embed_to_fhat(all_to_max_scale=False) / idxBl_to_img(same_shape=False) (quant.py:171-180, vqvae.py:91-104): the oracle's per-scale
+    f_hat list and the images decoded from it against the reference's own (lowres.npz)"""
+    sd, msq = vae32
+    g = golden('lowres')
+    ids = split_ids(g['ids'])
+    ms_h = [msq.embed(i, p) for i, p in zip(ids, PN)]
+    low = vqvae_ref.embed_to_fhat_lowres(msq, ms_h)
+    for si, pn in enumerate(PN):
+        assert low[si].shape == (2, 32, pn, pn)
+        assert (low[si] - t(g[f'low_{si}'])).abs().max() < 2e-5, si
+    imgs = vqvae_ref.idxBl_to_img_lowres(sd, msq, ids)
+    for si, pn in enumerate(PN):
+        assert imgs[si].shape == (2, 3, 16 * pn, 16 * pn)
+        assert (imgs[si][:, :, :16, :16] - t(g[f'img_crop_{si}'])).abs().max() < 2e-3, si
+        assert (imgs[si].mean(dim=(2, 3)) - t(g[f'img_mean_{si}'])).abs().max() < 1e-4, si
