@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
     }
 }
 
-template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_dq_mfma_kernel(const AttnBwdParams p);
+template <bool HOLES> __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdParams p);
 template <bool HOLES> __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdParams p);
 
 // ws: R*H*l floats (D = rowsum(dO * O)).  impl: 0 = auto (MFMA kernels for bf16, row-wise exact kernels for fp32), 1 = row-wise
@@ -675,6 +675,33 @@ __device__ __forceinline__ void bw_stage_transposed(bf16_t* dst, const bf16_t* s
         *(unsigned*)(dst + (chunk * 8 + e) * BW_T_STRIDE + 2 * kp) = packed;
     }
 }
+// One global fetch feeds both images of a 64 x 64 tile: a thread owns rows 2 kp, 2 kp + 1 of one 16-byte chunk, which is exactly what the
+// transposed image packs per 32-bit write; the same registers go to the row-major image as two b128 writes (both rows share the swizzle
+// (row >> 1) & 7 = kp & 7).  The loads of tile i + 1 are issued before the MFMA work on tile i (the synchronous form exposed the load
+// latency of every tile to the two resident workgroups).
+struct BwPair { bf16x8_t a, b; };
+__device__ __forceinline__ BwPair bw_load_pair(const bf16_t* src, long row_stride, int row0, int row_limit, int tid) {
+    const int w = tid >> 6, lane = tid & 63;
+    const int kp = 16 * (w >> 1) + (lane & 15), chunk = 4 * (w & 1) + (lane >> 4);
+    const bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int r0 = row0 + 2 * kp;
+    BwPair v;
+    v.a = r0 < row_limit ? *(const bf16x8_t*)(src + (long)r0 * row_stride + chunk * 8) : z;
+    v.b = (r0 + 1) < row_limit ? *(const bf16x8_t*)(src + (long)(r0 + 1) * row_stride + chunk * 8) : z;
+    return v;
+}
+__device__ __forceinline__ void bw_store_both(char* rm, bf16_t* tr, const BwPair& v, int tid) {
+    const int w = tid >> 6, lane = tid & 63;
+    const int kp = 16 * (w >> 1) + (lane & 15), chunk = 4 * (w & 1) + (lane >> 4);
+    char* d = rm + (2 * kp) * 128 + ((chunk ^ (kp & 7)) << 4);
+    *(bf16x8_t*)d = v.a;
+    *(bf16x8_t*)(d + 128) = v.b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const unsigned packed = (unsigned)(unsigned short)v.a[e] | ((unsigned)(unsigned short)v.b[e] << 16);
+        *(unsigned*)(tr + (chunk * 8 + e) * BW_T_STRIDE + 2 * kp) = packed;
+    }
+}
 __device__ __forceinline__ bf16x8_t bw_read_tfrag(const bf16_t* T, int row, int col0) {     // 4 + 4 elements at col0 and col0 + 8
     const bf16_t* p = T + row * BW_T_STRIDE + col0;
     const bf16x4_t v0 = *(const bf16x4_t*)p;
@@ -684,7 +711,7 @@ __device__ __forceinline__ bf16x8_t bw_read_tfrag(const bf16_t* T, int row, int 
 }
 
 template <bool HOLES>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_dq_mfma_kernel(const AttnBwdParams p) {   // 162 VGPRs, no spills
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdParams p) {
     constexpr int D = 64, KT = 64;
     __shared__ __attribute__((aligned(16))) char Ks[KT * 128];
     __shared__ __attribute__((aligned(16))) char Vs[KT * 128];
@@ -719,11 +746,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
 
+    BwPair kv_k = bw_load_pair(kbase, C3, 0, kv_end, tid), kv_v = bw_load_pair(vbase, C3, 0, kv_end, tid);
     for (int kt0 = 0; kt0 < kv_end; kt0 += KT) {
-        bw_stage_rowmajor(Ks, kbase, C3, kt0, kv_end, tid);
-        bw_stage_rowmajor(Vs, vbase, C3, kt0, kv_end, tid);
-        bw_stage_transposed(Kt, kbase, C3, kt0, kv_end, tid);
+        bw_store_both(Ks, Kt, kv_k, tid);
+        {
+            const int w_ = tid >> 6, lane_ = tid & 63;
+            const int kp = 16 * (w_ >> 1) + (lane_ & 15), chunk = 4 * (w_ & 1) + (lane_ >> 4);
+            char* d = Vs + (2 * kp) * 128 + ((chunk ^ (kp & 7)) << 4);
+            *(bf16x8_t*)d = kv_v.a;
+            *(bf16x8_t*)(d + 128) = kv_v.b;
+        }
         __syncthreads();
+        if (kt0 + KT < kv_end) {            // next K / V tile travels while this one is computed
+            kv_k = bw_load_pair(kbase, C3, kt0 + KT, kv_end, tid);
+            kv_v = bw_load_pair(vbase, C3, kt0 + KT, kv_end, tid);
+        }
         f32x16_t s[2], dp[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -818,21 +855,36 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdPar
         for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
 
     const int q_begin = first_query_of(p, blockIdx.x * 128);            // first query that sees the block's first key
-    for (int qt0 = (q_begin / QT) * QT; qt0 < p.l; qt0 += QT) {
-        bw_stage_rowmajor(Qs, qbase, C3, qt0, p.l, tid);
-        bw_stage_rowmajor(Os, obase, (long)(p.H * D), qt0, p.l, tid);
-        bw_stage_transposed(Qt, qbase, C3, qt0, p.l, tid);
-        bw_stage_transposed(Ot, obase, (long)(p.H * D), qt0, p.l, tid);
+    const int qt_first = (q_begin / QT) * QT;
+    BwPair qv = bw_load_pair(qbase, C3, qt_first, p.l, tid), ov = bw_load_pair(obase, (long)(p.H * D), qt_first, p.l, tid);
+    float ls_v = 0.f, ds_v = 0.f;
+    auto load_rowstats = [&](int qt0) {
         if (tid < QT) {
             const int qi = qt0 + tid;
             const bool ok = qi < p.l;
-            Ls[tid] = ok ? p.lse[(r * p.H + h) * (long)p.l + qi] * 1.4426950408889634f : 0.f;
-            Dsum[tid] = ok ? p.dsum[(r * p.H + h) * (long)p.l + qi] : 0.f;
+            ls_v = ok ? p.lse[(r * p.H + h) * (long)p.l + qi] * 1.4426950408889634f : 0.f;
+            ds_v = ok ? p.dsum[(r * p.H + h) * (long)p.l + qi] : 0.f;
+        }
+    };
+    load_rowstats(qt_first);
+    for (int qt0 = qt_first; qt0 < p.l; qt0 += QT) {
+        bw_store_both(Qs, Qt, qv, tid);
+        bw_store_both(Os, Ot, ov, tid);
+        if (tid < QT) {
+            const int qi = qt0 + tid;
+            const bool ok = qi < p.l;
+            Ls[tid] = ls_v;
+            Dsum[tid] = ds_v;
             const Vis vq = vis_of(p, p.q_off + (ok ? qi : 0));
             Kv[tid] = ok ? vq.kvlen : 0;
             if constexpr (HOLES) { Hlo[tid] = vq.hlo; Hhi[tid] = vq.hhi; }
         }
         __syncthreads();
+        if (qt0 + QT < p.l) {               // next tile's operands travel while this tile is computed
+            qv = bw_load_pair(qbase, C3, qt0 + QT, p.l, tid);
+            ov = bw_load_pair(obase, (long)(p.H * D), qt0 + QT, p.l, tid);
+            load_rowstats(qt0 + QT);
+        }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16_t s, dp;
