@@ -145,6 +145,85 @@ __global__ __launch_bounds__(256) void ln_bwd_row_kernel(const float* __restrict
     }
     if (lane == 0) { stats[2 * (long)row] = mu; stats[2 * (long)row + 1] = rstd; }
 }
+// The same row kernel with the row held in registers (x, dy, 1 + s as NV float4 vectors per lane, C <= NV * 256): one pass over memory
+// instead of four dword-strided ones (the scalar form re-read the 6 KB row through L2 four times and ran at 2.4 TB/s effective).
+template <typename T, int NV, bool TAIL>
+__global__ __launch_bounds__(256) void ln_bwd_row_vec_kernel(const float* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ scale,
+                                                            long ld_ada, int rows_per, const float* __restrict__ dx_in, float* __restrict__ dx_out,
+                                                            float* __restrict__ stats, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (long)row * C;
+    const T* dyr = dy + (long)row * C;
+    const float* sc = scale + (long)(row / rows_per) * ld_ada;
+    f32x4_t xv[NV], gv[NV], din[NV];
+    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        const bool ok = !(TAIL && i == NV - 1) || c < C;
+        xv[i] = ok ? *(const f32x4_t*)(xr + c) : zero4;
+        const f32x4_t s4 = ok ? *(const f32x4_t*)(sc + c) : zero4;
+        f32x4_t d4 = zero4;
+        if (ok) {
+            if constexpr (sizeof(T) == 2) {
+                const bf16x4_t dq = *(const bf16x4_t*)(dyr + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d4[e] = bf16_to_f32((bf16_t)dq[e]);
+            } else {
+                d4 = *(const f32x4_t*)(dyr + c);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gv[i][e] = d4[e] * (1.0f + s4[e]);
+        din[i] = (ok && dx_in) ? *(const f32x4_t*)(dx_in + (long)row * C + c) : zero4;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        const bool ok = !(TAIL && i == NV - 1) || c < C;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xv[i][e] = ok ? xv[i][e] - mu : 0.f; q += xv[i][e] * xv[i][e]; }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { xv[i][e] *= rstd; sg += gv[i][e]; sgx += gv[i][e] * xv[i][e]; }
+    const float mg = wave_sum(sg) / (float)C, mgx = wave_sum(sgx) / (float)C;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (TAIL && i == NV - 1 && c >= C) continue;
+        f32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = din[i][e] + rstd * (gv[i][e] - mg - xv[i][e] * mgx);
+        *(f32x4_t*)(dx_out + (long)row * C + c) = o;
+    }
+    if (lane == 0) { stats[2 * (long)row] = mu; stats[2 * (long)row + 1] = rstd; }
+}
+template <typename T>
+static bool ln_bwd_row_vec_launch(const float* x, const T* dy, const float* scale, long ld_ada, int rows_per, const float* dx_in, float* dx_out, float* stats,
+                                  int M, int C, float eps, hipStream_t st) {
+    if (C % 4 || C > 2048 || ld_ada % 4 || (((uintptr_t)x | (uintptr_t)scale | (uintptr_t)dx_out | (uintptr_t)dx_in) & 15) || ((uintptr_t)dy & 7)) return false;
+    const int nv = (C + 255) / 256;
+    const bool tail = (C % 256) != 0;
+    const dim3 grid(cdiv(M, 4)), block(256);
+#define CVAR_LNB(NVV)                                                                                                                          \
+    case NVV:                                                                                                                                  \
+        if (tail) hipLaunchKernelGGL((ln_bwd_row_vec_kernel<T, NVV, true>), grid, block, 0, st, x, dy, scale, ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps); \
+        else hipLaunchKernelGGL((ln_bwd_row_vec_kernel<T, NVV, false>), grid, block, 0, st, x, dy, scale, ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps);     \
+        return true;
+    switch (nv) { CVAR_LNB(1) CVAR_LNB(2) CVAR_LNB(3) CVAR_LNB(4) CVAR_LNB(5) CVAR_LNB(6) CVAR_LNB(7) CVAR_LNB(8) default: return false; }
+#undef CVAR_LNB
+}
 // column kernel: partial[s][r][0][c] = sum dy * xhat, partial[s][r][1][c] = sum dy
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_col_kernel(const float* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ stats,
@@ -183,10 +262,12 @@ extern "C" int cvar_ln_modulate_bwd(const float* x, const void* dy, int dtype, c
     float* partial = ws + 2 * (size_t)M;
     dim3 b256(256);
     if (dtype == CVAR_BF16) {
-        hipLaunchKernelGGL(ln_bwd_row_kernel<bf16_t>, dim3(cdiv(M, 4)), b256, 0, as_stream(stream), x, (const bf16_t*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps);
+        if (!ln_bwd_row_vec_launch<bf16_t>(x, (const bf16_t*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps, as_stream(stream)))
+            hipLaunchKernelGGL(ln_bwd_row_kernel<bf16_t>, dim3(cdiv(M, 4)), b256, 0, as_stream(stream), x, (const bf16_t*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps);
         hipLaunchKernelGGL(ln_bwd_col_kernel<bf16_t>, dim3(cdiv(C, 256), R, RED_S), b256, 0, as_stream(stream), x, (const bf16_t*)dy, stats, partial, R, rows_per, C);
     } else if (dtype == CVAR_F32) {
-        hipLaunchKernelGGL(ln_bwd_row_kernel<float>, dim3(cdiv(M, 4)), b256, 0, as_stream(stream), x, (const float*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps);
+        if (!ln_bwd_row_vec_launch<float>(x, (const float*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps, as_stream(stream)))
+            hipLaunchKernelGGL(ln_bwd_row_kernel<float>, dim3(cdiv(M, 4)), b256, 0, as_stream(stream), x, (const float*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps);
         hipLaunchKernelGGL(ln_bwd_col_kernel<float>, dim3(cdiv(C, 256), R, RED_S), b256, 0, as_stream(stream), x, (const float*)dy, stats, partial, R, rows_per, C);
     } else return CVAR_EUNSUPPORTED;
     hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(cdiv(C, 256), R), b256, 0, as_stream(stream), partial, dscale, dshift, (long)ldo, R, C);
