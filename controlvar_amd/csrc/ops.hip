@@ -200,25 +200,44 @@ extern "C" int cvar_cos_qk_norm_bwd(const void* qkv, void* dqkv, int dtype, int 
 // ------------------------------------------------------------------------------------------------
 // word_embed + lvl_pos (fp32): x[rep*nb+b][t][c] = bias[c] + lvl_pos[t][c] + sum_k tok[b][t][k] W[c][k]
 // ------------------------------------------------------------------------------------------------
+// A thread owns ONE output channel (its 32-float weight row stays in registers) and walks WE_TOK tokens of the block's tile, whose token vectors
+// sit in LDS (broadcast reads).  The token-per-block form re-read the whole 196 KB weight matrix from L2 for every 6 KB output row.  Same fma
+// chain per output as before: bit-identical.
+constexpr int WE_TOK = 64;
 __global__ __launch_bounds__(256) void word_embed_kernel(const float* __restrict__ tok, const float* __restrict__ W,
                                                         const float* __restrict__ bias, const float* __restrict__ lvl_pos,
                                                         float* __restrict__ x, int nb, int nrep, int l, int Cvae, int C,
                                                         int x_rows, int x_off) {
-    __shared__ float tk[64];
-    const long bt = blockIdx.x;               // b*l + t
-    const int t = (int)(bt % l);
-    const long b = bt / l;
-    if (threadIdx.x < Cvae) tk[threadIdx.x] = tok[bt * Cvae + threadIdx.x];
+    __shared__ __attribute__((aligned(16))) float tk[WE_TOK * 64];
+    const long ntok = (long)nb * l;
+    const long bt0 = (long)blockIdx.x * WE_TOK;
+    const int nt = (int)min((long)WE_TOK, ntok - bt0);
+    for (int i = threadIdx.x; i < nt * Cvae; i += 256) tk[i] = tok[bt0 * Cvae + i];
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const float* w = W + (long)c * Cvae;
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    f32x4_t wv[16];
+#pragma unroll
+    for (int k4 = 0; k4 < 16; ++k4) {
+        const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+        wv[k4] = 4 * k4 < Cvae ? *(const f32x4_t*)(W + (long)c * Cvae + 4 * k4) : z;
+    }
+    const float bc = bias[c];
+    for (int i = 0; i < nt; ++i) {
+        const long bt = bt0 + i;
+        const int t = (int)(bt % l);
+        const long b = bt / l;
+        const float* tv = tk + i * Cvae;
         float acc = 0.f;
-        for (int k = 0; k < Cvae; k += 4) {
-            const f32x4_t wv = *(const f32x4_t*)(w + k);
-            acc = fmaf(tk[k], wv[0], acc); acc = fmaf(tk[k + 1], wv[1], acc);
-            acc = fmaf(tk[k + 2], wv[2], acc); acc = fmaf(tk[k + 3], wv[3], acc);
+#pragma unroll
+        for (int k4 = 0; k4 < 16; ++k4) {
+            if (4 * k4 < Cvae) {
+                const f32x4_t q = *(const f32x4_t*)(tv + 4 * k4);
+                acc = fmaf(q[0], wv[k4][0], acc); acc = fmaf(q[1], wv[k4][1], acc);
+                acc = fmaf(q[2], wv[k4][2], acc); acc = fmaf(q[3], wv[k4][3], acc);
+            }
         }
-        const float v = (acc + bias[c]) + lvl_pos[(long)t * C + c];
+        const float v = (acc + bc) + lvl_pos[(long)t * C + c];
         for (int rep = 0; rep < nrep; ++rep) x[(((long)rep * nb + b) * x_rows + x_off + t) * C + c] = v;
     }
 }
@@ -228,7 +247,9 @@ extern "C" int cvar_word_embed(const float* tok, const float* W, const float* bi
     if (!tok || !W || !bias || !lvl_pos || !x || nb <= 0 || nrep <= 0 || l <= 0) return CVAR_EINVAL;
     if (x_rows < x_off + l || x_off < 0) return CVAR_EINVAL;
     if (Cvae > 64 || Cvae % 4) return CVAR_EUNSUPPORTED;
-    hipLaunchKernelGGL(word_embed_kernel, dim3((unsigned)((long)nb * l)), dim3(256), 0, as_stream(stream), tok, W, bias, lvl_pos, x, nb, nrep, l, Cvae, C, x_rows, x_off);
+    const long ntok = (long)nb * l;
+    hipLaunchKernelGGL(word_embed_kernel, dim3((unsigned)((ntok + WE_TOK - 1) / WE_TOK), (unsigned)cdiv(C, 256)), dim3(256), 0, as_stream(stream), tok, W,
+                       bias, lvl_pos, x, nb, nrep, l, Cvae, C, x_rows, x_off);
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;
 }
