@@ -1080,12 +1080,21 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     }
     // stride-1 3x3 convs (plain or behind the nearest x2 upsample) over 32-channel multiples with 160-multiple outputs on 16-multiple images (every ResnetBlock conv of the VQVAE
     // decoder from 16x16 up): the LDS-halo kernel (conv_halo.hip).  tile_cfg 5 keeps them on the implicit-GEMM tiles, 6 forces the halo kernel at any grid size (A/B runs, tests).
-    if (d->conv && d->dtype == CVAR_BF16 && d->out_dtype == CVAR_BF16 && d->stride == 1 && d->batch == 1 && (d->tile_cfg == 0 || d->tile_cfg == 6) &&
-        d->Cin % 32 == 0 && d->N % 160 == 0 && d->Hout % 16 == 0 && d->Wout % 16 == 0 && d->act == CVAR_ACT_NONE && !d->gate && d->alpha == 1.0f &&
-        d->ldc == d->N && (!d->residual || (d->res_dtype == CVAR_BF16 && d->ldr == d->N && (((uintptr_t)d->residual & 7) == 0))) &&
-        (((uintptr_t)d->C & 7) == 0) && (!d->bias || (((uintptr_t)d->bias & 15) == 0)) && (long)d->Hin * d->Win * d->Cin * 2 < 0x7fffffffL &&
-        ((long)(d->M / 256) * (d->N / 160) >= 512 || d->tile_cfg == 6))   // two workgroups per CU or the implicit-GEMM tiles win (640->640 at 16x16); 6 forces it
-        return cvar_conv3x3_halo_bf16(d->A, d->W, d->bias, d->residual, d->C, d->M / (d->Hout * d->Wout), d->Hout, d->Wout, d->Cin, d->N, d->up, st);
+    if (d->conv && d->dtype == CVAR_BF16 && d->stride == 1 && d->batch == 1 && (d->tile_cfg == 0 || d->tile_cfg == 6) &&
+        d->Cin % 32 == 0 && d->Hout % 16 == 0 && d->Wout % 16 == 0 && d->act == CVAR_ACT_NONE && !d->gate && d->alpha == 1.0f &&
+        !d->pre_act && !d->aux && !d->gate_scale && d->remap_l == 0 && d->split_n == 0 && d->strideC == 0 && d->ldc == d->N &&
+        (!d->bias || (((uintptr_t)d->bias & 15) == 0)) && (long)d->Hin * d->Win * d->Cin * 2 < 0x7fffffffL) {
+        const long tiles = (long)(d->M / 256);
+        // wide form: Cout a multiple of 160, bf16 output, optional bf16 residual; two workgroups per CU or the implicit-GEMM tiles win (640->640 at 16x16)
+        const bool wide = d->N % 160 == 0 && d->out_dtype == CVAR_BF16 && (((uintptr_t)d->C & 7) == 0) &&
+                          (!d->residual || (d->res_dtype == CVAR_BF16 && d->ldr == d->N && (((uintptr_t)d->residual & 7) == 0))) &&
+                          (tiles * (d->N / 160) >= 512 || d->tile_cfg == 6);
+        // narrow form: Cout <= 32 (conv_out, 160 -> 3), bf16 or fp32 output, no residual - the implicit-GEMM tile spends its time re-fetching the input
+        const bool narrow = d->N <= 32 && !d->residual && (d->out_dtype == CVAR_BF16 || d->out_dtype == CVAR_F32) && (tiles >= 512 || d->tile_cfg == 6);
+        if (wide || narrow)
+            return cvar_conv3x3_halo_bf16(d->A, d->W, d->bias, d->residual, d->C, d->out_dtype == CVAR_F32, d->M / (d->Hout * d->Wout), d->Hout, d->Wout, d->Cin,
+                                          d->N, d->up, st);
+    }
     if (d->dtype == CVAR_BF16) return d->conv ? cvar_gemm_launch_conv_bf16(p, d->batch, st) : launch_typed<bf16_t>(p, d->batch, st);
     return cvar_gemm_launch_f32(p, d->batch, st);
 }

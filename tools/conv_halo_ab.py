@@ -43,6 +43,16 @@ for cfg in (0, 5):
     got = out.float().cpu().view(B, HW, HW, cout).permute(0, 3, 1, 2)
     print(f'cfg {cfg}: max |got - torch fp32| = {(got - ref).abs().max().item():.4f} (bf16 output rounding ~ {ref.abs().max().item() / 256:.4f})')
 
+# conv_out (160 -> 3, fp32 output): narrow form
+B, HW, cin, cout = 64, 256, 160, 3
+x = torch.randn(B * HW * HW, cin, device=dev).to(T); w = (torch.randn(cout, 9 * cin, device=dev) / (9 * cin) ** 0.5).to(T)
+bias = torch.randn(cout, device=dev)
+o0 = torch.empty(B * HW * HW, cout, device=dev, dtype=torch.float32); o5 = torch.empty_like(o0)
+run(x, w, bias, o0, None, B, HW, cin, cout, 0); run(x, w, bias, o5, None, B, HW, cin, cout, 5)
+t0 = timed(lambda: run(x, w, bias, o0, None, B, HW, cin, cout, 0)); t5 = timed(lambda: run(x, w, bias, o5, None, B, HW, cin, cout, 5))
+print(f' 160->   3 256^2 B=64 fp32 out (conv_out): halo {t0:7.3f} ms | implicit-GEMM {t5:7.3f} ms | x{t5 / t0:.3f} | max diff {(o0 - o5).abs().max().item():.2e}', flush=True)
+del x, w, o0, o5
+
 for (B, HW, cin, cout, res, up) in [(64, 256, 160, 160, 0, 0), (64, 256, 160, 160, 1, 0), (64, 128, 320, 320, 0, 0), (64, 128, 160, 160, 1, 0), (64, 128, 320, 160, 0, 0),
                                     (64, 64, 320, 320, 1, 0), (64, 32, 640, 640, 0, 0), (64, 16, 640, 640, 1, 0),
                                     (64, 256, 160, 160, 0, 1), (64, 128, 320, 320, 0, 1), (64, 64, 320, 320, 0, 1), (64, 32, 640, 640, 0, 1)]:
