@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, hi = lane >> 5;
-    int t_ = blockIdx.x;
+    int t_ = blockIdx.x;            // (an XCD-contiguous tile order, so that neighbouring tiles share one L2, measured neutral)
     const int tx = t_ % p.tiles_x; t_ /= p.tiles_x;
     const int ty = t_ % p.tiles_y;
     const int b = t_ / p.tiles_y;
