@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
 #pragma unroll
     for (int jj = 0; jj < 6; ++jj) issue_halo(0, jj);
     issue_w(0, 0);
-    if (p.nchunk > 0) issue_w(0, 1);
+    issue_w(0, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
