@@ -48,6 +48,21 @@ def test_interp_matrices_match_torch_fixture():
         assert np.abs(got.numpy() - g[f'bicubic_{p}']).max() < 5e-6
 
 
+def test_bicubic_matrices_between_consecutive_scales_match_torch():
+    """the low-resolution path resizes f_hat between consecutive scales (1->2, 2->3, ... 13->16, quant.py:176): the dense matrices of both
+    table builders (oracle and product host code) against F.interpolate(mode='bicubic') live"""
+    import torch.nn.functional as F
+    from controlvar_amd.pyramid import bicubic_matrix as product_matrix
+    g = torch.Generator().manual_seed(3)
+    for a, b in zip(PN[:-1], PN[1:]):
+        x = torch.randn(2, 3, a, a, generator=g, dtype=torch.float64)
+        want = F.interpolate(x, size=(b, b), mode='bicubic')
+        for build in (bicubic_matrix, product_matrix):
+            M = t(np.asarray(build(a, b), dtype=np.float64))
+            got = torch.einsum('ih,bchw,jw->bcij', M, x, M)
+            assert (got - want).abs().max() < 1e-10, (a, b)
+
+
 def test_phi_map():
     assert phi_index_map(10) == [0, 0, 1, 1, 1, 2, 2, 3, 3, 3]          # SURVEY A15, measured on the reference
 
