@@ -485,19 +485,22 @@ class VQVAE(nn.Module):
         idx, fh, _ = self._ms_encode(self._encode_f(x), want_fhat=True, v_patch_nums=v_patch_nums)
         if last_one:
             return self._decode(fh, lo=-3.0e38, hi=3.0e38)
-        if v_patch_nums is not None and tuple(self._scale_tables(v_patch_nums)[0]) != tuple(self.cfg.patch_nums):
-            raise NotImplementedError('per-scale reconstructions are built for the constructor scale list; pass last_one=True for another list')
-        return self._recon_all(idx)
+        return self._recon_all(idx, v_patch_nums)
 
-    def _recon_all(self, idx):
-        ms = self._split(idx)
+    def _recon_all(self, idx, v_patch_nums=None):
+        """decode f_hat after every scale (quant.py:184-215 with to_fhat=True) - for the constructor's scale list or a caller-chosen one"""
+        P = self._pack()
+        pns, up, down, phi_map = self._scale_tables(v_patch_nums) if v_patch_nums is not None else (self.cfg.patch_nums, P['up'], P['down'], P['phi_map'])
         B = idx.shape[0]
-        S = self.cfg.patch_nums[-1]
+        S = pns[-1]
         f_hat = torch.zeros(B, 1, self.Cvae, S, S, device=idx.device, dtype=torch.float32)
-        outs = []
-        for si in range(len(self.cfg.patch_nums)):
-            self._next_input(si, ms[si].contiguous(), f_hat, B, 1, False)
+        outs, o, tab = [], 0, 0
+        for si, pn in enumerate(pns):
+            ids = idx[:, o:o + pn * pn].contiguous()
+            ops.ms_next_input(ids, P['E'], P['phi_w'], P['phi_b'], up, down, f_hat, None, B, 1, pn, pn, S, self.Cvae, phi_map[si], tab, 0)
             outs.append(self._decode(f_hat[:, 0], lo=-3.0e38, hi=3.0e38))
+            o += pn * pn
+            tab += S * pn
         return outs
 
     def forward(self, *a, **k):

@@ -592,6 +592,10 @@ def case_tokenizer_alt():
             out[f'pns_{tag}'] = np.array(pns)
             out[f'ids_{tag}'] = torch.cat(ids, dim=1).to(torch.int16)
             out[f'rec_crop_{tag}'] = rec[:, :, 100:116, 60:76].clone()
+            recs = vae.img_to_recon(img, v_patch_nums=pns, last_one=False)          # one reconstruction per scale of the chosen list
+            assert len(recs) == len(pns) and torch.equal(recs[-1], rec)
+            out[f'recs_crop_{tag}'] = torch.stack([r[:, :, 100:116, 60:76] for r in recs])
+            out[f'recs_mean_{tag}'] = torch.stack([r.mean(dim=(2, 3)) for r in recs])
     save('tokenizer_alt', **out)
 
 

@@ -110,6 +110,11 @@ def test_tokenizer_with_caller_chosen_scale_lists(gpu_device):
         if not mism.any():
             rec = vae.img_to_recon(img, v_patch_nums=pns, last_one=True).cpu()
             assert (rec[:, :, 100:116, 60:76] - t(g[f'rec_crop_{tag}'])).abs().max() < 2e-3
+            recs = vae.img_to_recon(img, v_patch_nums=pns, last_one=False)                  # per-scale reconstructions of the chosen list
+            assert len(recs) == len(pns)
+            for si, r in enumerate(recs):
+                assert (r[:, :, 100:116, 60:76].cpu() - t(g[f'recs_crop_{tag}'][si])).abs().max() < 2e-3, (tag, si)
+                assert (r.mean(dim=(2, 3)).cpu() - t(g[f'recs_mean_{tag}'][si])).abs().max() < 3e-4, (tag, si)
     with pytest.raises(AssertionError):
         vae.img_to_idxBl(img, v_patch_nums=(1, 2, 4, 8))
     assert all(torch.equal(a, b) for a, b in zip(vae.img_to_idxBl(img, v_patch_nums=PN), vae.img_to_idxBl(img)))
