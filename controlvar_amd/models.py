@@ -1001,6 +1001,9 @@ class ControlVAR(nn.Module):
             self._decode_pair(self._generate_core(B, labels_all, types_all, 0, seed_dev, cfg, top_k, top_p, four_way))
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self._arena:                                     # the warm-up's K/V arena (arenas are per stream): the capture allocates its own
+            self._arena.pop(side.cuda_stream, None)         # in the graph's pool, and two of them do not fit at large batches
+            torch.cuda.empty_cache()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = self._decode_pair(self._generate_core(B, labels_all, types_all, 0, seed_dev, cfg, top_k, top_p, four_way))
