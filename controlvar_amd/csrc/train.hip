@@ -87,6 +87,33 @@ __global__ __launch_bounds__(256) void gated_grad_kernel(const float* __restrict
     }
     partial[((long)s * R + r) * C + c] = acc;
 }
+// four channels per thread (16-byte dx loads, 8-byte f / df accesses); per-channel summation order over the tokens is unchanged -> bit-identical
+__global__ __launch_bounds__(128) void gated_grad_vec_kernel(const float* __restrict__ dx, const bf16_t* __restrict__ f, const float* __restrict__ gate,
+                                                            long ldg, const float* __restrict__ rowscale, bf16_t* __restrict__ df,
+                                                            float* __restrict__ partial, int R, int l, int C) {
+    const int c = (blockIdx.x * 128 + threadIdx.x) * 4;
+    const int r = blockIdx.y, s = blockIdx.z;
+    if (c >= C) return;
+    const int seg = (l + RED_S - 1) / RED_S;
+    const int t0 = s * seg, t1 = min(l, t0 + seg);
+    const float rs = rowscale ? rowscale[r] : 1.0f;
+    const f32x4_t g4 = *(const f32x4_t*)(gate + (long)r * ldg + c);
+    float g[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) g[e] = g4[e] * rs;
+#pragma unroll 4
+    for (int t = t0; t < t1; ++t) {
+        const long i = ((long)r * l + t) * C + c;
+        const f32x4_t d = *(const f32x4_t*)(dx + i);
+        const bf16x4_t fq = *(const bf16x4_t*)(f + i);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[e] += d[e] * bf16_to_f32((bf16_t)fq[e]); o[e] = d[e] * g[e]; }
+        *(bf16x4_t*)(df + i) = pack_bf16x4(o);
+    }
+    const f32x4_t a4 = {acc[0], acc[1], acc[2], acc[3]};
+    *(f32x4_t*)(partial + ((long)s * R + r) * C + c) = a4;
+}
 // out[r*ldo + c] = scale_r * sum_s partial[s][r][c]
 __global__ void red_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, long ldo, const float* __restrict__ rowscale,
                                     int R, int C, int nseg) {
@@ -103,7 +130,11 @@ extern "C" int cvar_gated_grad(const float* dx, const void* f, int dtype, const 
                                void* df, float* dgate, int64_t ldo, int R, int l, int C, float* ws, void* stream) {
     if (!dx || !f || !gate || !df || !dgate || !ws || R <= 0 || l <= 0 || C <= 0) return CVAR_EINVAL;
     dim3 grid(cdiv(C, 256), R, RED_S), block(256);
-    if (dtype == CVAR_BF16) hipLaunchKernelGGL(gated_grad_kernel<bf16_t>, grid, block, 0, as_stream(stream), dx, (const bf16_t*)f, gate, (long)ldg, rowscale, (bf16_t*)df, ws, R, l, C);
+    const bool vec = dtype == CVAR_BF16 && C % 4 == 0 && ldg % 4 == 0 && ((((uintptr_t)dx | (uintptr_t)gate | (uintptr_t)ws) & 15) == 0) &&
+                     ((((uintptr_t)f | (uintptr_t)df) & 7) == 0);
+    if (vec) hipLaunchKernelGGL(gated_grad_vec_kernel, dim3(cdiv(C, 512), R, RED_S), dim3(128), 0, as_stream(stream), dx, (const bf16_t*)f, gate, (long)ldg, rowscale,
+                                (bf16_t*)df, ws, R, l, C);
+    else if (dtype == CVAR_BF16) hipLaunchKernelGGL(gated_grad_kernel<bf16_t>, grid, block, 0, as_stream(stream), dx, (const bf16_t*)f, gate, (long)ldg, rowscale, (bf16_t*)df, ws, R, l, C);
     else if (dtype == CVAR_F32) hipLaunchKernelGGL(gated_grad_kernel<float>, grid, block, 0, as_stream(stream), dx, (const float*)f, gate, (long)ldg, rowscale, (float*)df, ws, R, l, C);
     else return CVAR_EUNSUPPORTED;
     hipLaunchKernelGGL(red_finalize_kernel, dim3(cdiv(C, 256), R), block, 0, as_stream(stream), ws, dgate, (long)ldo, rowscale, R, C, RED_S);
@@ -243,6 +274,32 @@ __global__ __launch_bounds__(256) void ln_bwd_col_kernel(const float* __restrict
     partial[(((long)s * R + r) * 2 + 0) * C + c] = a;
     partial[(((long)s * R + r) * 2 + 1) * C + c] = b;
 }
+// four channels per thread; same per-channel order over the tokens -> bit-identical to ln_bwd_col_kernel
+__global__ __launch_bounds__(128) void ln_bwd_col_vec_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy, const float* __restrict__ stats,
+                                                            float* __restrict__ partial, int R, int l, int C) {
+    const int c = (blockIdx.x * 128 + threadIdx.x) * 4;
+    const int r = blockIdx.y, s = blockIdx.z;
+    if (c >= C) return;
+    const int seg = (l + RED_S - 1) / RED_S;
+    const int t0 = s * seg, t1 = min(l, t0 + seg);
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int t = t0; t < t1; ++t) {
+        const long m = (long)r * l + t;
+        const f32x4_t xv = *(const f32x4_t*)(x + m * C + c);
+        const bf16x4_t dq = *(const bf16x4_t*)(dy + m * C + c);
+        const float mu = stats[2 * m], rstd = stats[2 * m + 1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = bf16_to_f32((bf16_t)dq[e]);
+            a[e] += d * ((xv[e] - mu) * rstd);
+            b[e] += d;
+        }
+    }
+    const f32x4_t a4 = {a[0], a[1], a[2], a[3]}, b4 = {b[0], b[1], b[2], b[3]};
+    *(f32x4_t*)(partial + (((long)s * R + r) * 2 + 0) * C + c) = a4;
+    *(f32x4_t*)(partial + (((long)s * R + r) * 2 + 1) * C + c) = b4;
+}
 __global__ void ln_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dscale, float* __restrict__ dshift, long ldo, int R, int C) {
     const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
     if (c >= C) return;
@@ -264,7 +321,10 @@ extern "C" int cvar_ln_modulate_bwd(const float* x, const void* dy, int dtype, c
     if (dtype == CVAR_BF16) {
         if (!ln_bwd_row_vec_launch<bf16_t>(x, (const bf16_t*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps, as_stream(stream)))
             hipLaunchKernelGGL(ln_bwd_row_kernel<bf16_t>, dim3(cdiv(M, 4)), b256, 0, as_stream(stream), x, (const bf16_t*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps);
-        hipLaunchKernelGGL(ln_bwd_col_kernel<bf16_t>, dim3(cdiv(C, 256), R, RED_S), b256, 0, as_stream(stream), x, (const bf16_t*)dy, stats, partial, R, rows_per, C);
+        if (C % 4 == 0 && ((((uintptr_t)x | (uintptr_t)partial) & 15) == 0) && (((uintptr_t)dy & 7) == 0))
+            hipLaunchKernelGGL(ln_bwd_col_vec_kernel, dim3(cdiv(C, 512), R, RED_S), dim3(128), 0, as_stream(stream), x, (const bf16_t*)dy, stats, partial, R, rows_per, C);
+        else
+            hipLaunchKernelGGL(ln_bwd_col_kernel<bf16_t>, dim3(cdiv(C, 256), R, RED_S), b256, 0, as_stream(stream), x, (const bf16_t*)dy, stats, partial, R, rows_per, C);
     } else if (dtype == CVAR_F32) {
         if (!ln_bwd_row_vec_launch<float>(x, (const float*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps, as_stream(stream)))
             hipLaunchKernelGGL(ln_bwd_row_kernel<float>, dim3(cdiv(M, 4)), b256, 0, as_stream(stream), x, (const float*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps);
