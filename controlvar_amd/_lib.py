@@ -11,7 +11,7 @@ import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CVAR_LIB') or os.path.join(HERE, 'libcvar_hip.so')      # CVAR_LIB: A/B runs against another build
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 CVAR_F32, CVAR_BF16 = 0, 1
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_GRAD = 0, 1, 2
@@ -68,6 +68,7 @@ SIGNATURES = {
     'cvar_groupnorm_ws_bytes': (c_l, [c_i, c_i, c_i]),
     'cvar_groupnorm_silu': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p]),
     'cvar_softmax_rows': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    'cvar_gemm_tn': (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_p]),
     'cvar_embed_rows': (c_i, [c_p, c_p, c_i, c_p, c_l, c_i, c_p]),
     'cvar_resample_sep': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'cvar_transpose': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_l, c_l, c_p]),

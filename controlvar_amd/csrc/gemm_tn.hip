@@ -1,0 +1,217 @@
+// Weight-gradient GEMM on token-major operands:  C[n][k] = sum_t A[t][n] * B[t][k]   (dW = dY^T X, train_control_var_hpu.py:231 under autograd).
+//
+// Both operands have the contraction index t as their SLOW index (activations and their gradients are [tokens][channels]), which the MFMA
+// operand layout (8 consecutive contraction values per lane) cannot read from a row-major LDS tile with plain loads.  Round 1 transposed both
+// tensors in HBM first (6.7 % of a training step).  gfx950's `ds_read_b64_tr_b16` reads a [4 t][16 col] block and hands lane i column i:
+// two of them are one bf16x8 fragment, straight from the [t][col] image the DMA wrote.
+//   tile 128 (n) x 256 (k) per workgroup, 4 waves x (64 x 128), K step = 32 tokens, ring of three 24 KB stages -> two workgroups per CU;
+//   LDS rows are split in 64-byte segments XOR-swizzled by (t & 3): the four rows a transpose-read touches fall in four different bank groups;
+//   split over the tokens (grid.z) with fp32 partial tiles in a caller workspace, summed in a fixed order (bit-reproducible).
+#include "cvar_common.h"
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct GemmTnParams {
+    const bf16_t* A; const bf16_t* B; float* C;
+    long lda, ldb, ldc;          // elements
+    int T, Nn, Kk;               // tokens, rows of C (columns of A), columns of C (columns of B)
+    int tiles_k;                 // column tiles of C
+    int steps_per_split, nsteps; // K steps (32 tokens) per grid.z slice, total
+    long split_stride;           // elements between the partial outputs of consecutive slices (0: single slice writes C directly)
+};
+
+constexpr int TN_BM = 128, TN_BN = 256, TN_BK = 32;
+constexpr int TN_A_BYTES = TN_BK * TN_BM * 2;       // 8 KB: [32 t][256 B]
+constexpr int TN_B_BYTES = TN_BK * TN_BN * 2;       // 16 KB: [32 t][512 B]
+constexpr int TN_STAGE = TN_A_BYTES + TN_B_BYTES;
+
+// The transpose-read is issued as inline asm: through the builtin the compiler treats it as an LDS read that may alias the DMA writes and puts
+// an `s_waitcnt vmcnt(0)` in front of every group - which waits for the stage issued in this very step and throws the ring's depth away.
+// As asm the read is invisible to the wait-count pass, so the lgkmcnt waits are written by hand, tied to the fragment registers.
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+#define TN_TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+__device__ __forceinline__ bf16x8_t tn_pack(const v2i_t lo, const v2i_t hi) {
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    const v4i_t q = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8_t, q);
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmTnParams p) {
+    __shared__ __attribute__((aligned(1024))) char smem[3 * TN_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;                    // wave tile: rows 64 wm .. +64, columns 128 wn .. +128
+    const int tile = blockIdx.x;
+    const int tk = tile % p.tiles_k, tn = tile / p.tiles_k;
+    const int n0 = tn * TN_BM, k0 = tk * TN_BN;
+    const int step0 = blockIdx.z * p.steps_per_split;
+    const int nstep = min(p.steps_per_split, p.nsteps - step0);
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + n0), 0, (int)min((long)0x7fffffff, ((long)p.T * p.lda - n0) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + k0), 0, (int)min((long)0x7fffffff, ((long)p.T * p.ldb - k0) * 2), 0x00020000);
+
+    // DMA pieces (1 KiB = 64 lanes x 16 B, lane-linear in LDS).  A: piece q holds token rows 4q..4q+3 (256-B rows), B: rows 2q, 2q+1 (512-B rows).
+    // The lane fetches the LOGICAL chunk whose swizzled home is its physical slot: segment' = segment ^ (t & 3).
+    unsigned a_off[2], b_off[4];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int q = wave + 4 * jj;
+        const int t = 4 * q + (lane >> 4), pc = lane & 15;
+        const int lc = (((pc >> 2) ^ (t & 3)) << 2) | (pc & 3);
+        a_off[jj] = (unsigned)((t * p.lda + lc * 8) * 2);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int q = wave + 4 * jj;
+        const int t = 2 * q + (lane >> 5), pc = lane & 31;
+        const int lc = (((pc >> 2) ^ (t & 3)) << 2) | (pc & 3);
+        b_off[jj] = (unsigned)((t * p.ldb + lc * 8) * 2);
+    }
+    auto issue = [&](int step, int slot) {            // all six pieces of this wave for K step `step` (token rows 32 step ..)
+        char* sb = smem + slot * TN_STAGE;
+        const int sa = (int)((long)(step0 + step) * TN_BK * p.lda * 2), sbo = (int)((long)(step0 + step) * TN_BK * p.ldb * 2);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(sb + (wave + 4 * jj) * 1024), 16, (int)a_off[jj], sa, 0, 0);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rsrc, (lptr_t)(sb + TN_A_BYTES + (wave + 4 * jj) * 1024), 16, (int)b_off[jj], sbo, 0, 0);
+    };
+
+    // transpose-read addressing: lane l of a 16-lane group points at row (l & 15) >> 2 of the [4 t][16 col] block, columns 4 (l & 3) .. +3;
+    // groups 0 / 1 of a half-wave are the two 16-column halves of a 32-wide MFMA block, the upper half-wave is the k-group 8 tokens later.
+    const int l15 = lane & 15, g = (lane >> 4) & 1, hi = lane >> 5;
+    const int jrow = l15 >> 2, m = l15 & 3;
+    const int t_lane = 8 * hi + jrow;                                          // + 16 ks + 4 q
+    const int inseg = ((2 * g + (m >> 1)) << 4) + (m & 1) * 8;                 // byte offset inside the 64-B segment
+    // A: 4 segments per 256-B row, segment of block i of this wave = 2 wm + i;  B: 8 segments per 512-B row, segment = 4 wn + j
+    int a_lane[2], b_lane[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_lane[i] = t_lane * 256 + (((2 * wm + i) ^ jrow) << 6) + inseg;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b_lane[j] = TN_A_BYTES + t_lane * 512 + (((4 * wn + j) ^ jrow) << 6) + inseg;
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;        // LDS byte address of the ring
+
+    f32x16_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nstep > 0) issue(0, 0);
+    if (nstep > 1) issue(1, 1);
+    for (int s = 0; s < nstep; ++s) {
+        // stage s was issued two steps ago (or in the prologue): wait for everything but the newest six pieces, then publish
+        if (s + 1 < nstep) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 2 < nstep) issue(s + 2, (s + 2) % 3);
+        const unsigned st = lds0 + (unsigned)((s % 3) * TN_STAGE);
+        unsigned aa[2], ba[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) aa[i] = st + (unsigned)a_lane[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ba[j] = st + (unsigned)b_lane[j];
+        v2i_t ar[2][2][2], br[2][4][2];          // [ks][block][q]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (ks == 0) { TN_TR_READ(ar[0][i][0], aa[i], 0); TN_TR_READ(ar[0][i][1], aa[i], 4 * 256); }
+                else { TN_TR_READ(ar[1][i][0], aa[i], 16 * 256); TN_TR_READ(ar[1][i][1], aa[i], 20 * 256); }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (ks == 0) { TN_TR_READ(br[0][j][0], ba[j], 0); TN_TR_READ(br[0][j][1], ba[j], 4 * 512); }
+                else { TN_TR_READ(br[1][j][0], ba[j], 16 * 512); TN_TR_READ(br[1][j][1], ba[j], 20 * 512); }
+            }
+        }
+        // LDS returns in order: at most 12 outstanding = the ks = 0 set is back
+        asm volatile("s_waitcnt lgkmcnt(12)"
+                     : "+v"(ar[0][0][0]), "+v"(ar[0][0][1]), "+v"(ar[0][1][0]), "+v"(ar[0][1][1]), "+v"(br[0][0][0]), "+v"(br[0][0][1]), "+v"(br[0][1][0]),
+                       "+v"(br[0][1][1]), "+v"(br[0][2][0]), "+v"(br[0][2][1]), "+v"(br[0][3][0]), "+v"(br[0][3][1]));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tn_pack(ar[0][i][0], ar[0][i][1]), tn_pack(br[0][j][0], br[0][j][1]), acc[i][j], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ar[1][0][0]), "+v"(ar[1][0][1]), "+v"(ar[1][1][0]), "+v"(ar[1][1][1]), "+v"(br[1][0][0]), "+v"(br[1][0][1]), "+v"(br[1][1][0]),
+                       "+v"(br[1][1][1]), "+v"(br[1][2][0]), "+v"(br[1][2][1]), "+v"(br[1][3][0]), "+v"(br[1][3][1]));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tn_pack(ar[1][i][0], ar[1][i][1]), tn_pack(br[1][j][0], br[1][j][1]), acc[i][j], 0, 0, 0);
+    }
+
+    // D[n][k]: lane holds column k = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 hi of the 32x32 block -> 128-byte row segments per store
+    float* cbase = p.C + (long)blockIdx.z * p.split_stride;
+    const int lrow = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int k = k0 + 128 * wn + 32 * j + lrow;
+                cbase[(long)n * p.ldc + k] = acc[i][j][r];
+            }
+}
+
+// out[i] = sum_s part[s][i] in slice order (fixed -> bit-reproducible); row-major [Nn][Kk] partials -> C with leading dimension ldc
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, long ldc, int Nn, int Kk, int nsplit) {
+    const long nvec = (long)Nn * (Kk / 4);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const int n = (int)(i / (Kk / 4)), k = (int)(i % (Kk / 4)) * 4;
+        f32x4_t v = *(const f32x4_t*)(part + (long)n * Kk + k);
+        for (int s = 1; s < nsplit; ++s) {
+            const f32x4_t w = *(const f32x4_t*)(part + (long)s * Nn * Kk + (long)n * Kk + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += w[e];
+        }
+        *(f32x4_t*)(C + (long)n * ldc + k) = v;
+    }
+}
+
+/* C[Nn][Kk] (fp32, leading dimension ldc) = A^T B with A = [T][lda] (Nn columns used), B = [T][ldb] (Kk columns used), both bf16.
+ * Nn % 128 == 0, Kk % 256 == 0; lda, ldb multiples of 8 (any T: the last K step is zero-filled); ws: caller workspace for the token-split partials (may be NULL: one slice). */
+extern "C" int cvar_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int T, int Nn, int Kk,
+                            float* ws, int64_t ws_bytes, void* stream) {
+    if (!A || !B || !C || T <= 0 || Nn <= 0 || Kk <= 0) return CVAR_EINVAL;
+    if (Nn % TN_BM || Kk % TN_BN || lda % 8 || ldb % 8 || ldc % 4 || lda < Nn || ldb < Kk || ldc < Kk) return CVAR_EUNSUPPORTED;
+    if ((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) || (long)T * lda * 2 >= 0x7fffffffL || (long)T * ldb * 2 >= 0x7fffffffL) return CVAR_EUNSUPPORTED;
+    GemmTnParams p;
+    p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.T = T; p.Nn = Nn; p.Kk = Kk;
+    p.tiles_k = Kk / TN_BN;
+    p.nsteps = (T + TN_BK - 1) / TN_BK;          // token rows past T lie outside the buffer resources: the DMA writes zeros for them
+    const int tiles = (Nn / TN_BM) * p.tiles_k;
+    // slices over the tokens: fill whole rounds of the 512 workgroup slots (two per CU), at least 24 K steps per slice, workspace permitting
+    int best = 1;
+    if (ws && (((uintptr_t)ws & 15) == 0)) {
+        double best_cost = 1e30;
+        for (int sp = 1; sp <= 16; ++sp) {
+            if (p.nsteps / sp < 24 && sp > 1) break;
+            if (sp > 1 && (size_t)sp * Nn * Kk * sizeof(float) > (size_t)ws_bytes) break;
+            const double cost = (double)((tiles * sp + 511) / 512) / sp + 0.004 * sp;       // rounds per slice + a price for the partial traffic
+            if (cost < best_cost) { best_cost = cost; best = sp; }
+        }
+    }
+    p.steps_per_split = (p.nsteps + best - 1) / best;
+    const int nsplit = (p.nsteps + p.steps_per_split - 1) / p.steps_per_split;
+    hipStream_t st = as_stream(stream);
+    if (nsplit == 1) {
+        p.C = C; p.split_stride = 0;
+        hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(tiles, 1, 1), dim3(256), 0, st, p);
+    } else {
+        p.C = ws; p.ldc = Kk; p.split_stride = (long)Nn * Kk;
+        hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(tiles, 1, nsplit), dim3(256), 0, st, p);
+        const long nvec = (long)Nn * (Kk / 4);
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)min((long)2048, (nvec + 255) / 256)), dim3(256), 0, st, ws, C, (long)ldc, Nn, Kk, nsplit);
+    }
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}

@@ -119,6 +119,16 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
     return out
 
 
+def gemm_tn(A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, T: int, Nn: int, Kk: int, lda: int = 0, ldb: int = 0, ldc: int = 0, c_off: int = 0):
+    """out[n, k] (fp32) = sum_t A[t, n] * B[t, k] - the weight gradient dW = dY^T X on token-major bf16 operands (cvar_gemm_tn)"""
+    ws = _SPLITK_WS.get((A.device.index, _stream()))
+    if ws is None:
+        ws = ensure_splitk_workspace(A.device)
+    check(_lib.load().cvar_gemm_tn(_ptr(A), lda or Nn, _ptr(B), ldb or Kk, _ptr(out) + 4 * c_off, ldc or Kk, T, Nn, Kk, ws.data_ptr(), ws.numel(), _stream()),
+          'cvar_gemm_tn')
+    return out
+
+
 def ln_modulate(x: torch.Tensor, ada: torch.Tensor, scale_off: int, shift_off: int, ld_ada: int, rows_per: int,
                 out: torch.Tensor, M: int, Cdim: int, eps: float):
     base = _ptr(ada)

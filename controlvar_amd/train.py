@@ -363,6 +363,23 @@ class TrainEngine:
         return self.logits
 
     @torch.no_grad()
+    def _wgrad(self, dY, n_out: int, X, k_in: int, G, w_off: int, b_off=None):
+        """dW[n_out, k_in] = dY^T X into the fp32 gradient slab (+ the bias gradient = column sums of dY).  bf16 mode: `cvar_gemm_tn` reads both
+        token-major operands in place (LDS transpose-read) - no transposed copies; shapes it does not take (a dimension that is not a
+        multiple of its tile, the fp32 parity mode) go through two HBM transposes + `cvar_gemm` as in round 1."""
+        M, Mp = self.M, self.Mp
+        if (dY.dtype == torch.bfloat16 and X.dtype == torch.bfloat16 and n_out % 128 == 0 and k_in % 256 == 0
+                and 2 * M * max(n_out, k_in) < 2 ** 31 - 1):
+            ops.gemm_tn(dY, X, G, T=M, Nn=n_out, Kk=k_in, c_off=w_off)
+            if b_off is not None:
+                ops.colsum(dY, n_out, G, M, n_out, self.ws, out_off=b_off)
+            return
+        ops.transpose(dY, self.TA, 1, M, n_out, n_out, ld_out=Mp)
+        ops.transpose(X, self.TB, 1, M, k_in, k_in, ld_out=Mp)
+        ops.gemm(self.TA, self.TB, G, M=n_out, N=k_in, K=Mp, c_off=w_off)
+        if b_off is not None:
+            ops.rowsum(self.TA, Mp, G, n_out, M, out_off=b_off)
+
     def backward(self):
         """backward from self.dlogits (compute dtype, (B*L, V)) through head, blocks, adaLN generator and embeddings"""
         cfg, var = self.cfg, self.var
@@ -386,10 +403,7 @@ class TrainEngine:
         mo = self.misc_off
         self.dada.zero_()
         ops.gemm(self.dlogits, self.WT['head'], self.DU, M=M, N=C, K=V)
-        ops.transpose(self.dlogits, TA, 1, M, V, V, ld_out=Mp)
-        ops.transpose(self.UH, TB, 1, M, C, C, ld_out=Mp)
-        ops.gemm(TA, TB, self.G_misc, M=V, N=C, K=Mp, c_off=mo['w_head'][0])
-        ops.rowsum(TA, Mp, self.G_misc, V, M, out_off=mo['b_head'][0])
+        self._wgrad(self.dlogits, V, self.UH, C, self.G_misc, mo['w_head'][0], mo['b_head'][0])
         ops.ln_modulate_bwd(self.Xs[depth], self.DU, ada, ah, n_ada, L, None, self.dX, self.dada, ah, ah + C, n_ada, M, C, eps, ws)
         # ---- backward: blocks
         for i in reversed(range(depth)):
@@ -399,32 +413,20 @@ class TrainEngine:
             # FFN branch
             ops.gated_grad(self.dX, self.F2[i], ada, a0 + C, n_ada, dp2[i].contiguous() if dp2 is not None else None, self.DF, self.dada, a0 + C, n_ada, B, L, C, ws)
             ops.gemm(self.DF, self.WT['fc2'], self.DH, M=M, N=hid, K=C, w_off=i * hid * C, act=ACT_GELU_GRAD, aux=self.A[i])   # dH = (dF W2) * gelu'(A)
-            ops.transpose(self.DF, TA, 1, M, C, C, ld_out=Mp)
-            ops.transpose(self.Hh[i], TB, 1, M, hid, hid, ld_out=Mp)
-            ops.gemm(TA, TB, G, M=C, N=hid, K=Mp, c_off=go + so['w_fc2'])
-            ops.rowsum(TA, Mp, G, C, M, out_off=go + so['b_fc2'])
+            self._wgrad(self.DF, C, self.Hh[i], hid, G, go + so['w_fc2'], go + so['b_fc2'])
             ops.gemm(self.DH, self.WT['fc1'], self.DU, M=M, N=C, K=hid, w_off=i * C * hid)
-            ops.transpose(self.DH, TA, 1, M, hid, hid, ld_out=Mp)
-            ops.transpose(self.U2[i], TB, 1, M, C, C, ld_out=Mp)
-            ops.gemm(TA, TB, G, M=hid, N=C, K=Mp, c_off=go + so['w_fc1'])
-            ops.rowsum(TA, Mp, G, hid, M, out_off=go + so['b_fc1'])
+            self._wgrad(self.DH, hid, self.U2[i], C, G, go + so['w_fc1'], go + so['b_fc1'])
             ops.ln_modulate_bwd(self.X1s[i], self.DU, ada, a0 + 3 * C, n_ada, L, self.dX, self.dX, self.dada, a0 + 3 * C, a0 + 5 * C, n_ada, M, C, eps, ws)
             # attention branch
             ops.gated_grad(self.dX, self.F1[i], ada, a0, n_ada, dp1[i].contiguous() if dp1 is not None else None, self.DF, self.dada, a0, n_ada, B, L, C, ws)
             ops.gemm(self.DF, self.WT['proj'], self.DU, M=M, N=C, K=C, w_off=i * C * C)
-            ops.transpose(self.DF, TA, 1, M, C, C, ld_out=Mp)
-            ops.transpose(self.O[i], TB, 1, M, C, C, ld_out=Mp)
-            ops.gemm(TA, TB, G, M=C, N=C, K=Mp, c_off=go + so['w_proj'])
-            ops.rowsum(TA, Mp, G, C, M, out_off=go + so['b_proj'])
+            self._wgrad(self.DF, C, self.O[i], C, G, go + so['w_proj'], go + so['b_proj'])
             ops.attention_bwd(self.arena[i], self.O[i], self.DU, self.LSE[i], self.DQKV, ws, B, H, L, L, scale, lvl_end, holes=holes)
             if cfg.uses_cos_attn:           # normalisation + learned temperature of basic_var.py:99-104
                 ops.cos_qk_norm_bwd(self.arena[i], self.DQKV, B, H, L, L, P['scale_mul'], self.NORMS[i], self.DSM, sm_off=i * H)
                 ops.colsum(self.DSM, H, G, M, H, ws, out_off=go + so['scale_mul'])
             ops.gemm(self.DQKV, self.WT['qkv'], self.DU, M=M, N=C, K=3 * C, w_off=i * C * 3 * C)
-            ops.transpose(self.DQKV, TA, 1, M, 3 * C, 3 * C, ld_out=Mp)
-            ops.transpose(self.U[i], TB, 1, M, C, C, ld_out=Mp)
-            ops.gemm(TA, TB, G, M=3 * C, N=C, K=Mp, c_off=go + so['w_qkv'])
-            ops.rowsum(TA, Mp, G, 3 * C, M, out_off=go + so['b_qkv'])      # the k-bias third is unused (zero_k_bias is a buffer)
+            self._wgrad(self.DQKV, 3 * C, self.U[i], C, G, go + so['w_qkv'], go + so['b_qkv'])      # the k-bias third is unused (zero_k_bias is a buffer)
             ops.ln_modulate_bwd(self.Xs[i], self.DU, ada, a0 + 2 * C, n_ada, L, self.dX, self.dX, self.dada, a0 + 2 * C, a0 + 4 * C, n_ada, M, C, eps, ws)
             if self.reducer is not None:
                 self.reducer.ready(i)

@@ -243,3 +243,49 @@ def test_gemm_fused_gelu_forward_keeps_preactivation_and_gelu_grad_epilogue(gpu_
     assert close(x1, x + g_rows * pre_ref, F32 if dtype == F32 else BF16)
     with pytest.raises(Exception):
         ops.gemm(ad, wd, x1, M=M, N=N, K=K, gate_scale=keep.to(gpu_device))   # gate_scale without a gate -> CVAR_EINVAL
+
+
+@pytest.mark.parametrize('T,Nn,Kk,lda,ldb', [(96, 128, 256, 128, 256),            # three whole K steps, one tile
+                                            (1360, 384, 512, 384, 512),           # several tiles, token split through the workspace
+                                            (1000, 256, 256, 640, 768),           # T % 32 != 0 (zero-filled tail step), operands are column windows
+                                            (50, 128, 256, 128, 256),             # fewer tokens than two K steps
+                                            (43520, 1536, 1536, 1536, 1536)])     # the d24 proj weight gradient at B = 32
+def test_gemm_tn_weight_gradient(gpu_device, T, Nn, Kk, lda, ldb):
+    """cvar_gemm_tn: dW[n, k] = sum_t dY[t, n] X[t, k] read token-major (LDS transpose-read, no transposed copies) against torch on the
+    bf16-rounded operands.  The operands sit inside NaN-filled buffers and, where lda > Nn, inside wider NaN rows: every element outside
+    the (T x Nn) / (T x Kk) windows that reached an accumulator would poison the result."""
+    g = torch.Generator().manual_seed(T + Nn)
+    A = torch.randn(T, Nn, generator=g).to(torch.bfloat16)
+    B = torch.randn(T, Kk, generator=g).to(torch.bfloat16)
+    pad = 4096
+
+    def fenced(t, ld):
+        rows = torch.full((T, ld), float('nan'), dtype=torch.bfloat16)
+        rows[:, :t.shape[1]] = t
+        buf = torch.full((T * ld + 2 * pad,), float('nan'), dtype=torch.bfloat16, device=gpu_device)
+        v = buf[pad:pad + T * ld].view(T, ld)
+        v.copy_(rows)
+        return v
+    Ad, Bd = fenced(A, lda), fenced(B, ldb)
+    out = torch.full((Nn + 2, Kk + 8), float('nan'), device=gpu_device)
+    ops.gemm_tn(Ad, Bd, out, T=T, Nn=Nn, Kk=Kk, lda=lda, ldb=ldb, ldc=Kk + 8)
+    got = out[:Nn, :Kk].cpu()
+    assert torch.isnan(out[Nn:]).all() and torch.isnan(out[:, Kk:]).all()            # nothing written outside the result window
+    if T <= 2000:
+        ref = A.double().t() @ B.double()
+        assert torch.isfinite(got).all()
+        assert ((got.double() - ref).abs() <= 1e-4 * (ref.abs() + math.sqrt(T))).all(), (got.double() - ref).abs().max().item()
+    else:                                                                            # full size: against the round-1 path (two transposes + cvar_gemm)
+        TA = torch.zeros(Nn, T, device=gpu_device, dtype=torch.bfloat16); TB = torch.zeros(Kk, T, device=gpu_device, dtype=torch.bfloat16)
+        ops.transpose(Ad, TA, 1, T, Nn, lda, ld_out=T); ops.transpose(Bd, TB, 1, T, Kk, ldb, ld_out=T)
+        old = torch.empty(Nn, Kk, device=gpu_device)
+        ops.gemm(TA, TB, old, M=Nn, N=Kk, K=T)
+        assert torch.isfinite(got).all()
+        assert ((got - old.cpu()).abs() <= 2e-5 * (old.cpu().abs() + math.sqrt(T))).all()
+    # run-to-run bit-reproducible (the token split is summed in a fixed order)
+    out2 = torch.empty_like(out)
+    ops.gemm_tn(Ad, Bd, out2, T=T, Nn=Nn, Kk=Kk, lda=lda, ldb=ldb, ldc=Kk + 8)
+    assert torch.equal(out2[:Nn, :Kk].cpu(), got)
+    from controlvar_amd._lib import CvarError
+    with pytest.raises(CvarError):
+        ops.gemm_tn(Ad, Bd, out, T=T, Nn=Nn - 64, Kk=Kk, lda=lda, ldb=ldb, ldc=Kk + 8)      # Nn must be a multiple of the 128-row tile
