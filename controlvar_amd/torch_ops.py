@@ -94,15 +94,19 @@ def _linear_grads(x, weight, dy, want_bias):
     K.transpose(weight.contiguous(), wt, 1, N, Kd, Kd)
     dx = torch.empty(M, Kd, device=dev, dtype=T)
     K.gemm(dy2, wt, dx, M=M, N=Kd, K=N)
+    dw = torch.empty(N, Kd, device=dev, dtype=torch.float32)
+    db = torch.empty(N, device=dev, dtype=torch.float32) if want_bias else None
+    if T == torch.bfloat16 and N % 128 == 0 and Kd % 256 == 0 and 2 * M * max(N, Kd) < 2 ** 31 - 1:
+        K.gemm_tn(dy2, x2, dw, T=M, Nn=N, Kk=Kd)                       # token-major operands read in place (cvar_gemm_tn): no transposed copies
+        if want_bias:
+            K.colsum(dy2, N, db, M, N, torch.empty(64 * N + 16, device=dev, dtype=torch.float32))
+        return dx.view_as(x), dw, db
     ta = torch.zeros(N, Mp, device=dev, dtype=T)
     tb = torch.zeros(Kd, Mp, device=dev, dtype=T)
     K.transpose(dy2, ta, 1, M, N, N, ld_out=Mp)
     K.transpose(x2, tb, 1, M, Kd, Kd, ld_out=Mp)
-    dw = torch.empty(N, Kd, device=dev, dtype=torch.float32)
     K.gemm(ta, tb, dw, M=N, N=Kd, K=Mp)
-    db = None
     if want_bias:
-        db = torch.empty(N, device=dev, dtype=torch.float32)
         K.rowsum(ta, Mp, db, N, M)
     return dx.view_as(x), dw, db
 
