@@ -23,7 +23,27 @@ def arena(t, dtype):
     return v
 
 
+def one_tn(case):
+    """cvar_gemm_tn: dW = A^T B on token-major operands (column windows of wider NaN rows), any token count"""
+    g = torch.Generator().manual_seed(case)
+    T = rng.choice([1, 31, 32, 33, 200, 777, 1360, 2999])
+    Nn, Kk = rng.choice([128, 256, 384]), rng.choice([256, 512])
+    lda, ldb = Nn + rng.choice([0, 8, 128]), Kk + rng.choice([0, 16, 256])
+    a = torch.randn(T, Nn, generator=g); b = torch.randn(T, Kk, generator=g)
+    Aw = torch.full((T, lda), float('nan')); Aw[:, :Nn] = a
+    Bw = torch.full((T, ldb), float('nan')); Bw[:, :Kk] = b
+    A, B = arena(Aw, torch.bfloat16), arena(Bw, torch.bfloat16)
+    out = arena(torch.zeros(Nn, Kk), torch.float32)
+    ops.gemm_tn(A, B, out, T=T, Nn=Nn, Kk=Kk, lda=lda, ldb=ldb)
+    ref = a.to(torch.bfloat16).double().t() @ b.to(torch.bfloat16).double()
+    got = out.double().cpu()
+    err = ((got - ref).abs() / (ref.abs() + math.sqrt(T))).max().item() if torch.isfinite(got).all() else float('nan')
+    return err == err and err < 1e-4, f'gemm_tn T={T} {Nn}x{Kk} lda={lda} ldb={ldb}: err {err:.3e}'
+
+
 def one(case):
+    if rng.random() < 0.1:
+        return one_tn(case)
     dtype = torch.bfloat16 if rng.random() < 0.8 else torch.float32
     g = torch.Generator().manual_seed(case)
     conv = rng.random() < 0.4
