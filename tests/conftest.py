@@ -30,3 +30,41 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     return torch.device('cuda:0')
+
+
+# ------------------------------------------------------------------------------------------------ integer-parity bookkeeping
+PARITY_REPORT = os.environ.get('CVAR_PARITY_REPORT', os.path.join(ROOT, 'gpurun_out', 'parity_report.jsonl'))
+
+
+def record(what, **vals):
+    """append one measured parity record (flip counts, logit distances) to the JSON-lines report tools/parity_report.py summarises into
+    profiles/rNN_parity_report.json; never fails a test"""
+    import json
+    try:
+        os.makedirs(os.path.dirname(PARITY_REPORT), exist_ok=True)
+        with open(PARITY_REPORT, 'a') as f:
+            f.write(json.dumps(dict(what=what, **vals)) + '\n')
+    except OSError:
+        pass
+
+
+def ids_parity(got, ref, margin, tol, what, strict=True):
+    """Integer parity of ids (VQ ids, greedy tokens, argmax of logits) against a reference-recorded fixture.
+
+    strict=True  (every fp32-mode fixture): the ids must be IDENTICAL - zero flips.
+    strict=False (bf16 mode, random-feature sweeps): a flip is tolerated only where the reference's own top-1/top-2 margin is < tol.
+    The flip count is printed and recorded either way.  Returns (flips, rows_ok) - rows_ok[b] is True for every batch row without a
+    flip, so float / image checks always run on those rows (nothing is skipped behind `if flips == 0`)."""
+    got, ref = np.asarray(got).astype(np.int64), np.asarray(ref).astype(np.int64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    mism = got != ref
+    n = int(mism.sum())
+    worst = float(np.asarray(margin)[mism].max()) if n else 0.0
+    rows_ok = ~mism.reshape(mism.shape[0], -1).any(axis=1)
+    print(f'[parity] {what}: {n} of {mism.size} ids differ from the reference' + (f' (largest reference margin at a flip {worst:.3e})' if n else ''))
+    record(what, kind='ids', flips=n, total=int(mism.size), worst_margin_at_flip=worst, strict=bool(strict), tol=float(tol))
+    if strict:
+        assert n == 0, f'{what}: {n} of {mism.size} ids differ (strict); largest reference margin at a flip {worst:.3e}'
+    elif n:
+        assert worst < tol, f'{what}: {n} id mismatches, largest reference margin at a mismatch {worst:.3e} >= {tol:.3e}'
+    return n, rows_ok

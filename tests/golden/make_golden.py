@@ -556,6 +556,118 @@ def case_generate_d12_bf16emu():
          absmax_per_scale=torch.stack([t.abs().amax() for t in trace['logits']]), labels=labels, types=types)
 
 
+class ReplayIdx(CaptureIdx):
+    """CaptureIdx that makes the reference CONTINUE from recorded ids: the sampler's result is replaced by `forced[stage]`, the logits of
+    every stage are still recorded.  Lets the fp32 reference be walked along the trace its bf16-autocast run produced."""
+
+    def __init__(self, module, forced):
+        super().__init__(module)
+        self.forced = forced
+
+    def __enter__(self):
+        def wrapped(logits, *a, **k):
+            lg = logits.detach().clone().float()
+            t2 = lg.topk(2, dim=-1).values
+            self.margins.append((t2[..., 0] - t2[..., 1]).clone())
+            self.logit_samples.append(lg.clone())
+            out = self.forced[len(self.idx)].clone().unsqueeze(-1)
+            self.idx.append(out[:, :, 0].clone())
+            return out
+        self.module.sample_with_top_k_top_p_ = wrapped
+        return self
+
+
+def _dist(a, b):
+    d = (a.double() - b.double())
+    return [float(d.abs().max()), float(d.pow(2).mean().sqrt())]
+
+
+def case_forward_d12_bf16ref():
+    """north_star: "within 1e-3 on bf16 logits".  The reference's OWN bf16 behaviour, recorded: teacher-forced logits of the d12-width
+    model (inputs of forward_d12.npz) from the reference in fp32, from the reference under torch.autocast('cpu', torch.bfloat16)
+    (control_var.py:568-651 runs there; only the tokenizer ENCODE fails under CPU autocast, quant.py:205-206, and it is not on this
+    call), and from the oracle with bf16 storage points.  Stored: the [::9, ::31] sample of each and the full-tensor max / RMS distances
+    between them, so that the GPU test can place the HIP bf16 path among them."""
+    from oracle import var_ref
+    from oracle.vqvae_ref import Prec
+    vae = make_vae(32)
+    cfg = VarConfig(depth=12)
+    m = make_cvar(vae, cfg)
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, cfg.pyramid.L - cfg.pyramid.first_l, 32, generator=g)
+    labels, types = torch.tensor([12, 800]), torch.tensor([3, 1])
+    with torch.no_grad():
+        l32 = m(labels, x, types, True).float()
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            lac = m(labels, x, types, True).float()
+        lemu = var_ref.forward_logits(synth_var_state(cfg), cfg, labels, x, types, prec=Prec(True))
+    S = (slice(None), slice(None, None, 9), slice(None, None, 31))
+    t2 = lac.topk(2, dim=-1).values
+    print(f'  max|logit| {float(l32.abs().max()):.3f}; autocast-fp32 {_dist(lac, l32)}, emu-fp32 {_dist(lemu, l32)}, emu-autocast {_dist(lemu, lac)}')
+    save('forward_d12_bf16ref', labels=labels, types=types, absmax=l32.abs().amax(), ref_fp32=l32[S].contiguous(), ref_autocast=lac[S].contiguous(),
+         emu=lemu[S].contiguous(), d_autocast_fp32=_dist(lac, l32), d_emu_fp32=_dist(lemu, l32), d_emu_autocast=_dist(lemu, lac),
+         argmax_autocast=lac.argmax(-1).to(torch.int16), margin_autocast=(t2[..., 0] - t2[..., 1]),
+         argmax_agree_autocast_fp32=float((lac.argmax(-1) == l32.argmax(-1)).float().mean()),
+         argmax_agree_emu_fp32=float((lemu.argmax(-1) == l32.argmax(-1)).float().mean()))
+
+
+def case_generate_d12_bf16ref():
+    """BASELINE config 2 pinned to the reference's bf16: d12 + full VQVAE, B=8 (labels arange(8), types arange(8) % 4), greedy, cfg 4,
+    autoregressive_infer_cfg (control_var.py:356-565) under torch.autocast('cpu', torch.bfloat16): per-stage ids and CFG-combined logits.
+    Then the fp32 reference and the bf16-emulating oracle are walked along THOSE ids (sampler replaced by the recorded ids), so the three
+    logit sets belong to the same token path.  Stored per stage: ids, margins and the [rows 0..3, :, 5::128] logit sample of all three, and
+    the full-tensor max / RMS distances per scale."""
+    from oracle import var_ref
+    from oracle.vqvae_ref import MSQuant, Prec
+    from controlvar_amd.spec import phi_index_map
+    vae = make_vae(160)
+    cfg = VarConfig(depth=12)
+    m = make_cvar(vae, cfg)
+    B = 8
+    labels, types = torch.arange(B) % 1000, torch.arange(B) % 4
+    kw = dict(B=B, label_B=labels, g_seed=0, cfg=4.0, top_k=1, top_p=0.0, cond_type=types)
+    t0 = time.time()
+    full = {}
+
+    class Cap(CaptureIdx):
+        def __enter__(s2):
+            def wrapped(logits, *a, **k):
+                lg = logits.detach().clone().float()
+                t2 = lg.topk(2, dim=-1).values
+                s2.margins.append((t2[..., 0] - t2[..., 1]).clone())
+                s2.logit_samples.append(lg.clone())
+                out = s2.orig(logits, *a, **k)
+                s2.idx.append(out[:, :, 0].clone())
+                return out
+            s2.module.sample_with_top_k_top_p_ = wrapped
+            return s2
+
+    with Cap(ref_cv) as cap, torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16):
+        img = m.autoregressive_infer_cfg(**kw)
+    print(f'  reference d12 B={B} autocast(bf16) generate {time.time() - t0:.1f}s')
+    ids = [i.clone() for i in cap.idx]
+    t0 = time.time()
+    with ReplayIdx(ref_cv, ids) as rep, torch.no_grad():
+        m.autoregressive_infer_cfg(**kw)
+    print(f'  reference fp32 along the same ids {time.time() - t0:.1f}s')
+    sdv, sd = synth_vae_state(VaeConfig(ch=160)), synth_var_state(cfg)
+    trace = {}
+    with torch.no_grad():
+        var_ref.generate(sd, cfg, MSQuant(sdv, PN, phi_index_map(10)), B, labels, 4.0, top_k=1, cond_type=types, prec=Prec(True), trace=trace, force_idx=ids)
+    lac, l32, lemu = cap.logit_samples, rep.logit_samples, trace['logits']
+    d_ac32 = [_dist(a, b) for a, b in zip(lac, l32)]
+    d_emu32 = [_dist(a, b) for a, b in zip(lemu, l32)]
+    d_emuac = [_dist(a, b) for a, b in zip(lemu, lac)]
+    amax = torch.stack([t.abs().amax() for t in l32])
+    for si in range(len(PN)):
+        print(f'   scale {si}: max|logit| {float(amax[si]):.2f}  autocast-fp32 {d_ac32[si][0]:.3e}/{d_ac32[si][1]:.3e}  emu-fp32 {d_emu32[si][0]:.3e}/{d_emu32[si][1]:.3e}  emu-autocast {d_emuac[si][0]:.3e}/{d_emuac[si][1]:.3e}')
+    samp = lambda L: torch.cat([t[:4, :, 5::128] for t in L], dim=1).contiguous()
+    st = img_stats(img.float())
+    save('gen_d12_bf16ref', ids=torch.cat(ids, dim=1).to(torch.int16), margin_autocast=torch.cat(cap.margins, dim=1), margin_fp32=torch.cat(rep.margins, dim=1),
+         ref_autocast=samp(lac), ref_fp32=samp(l32), emu=samp(lemu), absmax_per_scale=amax, d_autocast_fp32=d_ac32, d_emu_fp32=d_emu32, d_emu_autocast=d_emuac,
+         labels=labels, types=types, img_mean=st['mean'], img_std=st['std'], img_crop=st['crop'])
+
+
 def case_generate_d30():
     """BASELINE config 4: d30 (cos-attention, C=1920, 30 heads) at FULL width with the full VQVAE, B=4, cond_type=None -> the four
     condition types [0,1,2,3] (control_var.py:387-389), cfg 4, greedy; and conditional_infer_cfg with cfg=(4,4,4) (the script
@@ -715,6 +827,8 @@ CASES = {
     'train_separate_decoding': lambda: case_train_step(VarConfig(depth=2, separate_decoding=True, indep=True), 'd2si', 12),
     'fwd_d12': case_forward_d12,
     'gen_d12_bf16emu': case_generate_d12_bf16emu,
+    'fwd_d12_bf16ref': case_forward_d12_bf16ref,
+    'gen_d12_bf16ref': case_generate_d12_bf16ref,
     'gen_d30': case_generate_d30,
     'train_d24': case_train_step_d24,
 }

@@ -6,18 +6,19 @@ completed by size-independent properties where the oracle cannot follow (B = 64,
   config 3  d24 training step (tokenise -> forward -> CE -> backward -> clip -> AdamW), fp32 against the reference, bf16 properties
   config 4  d30 (cos-attention) at FULL width, B=4 / cond_type=None (all four condition types), and conditional_infer_cfg cfg=(4,4,4)
 
-bf16 bound.  north_star asks for "within 1e-3 on bf16 logits".  The HIP bf16 path and the oracle round at the same storage points
-(weights, GEMM inputs, attention probabilities), so the remaining difference is accumulation order plus the few places where one
-bf16 rounding lands on the other side of a tie and then propagates through 12 blocks.  The number below is MEASURED on the d12
-model (printed by the test on every run) relative to max|logit| of the scale; the assertion is 2x the value measured when the
-test was written - see BF16_REL_BOUND."""
+bf16 bound.  north_star asks for "within 1e-3 on bf16 logits".  Round 3 pins the mode to the REFERENCE's own bf16: the reference runs
+under torch.autocast('cpu', bfloat16) in the build container, and its logits differ from its own fp32 logits by 9.7e-3 (max) / 1.8e-3
+(RMS) of max|logit| at d12 - no bf16 pipeline, the reference's included, is within 1e-3 of fp32 in the max norm.  The tests
+`*_among_the_references_bf16` / `*_along_the_references_bf16_trace` therefore assert that the HIP path is no farther from the reference's fp32
+logits than the reference's autocast is (max and RMS), and within 1e-3 RMS of the oracle's bf16 emulation; the older test below keeps the
+max-norm number against the emulation (2x the measured value, BF16_REL_BOUND)."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
-from conftest import golden  # noqa: E402
+from conftest import golden, ids_parity, record  # noqa: E402
 from controlvar_amd import models  # noqa: E402
 from controlvar_amd import train as T  # noqa: E402
 from controlvar_amd.spec import DEFAULT_PATCH_NUMS as PN, VarConfig  # noqa: E402
@@ -47,13 +48,7 @@ def build(depth, dtype, dev, ch=160):
     return vae, m
 
 
-def check_ids(got, ref, margin, tol, what):
-    got, ref, margin = np.asarray(got).astype(np.int64), np.asarray(ref).astype(np.int64), np.asarray(margin)
-    mism = got != ref
-    if mism.any():
-        worst = float(margin[mism].max())
-        assert worst < tol, f'{what}: {int(mism.sum())} id mismatches, largest oracle margin at a mismatch {worst:.3e} >= {tol:.3e}'
-    return int(mism.sum())
+check_ids = ids_parity            # (flips, rows_ok); strict (zero flips) unless a call says strict=False - see conftest.ids_parity
 
 
 # ---------------------------------------------------------------------------------------------------------------- config 2
@@ -104,7 +99,7 @@ def test_generate_d12_bf16_config2(gpu_device, B):
         err = (got - ref).abs().max().item()
         rel = err / float(g['absmax_per_scale'][si])
         worst_rel = max(worst_rel, rel)
-        check_ids(tr['idx'][si][:nref].cpu(), ref_ids[si][:nref], margin[:nref, o:o + l].numpy(), 4 * err + 1e-6, f'd12 bf16 B={B} scale {si}')
+        check_ids(tr['idx'][si][:nref].cpu(), ref_ids[si][:nref], margin[:nref, o:o + l].numpy(), 4 * err + 1e-6, f'd12 bf16 vs emulation B={B} scale {si}', strict=False)
         o += l
     print(f'd12 bf16 B={B}: worst per-scale logit error relative to max|logit| = {worst_rel:.3e} (bound {BF16_REL_BOUND:.1e}; north_star 1e-3)')
     assert worst_rel < BF16_REL_BOUND
@@ -136,6 +131,70 @@ def test_generate_d12_bf16_sampling_defaults(gpu_device):
     assert 0 <= int(ids_a.min()) and int(ids_a.max()) < 4096 and a.shape == (B, 3, 512, 256)
 
 
+# ------------------------------------------------------------------------------------ config 2: bf16 pinned to the REFERENCE's bf16
+def _d(a, b):
+    d = (a.double() - b.double())
+    return float(d.abs().max()), float(d.pow(2).mean().sqrt())
+
+
+def _fourway(what, hip, ref32, refac, emu, amax):
+    """the four distances VERDICT r2 asked for, as (max, RMS) relative to max|logit|: HIP-bf16 vs the reference in fp32, the reference's
+    own bf16 autocast vs its fp32, HIP-bf16 vs the reference's autocast, HIP-bf16 vs this repo's bf16 emulation"""
+    out = {k: [v / amax for v in _d(*pair)] for k, pair in dict(hip_vs_ref_fp32=(hip, ref32), ref_autocast_vs_ref_fp32=(refac, ref32),
+                                                               hip_vs_ref_autocast=(hip, refac), hip_vs_emulation=(hip, emu),
+                                                               emulation_vs_ref_fp32=(emu, ref32)).items()}
+    print(f'[bf16] {what} (max, RMS relative to max|logit| = {amax:.2f}): ' + '; '.join(f'{k} {v[0]:.2e} / {v[1]:.2e}' for k, v in out.items()))
+    record(what, kind='bf16_logits', absmax=amax, **out)
+    return out
+
+
+def test_forward_d12_bf16_among_the_references_bf16(gpu_device):
+    """north_star: "within 1e-3 on bf16 logits".  The yardstick is the reference itself: forward_d12_bf16ref.npz holds the d12-width
+    teacher-forced logits of the reference in fp32 AND under torch.autocast('cpu', bfloat16) (control_var.py:568-651), plus the oracle's
+    bf16 emulation, on one input.  Asserted: the HIP bf16 path is no farther from the reference's fp32 logits than the reference's own
+    bf16 autocast is (x1.1, max and RMS), and its RMS distance to the emulation (same storage points, different accumulation order) is
+    below 1e-3 * max|logit|.  All four distances are printed and recorded (profiles/r03_parity_report.json)."""
+    g = golden('forward_d12_bf16ref')
+    vae, m = build(12, BF16, gpu_device, ch=32)
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 1358, 32, generator=gen).to(gpu_device)
+    with torch.no_grad():
+        hip = m(t(g['labels']), x, t(g['types']), True).float().cpu()[:, ::9, ::31]
+    r = _fourway('forward_d12 bf16', hip, t(g['ref_fp32']), t(g['ref_autocast']), t(g['emu']), float(g['absmax']))
+    assert r['hip_vs_ref_fp32'][0] <= 1.1 * r['ref_autocast_vs_ref_fp32'][0]
+    assert r['hip_vs_ref_fp32'][1] <= 1.1 * r['ref_autocast_vs_ref_fp32'][1]
+    assert r['hip_vs_emulation'][1] <= 1e-3
+
+
+def test_generate_d12_bf16_along_the_references_bf16_trace(gpu_device):
+    """config 2 on the reference's own bf16 trace (gen_d12_bf16ref.npz: autoregressive_infer_cfg under CPU bf16 autocast, B=8, greedy; the
+    fp32 reference and the bf16 emulation walked along the same ids): the HIP bf16 model is forced along those ids and its per-scale
+    CFG-combined logits are placed among the three.  Asserted per scale as in the forward test; greedy ids agree with the reference's
+    autocast ids wherever the autocast margin exceeds the distance between the two bf16 implementations."""
+    g = golden('gen_d12_bf16ref')
+    vae, m = build(12, BF16, gpu_device)
+    B = 8
+    labels, types = t(g['labels']), t(g['types'])
+    ids = split(t(g['ids']).long())
+    m.autoregressive_infer_cfg(B, labels, g_seed=0, cfg=4.0, top_k=1, cond_type=types, _force_idx=ids, _trace=True)
+    tr = m.last_trace
+    o, flips = 0, 0
+    for si, p in enumerate(PN):
+        l = 2 * p * p
+        hip = tr['logits'][si][:4, :, 5::128].float().cpu()
+        sl = slice(o, o + l)
+        amax = float(g['absmax_per_scale'][si])
+        r = _fourway(f'gen_d12 bf16 scale {si}', hip, t(g['ref_fp32'])[:, sl], t(g['ref_autocast'])[:, sl], t(g['emu'])[:, sl], amax)
+        assert r['hip_vs_ref_fp32'][0] <= 1.1 * r['ref_autocast_vs_ref_fp32'][0], si
+        assert r['hip_vs_ref_fp32'][1] <= 1.1 * r['ref_autocast_vs_ref_fp32'][1], si
+        assert r['hip_vs_emulation'][1] <= 1e-3, si
+        n, _ = check_ids(tr['idx'][si].cpu(), ids[si], g['margin_autocast'][:, sl], 2.5 * r['hip_vs_ref_autocast'][0] * amax,
+                         f'gen_d12 bf16 greedy ids vs the reference autocast trace, scale {si}', strict=False)
+        flips += n
+        o += l
+    print(f'd12 bf16 along the reference autocast trace: {flips} of {B * 1360} greedy ids differ (all below the margin bound)')
+
+
 # ---------------------------------------------------------------------------------------------------------------- config 4
 def _gen_check(m, g, B, labels, scale, types, what, four=False, c_mask=None, tol=3e-3):
     if four:
@@ -143,11 +202,11 @@ def _gen_check(m, g, B, labels, scale, types, what, four=False, c_mask=None, tol
     else:
         img = m.autoregressive_infer_cfg(B, labels, g_seed=0, cfg=scale, top_k=1, cond_type=types, _trace=True)
     ids = torch.cat(m.last_trace['idx'], dim=1).cpu()
-    nm = check_ids(ids[:t(g['ids']).shape[0]], g['ids'], g['margin'], tol, what)
-    if nm == 0:
-        img = img.cpu()
-        assert (img[:, :, 100:116, 60:76] - t(g['img_crop'])).abs().max() < 5e-3
-        assert (img.mean(dim=(2, 3)) - t(g['img_mean'])).abs().max() < 5e-4
+    nm, ok = check_ids(ids[:t(g['ids']).shape[0]], g['ids'], g['margin'], tol, what)
+    ok = ok.reshape(-1, img.shape[0]).all(axis=0)
+    img = img.cpu()
+    assert (img[:, :, 100:116, 60:76] - t(g['img_crop']))[ok].abs().max() < 5e-3
+    assert (img.mean(dim=(2, 3)) - t(g['img_mean']))[ok].abs().max() < 5e-4
     return img
 
 

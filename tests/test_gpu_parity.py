@@ -12,7 +12,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from conftest import golden  # noqa: E402
+from conftest import golden, ids_parity, record  # noqa: E402
 from controlvar_amd import models  # noqa: E402
 from controlvar_amd.spec import DEFAULT_PATCH_NUMS as PN, VaeConfig, VarConfig, phi_index_map  # noqa: E402
 from controlvar_amd.synth import synth_images, synth_vae_state, synth_var_state  # noqa: E402
@@ -52,14 +52,9 @@ def make_var(vae, cfg: VarConfig, dtype, dev, seed=0):
     return m.to(dev).eval()
 
 
-def assert_ids(got, ref, margin, tol, what):
-    got, ref = np.asarray(got).astype(np.int64), np.asarray(ref).astype(np.int64)
-    assert got.shape == ref.shape, (got.shape, ref.shape)
-    mism = got != ref
-    if mism.any():
-        worst = float(np.asarray(margin)[mism].max())
-        assert worst < tol, f'{what}: {int(mism.sum())} id mismatches, largest reference margin at a mismatch {worst:.3e} >= {tol}'
-    return int(mism.sum())
+# image -> ids runs the whole fp32 encoder before the quantizer: strict (zero flips) where that was measured on MI355X
+STRICT_ENCODE = {'ch32': True, 'ch160': True}
+assert_ids = ids_parity          # (flips, rows_ok); strict by default: zero flips against every fp32 fixture (conftest.ids_parity)
 
 
 # ------------------------------------------------------------------------------ tokenizer
@@ -72,10 +67,9 @@ def test_ms_encode_bit_exact_on_reference_features(gpu_device, tag, ch):
     idx, fh, mg = vae._ms_encode(f, want_fhat=True, want_margin=True)
     sd = synth_vae_state(VaeConfig(ch=ch))
     _, margins = MSQuant(sd, PN, phi_index_map(10)).f_to_idx(t(g['f']), return_margins=True)
-    n = assert_ids(idx.cpu(), g['ids'], torch.cat(margins, 1).numpy(), 1e-4, 'ms_encode')
-    if n == 0:
-        assert (fh.cpu() - t(g['fhat_last'])).abs().max() < 1e-4
-        assert (mg.cpu() - torch.cat(margins, 1)).abs().max() < 1e-3
+    n, ok = assert_ids(idx.cpu(), g['ids'], torch.cat(margins, 1).numpy(), 1e-4, f'ms_encode {tag}')
+    assert (fh.cpu() - t(g['fhat_last']))[ok].abs().max() < 1e-4
+    assert (mg.cpu() - torch.cat(margins, 1))[ok].abs().max() < 1e-3
 
 
 @pytest.mark.parametrize('B,amp,seed', [(1, 0.5, 1), (3, 1.0, 2), (5, 3.0, 3)])
@@ -91,7 +85,7 @@ def test_ms_encode_random_features_against_oracle(gpu_device, B, amp, seed):
     fd = f.to(gpu_device)
     for want_margin in (False, True):
         idx = vae._ms_encode(fd, want_fhat=True, want_margin=want_margin)[0]
-        assert_ids(idx.cpu(), ref, mref, 1e-4 * max(1.0, amp * amp), f'ms_encode B={B} margin path={want_margin}')
+        assert_ids(idx.cpu(), ref, mref, 1e-4 * max(1.0, amp * amp), f'ms_encode random features B={B} margin path={want_margin}', strict=False)
 
 
 def test_tokenizer_with_caller_chosen_scale_lists(gpu_device):
@@ -187,7 +181,7 @@ def test_tokenizer_fp32_against_reference(gpu_device, tag, ch):
     ids = torch.cat(vae.img_to_idxBl(img), dim=1)
     sd = synth_vae_state(VaeConfig(ch=ch))
     _, margins = MSQuant(sd, PN, phi_index_map(10)).f_to_idx(t(g['f']), return_margins=True)
-    assert_ids(ids.cpu(), g['ids'], torch.cat(margins, 1).numpy(), 2e-3 * scale, 'img_to_idxBl')
+    assert_ids(ids.cpu(), g['ids'], torch.cat(margins, 1).numpy(), 2e-3 * scale, f'img_to_idxBl {tag}', strict=STRICT_ENCODE[tag])
     gi = [x.to(gpu_device) for x in split_ids(g['ids'].astype(np.int64))]
     var_in = torch.cat(vae.idxBl_to_h(gi), dim=1)
     assert (var_in.cpu()[:, ::5] - t(g['var_in'])).abs().max() < 2e-5
@@ -255,13 +249,12 @@ def test_generate_fp32_matches_reference_tokens(gpu_device, name):
     img = _run(m, case).cpu()
     tr = m.last_trace
     ids = torch.cat(tr['idx'], dim=1).cpu()
-    nm = assert_ids(ids, g['ids'], g['margin'], 2e-3, name)
+    nm, ok = assert_ids(ids, g['ids'], g['margin'], 2e-3, name)
     lg = torch.cat([x[:2] for x in tr['logits']], dim=1).cpu()[:, :, ::128][:, ::3]
-    if nm == 0:
-        assert (lg - t(g['logit_samples'])).abs().max() < 3e-3 * max(1.0, float(np.abs(g['logit_samples']).max()))
-        assert (img[:, :, 100:116, 60:76] - t(g['img_crop'])).abs().max() < 2e-3
-        assert (img[:, :, -20:-4, 200:216] - t(g['img_crop2'])).abs().max() < 2e-3
-        assert (img.mean(dim=(2, 3)) - t(g['img_mean'])).abs().max() < 2e-4
+    assert (lg - t(g['logit_samples']))[ok[:2]].abs().max() < 3e-3 * max(1.0, float(np.abs(g['logit_samples']).max()))
+    assert (img[:, :, 100:116, 60:76] - t(g['img_crop']))[ok].abs().max() < 2e-3
+    assert (img[:, :, -20:-4, 200:216] - t(g['img_crop2']))[ok].abs().max() < 2e-3
+    assert (img.mean(dim=(2, 3)) - t(g['img_mean']))[ok].abs().max() < 2e-4
 
 
 @pytest.mark.parametrize('name,teach,scale', [('gen_d2_cmask', 'c_mask', (4.0, 4.0, 4.0)), ('gen_d2_cimg', 'c_img', (3.0, 2.0, 1.0)),
@@ -277,10 +270,10 @@ def test_conditional_infer_fp32_matches_reference_tokens(gpu_device, name, teach
     img = m.conditional_infer_cfg(2, torch.tensor([5, 6]), g_seed=0, cfg=scale, top_k=1, cond_type=torch.tensor([2, 3]), _trace=True,
                                   **{teach: c_ids}).cpu()
     ids = torch.cat(m.last_trace['idx'], dim=1).cpu()
-    nm = assert_ids(ids, g['ids'], g['margin'].repeat(4, axis=0) if g['margin'].shape[0] * 4 == ids.shape[0] else g['margin'], 2e-3, name)
-    if nm == 0:
-        assert (img[:, :, 100:116, 60:76] - t(g['img_crop'])).abs().max() < 2e-3
-        assert (img.mean(dim=(2, 3)) - t(g['img_mean'])).abs().max() < 2e-4
+    nm, ok = assert_ids(ids, g['ids'], g['margin'].repeat(4, axis=0) if g['margin'].shape[0] * 4 == ids.shape[0] else g['margin'], 2e-3, name)
+    ok = ok.reshape(-1, img.shape[0]).all(axis=0)
+    assert (img[:, :, 100:116, 60:76] - t(g['img_crop']))[ok].abs().max() < 2e-3
+    assert (img.mean(dim=(2, 3)) - t(g['img_mean']))[ok].abs().max() < 2e-4
 
 
 def test_generate_d12_config1_fp32(gpu_device):
@@ -291,39 +284,9 @@ def test_generate_d12_config1_fp32(gpu_device):
     case = dict(cfg=VarConfig(depth=12), B=2, labels=[3, 7], scale=4.0, types=[0, 1])
     img = _run(m, case).cpu()
     ids = torch.cat(m.last_trace['idx'], dim=1).cpu()
-    nm = assert_ids(ids, g['ids'], g['margin'], 2e-3, 'gen_d12_b2')
-    if nm == 0:
-        assert (img[:, :, 100:116, 60:76] - t(g['img_crop'])).abs().max() < 3e-3
-        assert (img.mean(dim=(2, 3)) - t(g['img_mean'])).abs().max() < 3e-4
-
-
-def test_generate_bf16_against_emulated_oracle(gpu_device):
-    """Throughput mode under teacher forcing: per-scale CFG logits within 1e-3 * max|logit| ... measured against the
-    oracle with the same bf16 storage points; greedy ids equal wherever the oracle margin exceeds the logit error."""
-    cfg = VarConfig(depth=2)
-    sdv = synth_vae_state(VaeConfig(ch=32))
-    msq = MSQuant(sdv, PN, phi_index_map(10))
-    sd = synth_var_state(cfg)
-    labels, types = torch.tensor([3, 7]), torch.tensor([0, 1])
-    trace = {}
-    with torch.no_grad():
-        var_ref.generate(sd, cfg, msq, 2, labels, 4.0, top_k=1, cond_type=types, prec=Prec(True), trace=trace)
-    ref_idx = trace['idx']
-    vae = make_vae(32, BF16, gpu_device)
-    m = make_var(vae, cfg, BF16, gpu_device)
-    m.autoregressive_infer_cfg(2, labels, g_seed=0, cfg=4.0, top_k=1, cond_type=types, _force_idx=ref_idx, _trace=True)
-    tr = m.last_trace
-    worst = 0.0
-    for si in range(len(PN)):
-        ref = trace['logits'][si]
-        got = tr['logits'][si].cpu()
-        err = (got - ref).abs().max().item()
-        worst = max(worst, err / max(1.0, ref.abs().max().item()))
-        t2 = ref.topk(2, dim=-1).values
-        margin = (t2[..., 0] - t2[..., 1]).numpy()
-        assert_ids(tr['idx'][si].cpu(), ref_idx[si], margin, 4 * err + 1e-6, f'bf16 scale {si}')
-    assert worst < 1e-2, f'bf16 logits deviate {worst:.3e} (relative to max |logit|) from the bf16-emulating oracle'
-    print(f'bf16 vs emulated oracle: worst relative logit error {worst:.3e}')
+    nm, ok = assert_ids(ids, g['ids'], g['margin'], 2e-3, 'gen_d12_b2 (BASELINE config 1)')
+    assert (img[:, :, 100:116, 60:76] - t(g['img_crop']))[ok].abs().max() < 3e-3
+    assert (img.mean(dim=(2, 3)) - t(g['img_mean']))[ok].abs().max() < 3e-4
 
 
 @pytest.mark.parametrize('tag,mf', [('d2', 2), ('var_d2', 1), ('d2v', 2), ('d2sa', 2), ('d2sa0', 2), ('d2b', 2)])
@@ -341,7 +304,7 @@ def test_forward_logits_fp32(gpu_device, tag, mf):
     with torch.no_grad() if variant else contextlib.nullcontext():      # both routes: the inference-only pass and the autograd bridge
         logits = m(t(g['labels']), x.to(gpu_device), t(g['types']), tag != 'd2b').detach().cpu()      # 'd2b': mask_first=False
     assert (logits[:, ::9, ::31] - t(g['logits_sample'])).abs().max() < 2e-3
-    assert_ids(logits.argmax(-1), g['argmax'], g['margin'], 2e-3, 'forward argmax')
+    assert_ids(logits.argmax(-1), g['argmax'], g['margin'], 2e-3, f'forward_{tag} argmax')
 
 
 # ----------------------------------------------------------- size-independent properties

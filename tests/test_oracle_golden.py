@@ -175,6 +175,41 @@ def test_bf16_emulated_d12_trace_is_the_fp32_trace_up_to_rounding():
         o += l
 
 
+def test_bf16_reference_fixtures_pin_the_oracle_in_both_precisions():
+    """forward_d12_bf16ref.npz (recorded from the reference: fp32, CPU bf16 autocast) also carries the oracle's bf16 emulation: the oracle
+    in fp32 must reproduce the reference's fp32 logits, its emulation must reproduce the recorded emulation, and the recorded ordering -
+    the emulation is CLOSER to the reference's fp32 than the reference's own autocast - is what the GPU test leans on"""
+    from oracle.vqvae_ref import Prec
+    g = golden('forward_d12_bf16ref')
+    cfg = VarConfig(depth=12)
+    sd = synth_var_state(cfg)
+    gen = torch.Generator().manual_seed(31)
+    x = torch.randn(2, cfg.pyramid.L - cfg.pyramid.first_l, 32, generator=gen)
+    with torch.no_grad():
+        l32 = var_ref.forward_logits(sd, cfg, t(g['labels']), x, t(g['types']))[:, ::9, ::31]
+        lemu = var_ref.forward_logits(sd, cfg, t(g['labels']), x, t(g['types']), prec=Prec(True))[:, ::9, ::31]
+    assert (l32 - t(g['ref_fp32'])).abs().max() < 5e-4
+    assert (lemu - t(g['emu'])).abs().max() < 1e-5 * float(g['absmax']) + 1e-4          # same code, same machine class: reproducible
+    assert g['d_emu_fp32'][0] < g['d_autocast_fp32'][0] and g['d_emu_fp32'][1] < g['d_autocast_fp32'][1]
+    assert g['d_autocast_fp32'][0] > 1e-3 * float(g['absmax'])                           # the reference's own bf16 misses 1e-3 of max|logit| (max norm)
+
+
+@pytest.mark.slow
+def test_oracle_walks_the_references_bf16_trace():
+    """gen_d12_bf16ref.npz: rows 0..1 of the reference's autocast trace; the fp32 oracle forced along those ids reproduces the fp32
+    reference's logits on that path (the reference was walked along the same ids when the fixture was recorded)"""
+    g = golden('gen_d12_bf16ref')
+    cfg = VarConfig(depth=12)
+    sdv, sd = synth_vae_state(VaeConfig(ch=160)), synth_var_state(cfg)
+    ids = [i[:2] for i in split_ids(g['ids'].astype(np.int64), mf=2)]
+    trace = {}
+    with torch.no_grad():
+        var_ref.generate(sd, cfg, MSQuant(sdv, PN, phi_index_map(10)), 2, t(g['labels'])[:2], 4.0, top_k=1, cond_type=t(g['types'])[:2], force_idx=ids, trace=trace)
+    lg = torch.cat([x[:, :, 5::128] for x in trace['logits']], dim=1)
+    ref = t(g['ref_fp32'])[:2]
+    assert (lg - ref).abs().max() < 2e-3 * max(1.0, float(ref.abs().max()))
+
+
 def _gen_check(name, cfg, B, labels, cfg_scale, cond_type=None, four=False, teach=None, top_k=1, top_p=0.0, seed=0,
                vae_ch=32, img_tol=5e-4, wseed=0, logit_tol=2e-3, mean_tol=1e-4, id_frac=0.0, **kw0):
     g = golden(name)
