@@ -85,7 +85,7 @@ def test_ms_encode_random_features_against_oracle(gpu_device, B, amp, seed):
     fd = f.to(gpu_device)
     for want_margin in (False, True):
         idx = vae._ms_encode(fd, want_fhat=True, want_margin=want_margin)[0]
-        assert_ids(idx.cpu(), ref, mref, 1e-4 * max(1.0, amp * amp), f'ms_encode random features B={B} margin path={want_margin}', strict=False)
+        assert_ids(idx.cpu(), ref, mref, 1e-4 * max(1.0, amp * amp), f'ms_encode random features B={B} margin path={want_margin}')      # strict: measured 0 flips on MI355X (r03 parity report)
 
 
 def test_tokenizer_with_caller_chosen_scale_lists(gpu_device):
