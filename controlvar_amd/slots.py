@@ -32,6 +32,35 @@ def _need_cuda(t: torch.Tensor, what: str):
         raise RuntimeError(f'{what}: controlvar_amd operator slots run on the GPU only (no CPU fallback)')
 
 
+# ------------------------------------------------------------------------------------------------------------------------ autocast
+# The reference trains and validates under torch.autocast(bfloat16) with float32 Parameters (train_control_var_hpu.py:208).  ATen ops are
+# cast by the autocast dispatcher; flash-attn's fused_mlp_func does it itself (custom_fwd: x, both weights and biases go to the autocast
+# dtype).  torch.ops.cvar.* have no autocast rule, so the slot wrappers cast here: without it a bf16 activation meets a float32 weight
+# (TypeError in cvar::linear), or - in the adaLN path, whose LayerNorm output is float32 - the FFN would silently take the exact-f32 GEMM.
+_CAST_CACHE: dict = {}
+
+
+def _autocast_dtype(t: torch.Tensor):
+    dev = t.device.type
+    return torch.get_autocast_dtype(dev) if torch.is_autocast_enabled(dev) else None
+
+
+def _cast(t: Optional[torch.Tensor], dtype):
+    """t in `dtype`.  Differentiable for a parameter that needs a gradient; otherwise (inference) the cast copy is cached per
+    (storage, version) the way the autocast dispatcher caches its weight casts, so a weight is converted once, not once per call."""
+    if t is None or dtype is None or t.dtype == dtype or not t.is_floating_point():
+        return t
+    if t.requires_grad and torch.is_grad_enabled():
+        return t.to(dtype)
+    key = (t.data_ptr(), t._version, tuple(t.shape), t.dtype, dtype, t.device)
+    hit = _CAST_CACHE.get(key)
+    if hit is None:
+        if len(_CAST_CACHE) > 4096:
+            _CAST_CACHE.clear()
+        hit = _CAST_CACHE[key] = t.detach().to(dtype)
+    return hit
+
+
 # --------------------------------------------------------------------------------------------------------------------- fused MLP
 def fused_mlp_func(x, weight1, weight2, bias1=None, bias2=None, activation='gelu_approx', save_pre_act=True, return_residual=False,
                    checkpoint_lvl=0, heuristic=0, process_group=None):
@@ -45,20 +74,39 @@ def fused_mlp_func(x, weight1, weight2, bias1=None, bias2=None, activation='gelu
         raise NotImplementedError('fused_mlp_func: only activation="gelu_approx" (the one FFN passes) is built')
     if process_group is not None:
         raise NotImplementedError('fused_mlp_func: tensor-parallel process groups are out of scope (replicas only, SURVEY.md 8e)')
+    ac = _autocast_dtype(x)
+    if ac is not None:                                   # flash-attn's custom_fwd: inputs AND weights in the autocast dtype
+        x, weight1, weight2 = _cast(x, ac), _cast(weight1, ac), _cast(weight2, ac)
     h = cvar.linear(x, weight1, bias1, ACT_GELU_TANH)
     y = cvar.linear(h, weight2, bias2, ACT_NONE)
     return (y, x) if return_residual else y
 
 
 # --------------------------------------------------------------------------------------------------------------------- attention
+_LEVELS_CACHE: dict = {}
+
+
 def _prefix_levels(attn_mask: torch.Tensor, Lq: int, Lk: int):
+    """cached front of _prefix_levels_uncached: the reference passes the SAME registered buffer (attn_bias_for_masking, or a row slice of
+    it) on every layer of every step, and decoding it costs a device->host copy (a sync) plus a Python walk over its rows - once per
+    (storage, version, shape) instead of once per layer per forward."""
+    key = (attn_mask.data_ptr(), attn_mask._version, tuple(attn_mask.shape), tuple(attn_mask.stride()), attn_mask.dtype, attn_mask.device, Lq, Lk)
+    hit = _LEVELS_CACHE.get(key)
+    if hit is None:
+        if len(_LEVELS_CACHE) > 256:
+            _LEVELS_CACHE.clear()
+        hit = _LEVELS_CACHE[key] = _prefix_levels_uncached(attn_mask, Lq, Lk)
+    return hit
+
+
+def _prefix_levels_uncached(attn_mask: torch.Tensor, Lq: int, Lk: int):
     """The kernels implement 'query at position p sees keys [0, end(level(p))) minus one hole of its level', with level(p) = the first
     level whose end lies above p - exactly the structure of the reference's attn_bias_for_masking (control_var.py:158-191: plain,
     separate_decoding, separate_decoding + indep) and of its row slices.  Recover (level ends, holes) from an additive {0, -inf} mask
     and verify that it has that form; anything else is not something the reference passes and is refused, not approximated."""
     m = attn_mask
     while m.dim() > 2:
-        if m.shape[0] != 1:
+        if m.shape[0] != 1 and m.stride(0) != 0:         # an .expand()-ed broadcast (basic_var.py:115) is still one mask
             raise NotImplementedError('attention slot: per-batch / per-head masks are not built (the reference broadcasts one (1,1,L,L) mask)')
         m = m[0]
     if tuple(m.shape) != (Lq, Lk):
@@ -103,6 +151,9 @@ def _attention_blhc(q, k, v, scale: float, attn_mask=None, dropout_p: float = 0.
         raise NotImplementedError('attention slot: head_dim must be 64 (embed_dim = 64 * depth in every reference model)')
     if k.shape != v.shape or k.shape[0] != B or k.shape[2] != H or Lq > Lk:
         raise ValueError(f'attention slot: inconsistent shapes q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)}')
+    ac = _autocast_dtype(q)
+    if ac is not None:                                   # F.scaled_dot_product_attention is on autocast's lower-precision list
+        q, k, v = _cast(q, ac), _cast(k, ac), _cast(v, ac)
     if q.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError(f'attention slot: dtype {q.dtype} not supported (float32 or bfloat16)')
     q_off = Lk - Lq
