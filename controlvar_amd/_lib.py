@@ -11,7 +11,7 @@ import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CVAR_LIB') or os.path.join(HERE, 'libcvar_hip.so')      # CVAR_LIB: A/B runs against another build
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 CVAR_F32, CVAR_BF16 = 0, 1
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_GRAD = 0, 1, 2
@@ -37,7 +37,7 @@ class GemmDesc(C.Structure):
         ('remap_l', c_i), ('remap_L', c_i), ('remap_off', c_i),
         ('pre_act', c_p), ('aux', c_p), ('gate_scale', c_p),
         ('ws', c_p), ('ws_bytes', c_l), ('tile_cfg', c_i), ('stagger', c_i), ('group_m', c_i),
-        ('C_split', c_p), ('split_n', c_i), ('ld_split', c_l),
+        ('C_split', c_p), ('split_n', c_i), ('ld_split', c_l), ('split_alpha', c_f),
     ]
 
 
@@ -56,9 +56,11 @@ SIGNATURES = {
     'cvar_silu_cast': (c_i, [c_p, c_p, c_i, c_l, c_p]),
     'cvar_attention': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, C.POINTER(c_i), c_p, c_p, c_p]),
     'cvar_attention_rowwise': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, C.POINTER(c_i), c_p, c_p, c_p]),
+    'cvar_attention_v1': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, C.POINTER(c_i), c_p, c_p, c_p]),
+    'cvar_attention_prescaled': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, C.POINTER(c_i), c_i, C.POINTER(c_i), c_p, c_p, c_p]),
     'cvar_attention_bwd': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, C.POINTER(c_i), c_p, c_p, c_p]),
     'cvar_attention_bwd_rowwise': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, C.POINTER(c_i), c_i, C.POINTER(c_i), c_p, c_p, c_p]),
-    'cvar_cos_qk_norm': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    'cvar_cos_qk_norm': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p]),
     'cvar_cos_qk_norm_bwd': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     'cvar_cfg_sample': (c_i, [c_p, c_i, c_i, c_i, c_i, C.POINTER(c_f), c_i, c_f, C.c_uint64, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_f, c_f, c_p, c_p, c_p]),
     'cvar_ms_next_input': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

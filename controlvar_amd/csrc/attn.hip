@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p) {
 }
 
 // (a template takes its launch bounds from the FIRST declaration: without them here the kernels are compiled for 1024-thread groups, 128 VGPRs)
-template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_mfma_bf16_kernel(const AttnParams p);
+template <bool HOLES, bool QPRE> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_mfma_bf16_kernel(const AttnParams p);
+template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_mfma_bf16_v1_kernel(const AttnParams p);
 
 // impl: 0 = auto (MFMA flash kernel for bf16, row-wise exact kernel for fp32), 1 = row-wise
 template <typename P>
@@ -187,11 +188,26 @@ static int cvar_attention_impl(const void* qkv, const void* q, int dtype, int R,
     }
     p.qkv = qkv; p.out = out; p.R = R; p.H = H; p.Lmax = Lmax; p.q_off = q_off; p.l = l; p.scale = scale; p.lse = lse;
     { const int rc = fill_levels(p, lvl_end_host, n_lvl, hole_host); if (rc != CVAR_OK) return rc; }
-    if (dtype == CVAR_BF16 && impl == 0) {
+    const bool qpre = (impl & 4) != 0;                     // the query rows carry scale * log2(e) (cvar_attention_prescaled)
+    impl &= 3;
+    if (qpre && (dtype != CVAR_BF16 || impl == 1 || !q)) return CVAR_EUNSUPPORTED;
+    if (dtype == CVAR_BF16 && impl != 1) {
         bool holes = false;
         for (int i = 0; i < p.n_lvl; ++i) holes = holes || p.hole_lo[i] < p.hole_hi[i];
-        if (holes) hipLaunchKernelGGL(attn_mfma_bf16_kernel<true>, dim3(cdiv(l, 128), H, R), dim3(256), 0, as_stream(stream), p);
-        else hipLaunchKernelGGL(attn_mfma_bf16_kernel<false>, dim3(cdiv(l, 128), H, R), dim3(256), 0, as_stream(stream), p);
+        if (impl == 2) {                                   // round-2 kernel (A/B reference)
+            if (qpre) return CVAR_EUNSUPPORTED;
+            if (holes) hipLaunchKernelGGL(attn_mfma_bf16_v1_kernel<true>, dim3(cdiv(l, 128), H, R), dim3(256), 0, as_stream(stream), p);
+            else hipLaunchKernelGGL(attn_mfma_bf16_v1_kernel<false>, dim3(cdiv(l, 128), H, R), dim3(256), 0, as_stream(stream), p);
+            CVAR_CHECK_LAUNCH();
+            return CVAR_OK;
+        }
+        const long nblk = (long)cdiv(l, 128) * H * R;
+        if (nblk > 0x7fffffffL) return CVAR_EUNSUPPORTED;
+        const dim3 grid((unsigned)nblk), block(256);
+        if (holes) { if (qpre) hipLaunchKernelGGL((attn_mfma_bf16_kernel<true, true>), grid, block, 0, as_stream(stream), p);
+                     else hipLaunchKernelGGL((attn_mfma_bf16_kernel<true, false>), grid, block, 0, as_stream(stream), p); }
+        else { if (qpre) hipLaunchKernelGGL((attn_mfma_bf16_kernel<false, true>), grid, block, 0, as_stream(stream), p);
+               else hipLaunchKernelGGL((attn_mfma_bf16_kernel<false, false>), grid, block, 0, as_stream(stream), p); }
         CVAR_CHECK_LAUNCH();
         return CVAR_OK;
     }
@@ -204,7 +220,7 @@ static int cvar_attention_impl(const void* qkv, const void* q, int dtype, int R,
 }
 
 // ================================================================================================
-// attn_mfma_bf16_kernel: flash-style attention on the matrix cores (bf16 in, fp32 accumulate), head_dim 64.
+// attn_mfma_bf16_v1_kernel (the round-2 kernel, kept as the A/B reference of the round-3 one: cvar_attention_impl impl 2): flash-style attention on the matrix cores (bf16 in, fp32 accumulate), head_dim 64.
 //
 // Per workgroup: 4 waves x 32 queries; KV tiles of 64 keys.  Per wave and tile (16 MFMA 32x32x16):
 //   S^T = K . Q^T   (swapped product: each lane then holds 32 scores of ONE query -> the row max / row sum are
@@ -219,7 +235,7 @@ constexpr int FA_VT_STRIDE = 68;      // elements per V^T row (64 keys + pad): 1
 
 // 3 waves per SIMD (<= 168 VGPRs): the softmax phase of one wave overlaps the MFMA phases of the other two (+10 % over 2)
 template <bool HOLES>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_mfma_bf16_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_mfma_bf16_v1_kernel(const AttnParams p) {
     constexpr int D = 64, KT = 64;
     __shared__ __attribute__((aligned(16))) char Ks[KT * 128];
     __shared__ __attribute__((aligned(16))) bf16_t Vt[D * FA_VT_STRIDE];
@@ -405,6 +421,252 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+// ================================================================================================
+// attn_mfma_bf16_kernel: flash-style attention on the matrix cores (bf16 in, fp32 accumulate), head_dim 64.
+//
+// Per workgroup: 4 waves x 32 queries of one (row, head); KV tiles of 64 keys.  Per wave and tile:
+//   S^T = K . Q^T   (swapped product: each lane then holds 32 scores of ONE query -> the row max / row sum are
+//                    31 in-lane ops + one cross-half shuffle, no LDS)
+//   P   = 2^(...)   in fp32, packed to bf16 straight into the B-operand layout of the next product
+//   O^T += V^T . P^T
+// K tile: row-major 128-B rows with the 16-B chunk index XOR-swizzled by (key>>1)&7 (conflict-free ds_read_b128).
+// V tile (round 3): row-major as it lies in memory (two ds_write_b128 per thread, no packing), 32-B segments XOR-swizzled by key & 3;
+//   the V^T fragments are built by `ds_read_b64_tr_b16` transpose-reads (a [4 keys][16 d] block -> lane i gets column i).  Round 2
+//   transposed V on its way INTO LDS: 8 pack operations + 8 ds_write_b32 per thread and tile, all of them on the vector pipe that
+//   bounds this kernel.
+// Global -> register prefetch of tile i+1 is issued before the MFMA work on tile i and written to LDS after it.
+//
+// QPRE (inference, cvar_attention_prescaled): the query rows already carry scale * log2(e) (folded into the q columns of the QKV GEMM's
+//   epilogue, one rounding), so a score needs no multiply; the running maximum is subtracted ON THE MATRIX PIPE: a fifth k-step whose A
+//   operand is a column of ones and whose B operand holds -m~ per query (m~ = the running maximum rounded to bf16 - softmax is invariant
+//   under ANY per-query shift, so the rounding is exact mathematics, it only has to stay within a few units of the true maximum).  The
+//   accumulators then hold s - m~ and P = v_exp_f32 of them: per score one transcendental + one add (row sum) + 1/2 max3 + 1/2 cvt_pk
+//   instead of those plus one fma - the vector pipe is what bounds this kernel (VALU-busy 81 %, MFMA-busy 32 % in round 2), the matrix
+//   pipe has room for the 2 extra MFMAs per tile.  m~ moves only when a tile's maximum exceeds it by more than THR (= 2 + |m~|/64 in the
+//   log2 domain: P <= 4 ... ), then the tile's scores, O and the row sum are shifted by the same exact delta.
+// Workgroup -> (query block, head, row): 1-D grid; the query blocks of one (row, head) - which stream the same K/V - are given block
+//   ids congruent mod 8, i.e. the same XCD / L2, and adjacent in dispatch order.
+// ================================================================================================
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4_t lds_tr16_b64(const char* lds_ptr) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)lds_ptr);
+}
+
+// 3 waves per SIMD (<= 168 VGPRs): the softmax phase of one wave overlaps the MFMA phases of the other two (+10 % over 2)
+template <bool HOLES, bool QPRE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_mfma_bf16_kernel(const AttnParams p) {
+    constexpr int D = 64, KT = 64;
+    __shared__ __attribute__((aligned(16))) char Ks[KT * 128];
+    __shared__ __attribute__((aligned(16))) char Vs[KT * 128];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lrow = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
+    // ---- block id -> (query block, pair = row * H + head)
+    const int nqb = (p.l + 127) >> 7, pairs = p.R * p.H;
+    int qb, pair;
+    {
+        const int id = blockIdx.x;
+        if ((pairs & 7) == 0) { const int xcd = id & 7, local = id >> 3; qb = local % nqb; pair = (local / nqb) * 8 + xcd; }
+        else { qb = id % nqb; pair = id / nqb; }
+    }
+    const int h = pair % p.H;
+    const long r = pair / p.H;
+    const int C3 = p.ldkv;
+    const bf16_t* base = (const bf16_t*)p.qkv + r * (long)p.Lmax * C3;
+    const bf16_t* kbase = base + p.k_col + h * D;
+    const bf16_t* vbase = base + p.v_col + h * D;
+
+    const int q0 = qb * 128 + w * 32;
+    const bool active = q0 < p.l;                     // a wave without a single query of the scale only helps staging the tiles
+    const int qi = q0 + lrow;
+    const int qrow = min(qi, p.l - 1);
+    const Vis vis = vis_of(p, p.q_off + qrow);
+    const int kv_end = kv_len_of(p, p.q_off + min(p.l, (qb + 1) * 128) - 1);
+
+    bf16x8_t qf[4];
+    {
+        const bf16_t* qp = (const bf16_t*)p.q + (r * p.q_rows + (p.q_off + qrow - p.q_pos0)) * (long)p.ldq + h * D;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qp + (2 * ks + hi) * 8);
+    }
+    // staging map (K and V alike): thread -> keys k_key and k_key + 32, 16-byte chunk k_chunk of the 128-byte head row
+    const int k_key = tid >> 3, k_chunk = tid & 7;
+    bf16x8_t kreg[2], vreg[2];
+    auto load_tile = [&](int kt0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = kt0 + k_key + 32 * i;
+            bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+            kreg[i] = key < kv_end ? *(const bf16x8_t*)(kbase + (long)key * C3 + k_chunk * 8) : z;
+            vreg[i] = key < kv_end ? *(const bf16x8_t*)(vbase + (long)key * C3 + k_chunk * 8) : z;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = k_key + 32 * i;
+            *(bf16x8_t*)(Ks + key * 128 + ((k_chunk ^ ((key >> 1) & 7)) << 4)) = kreg[i];
+            *(bf16x8_t*)(Vs + key * 128 + ((((k_chunk >> 1) ^ (key & 3)) << 5) | ((k_chunk & 1) << 4))) = vreg[i];
+        }
+    };
+    // transpose-read addressing of V: lane l of a 16-lane group points at key row (l & 15) >> 2 of a [4 keys][16 d] block, d columns
+    // 4 (l & 3) .. +3; the two groups of a half-wave are the two 16-d halves of a 32-d MFMA block, the upper half-wave takes the keys
+    // 4 further (the key order of an 8-key fragment is 4 hi + {0..3}, 8 + 4 hi + {0..3} - the order the swapped QK^T leaves P in)
+    const int v_jrow = (lane & 15) >> 2, v_g = (lane >> 4) & 1;
+    const char* v_lane[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) v_lane[db] = Vs + (4 * hi + v_jrow) * 128 + (((2 * db + v_g) ^ v_jrow) << 5) + (lane & 3) * 8;
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+    float m = QPRE ? 0.f : -INFINITY;                      // QPRE: m~ (a bf16 value), the shift the bias k-step applies
+    const float c2 = p.scale * 1.4426950408889634f;
+    float lsum = 0.f;
+    // QPRE: operands of the bias k-step.  A: k index 0 is a column of ones (lanes hi == 0, element 0), B: k index 0 holds -m~ of the lane's query
+    const short one_bf = hi == 0 ? (short)0x3f80 : (short)0;
+    const bf16x8_t k_ones = {one_bf, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8_t q_m = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    // One KV tile.  MASK is a compile-time flag: tiles that every query of the wave sees completely (all but the last one at
+    // inference, all but the level-boundary ones under the training mask) run without any per-score compare / select - left
+    // as a run-time flag the compiler if-converts the masking into ~100 extra vector instructions on every tile.
+    auto tile = [&](int kt0, auto MASK, auto FIRST) {
+        store_tile();
+        __syncthreads();
+        if (kt0 + KT < kv_end) load_tile(kt0 + KT);
+        if (active) {
+        // ---- S^T = K Q^T
+        f32x16_t s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+            if constexpr (QPRE && !decltype(FIRST)::value) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_ones, q_m, s[kb], 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8_t kf = *(const bf16x8_t*)(Ks + (32 * kb + lrow) * 128 + (((2 * ks + hi) ^ sw) << 4));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+            }
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if constexpr (decltype(MASK)::value) {
+                    const int key = kt0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hi;
+                    if (!vis_key_t<HOLES>(vis, key)) s[kb][i] = -INFINITY;
+                }
+                tmax = fmaxf(tmax, s[kb][i]);
+            }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        bf16x8_t pf[2][2];
+        if constexpr (QPRE) {
+            // the accumulators hold s - m~ (log2 domain).  m~ follows the maximum only when a tile exceeds it by more than THR (always on
+            // the first tile, which sets it): then everything still at the old shift - this tile's scores, O, the row sum - moves by
+            // the same delta = m~_new - m~_old (both bf16 values: the fp32 difference is exact)
+            const bool need = decltype(FIRST)::value ? true : tmax > 2.0f + fabsf(m) * 0.015625f;
+            if (decltype(FIRST)::value || __any(need)) {
+                const float m_new = need ? bf16_to_f32(f32_to_bf16(m + tmax)) : m;
+                const float delta = m_new - m;
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                lsum *= alpha;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) s[kb][i] -= delta;
+                m = m_new;
+                q_m[0] = hi == 0 ? (short)f32_to_bf16(-m_new) : (short)0;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float pr[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        pr[j] = __builtin_amdgcn_exp2f(s[kb][8 * t + j]);
+                        lsum += pr[j];
+                    }
+                    pf[kb][t] = pack_bf16x8(pr);
+                }
+        } else {
+            // softmax bookkeeping in the exp2 domain: p = 2^(s*c - m), c = scale*log2(e)  (one fma + one v_exp_f32 per score)
+            const float m_new = fmaxf(m, tmax * c2);            // c2 > 0; finite from the first tile on (key 0 is always visible)
+            if (!__all(m_new == m)) {                           // rescale only when some row's running max moved (exact skip)
+                const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+                lsum *= alpha;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+                m = m_new;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float pr[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        pr[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][8 * t + j], c2, -m));
+                        lsum += pr[j];
+                    }
+                    pf[kb][t] = pack_bf16x8(pr);
+                }
+        }
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const char* vp = v_lane[db] + (32 * kb + 16 * t) * 128;
+                    const s16x4_t v0 = lds_tr16_b64(vp);
+                    const s16x4_t v1 = lds_tr16_b64(vp + 8 * 128);
+                    const bf16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][t], o[db], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    };
+    typedef std::integral_constant<bool, true> Yes;
+    typedef std::integral_constant<bool, false> No;
+    load_tile(0);
+    int kt0 = 0;
+    // wave_min_kv is wave-uniform per construction but tiles are shared by the workgroup (barriers inside): the split point
+    // must be the same for all four waves, so it is taken over the workgroup's first query
+    const int wg_min_kv = range_full_prefix(p, p.q_off + min(qb * 128, p.l - 1), p.q_off + min(p.l, (qb + 1) * 128) - 1);
+    if constexpr (QPRE) {                                  // the first tile sets m~ unconditionally
+        if (KT <= wg_min_kv) tile(0, No{}, Yes{}); else tile(0, Yes{}, Yes{});
+        kt0 = KT;
+    }
+    for (; kt0 + KT <= wg_min_kv && kt0 < kv_end; kt0 += KT) tile(kt0, No{}, No{});
+    for (; kt0 < kv_end; kt0 += KT) tile(kt0, Yes{}, No{});
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (qi < p.l) {
+        if (p.lse && hi == 0) p.lse[(r * p.H + h) * (long)p.l + qi] = (m + log2f(lsum)) * 0.6931471805599453f;
+        const float inv = 1.0f / lsum;
+        bf16_t* op = (bf16_t*)p.out + (r * p.l + qi) * (long)(p.H * D) + h * D;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float ov[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = o[db][4 * g + e] * inv;
+                *(bf16x4_t*)(op + 32 * db + 8 * g + 4 * hi) = pack_bf16x4(ov);
+            }
+    }
+}
+
 extern "C" int cvar_attention_rowwise(const void* qkv, const void* q, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
                                       const int* lvl_end_host, int n_lvl, const int* hole_host, void* out, float* lse, void* stream) {
     return cvar_attention_impl(qkv, q, dtype, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, hole_host, out, lse, stream, 1);
@@ -412,6 +674,14 @@ extern "C" int cvar_attention_rowwise(const void* qkv, const void* q, int dtype,
 extern "C" int cvar_attention(const void* qkv, const void* q, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
                               const int* lvl_end_host, int n_lvl, const int* hole_host, void* out, float* lse, void* stream) {
     return cvar_attention_impl(qkv, q, dtype, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, hole_host, out, lse, stream, 0);
+}
+extern "C" int cvar_attention_prescaled(const void* kv, const void* q, int dtype, int R, int H, int Lmax, int q_off, int l,
+                                        const int* lvl_end_host, int n_lvl, const int* hole_host, void* out, float* lse, void* stream) {
+    return cvar_attention_impl(kv, q, dtype, R, H, Lmax, q_off, l, 1.0f, lvl_end_host, n_lvl, hole_host, out, lse, stream, 4);
+}
+extern "C" int cvar_attention_v1(const void* qkv, const void* q, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
+                                 const int* lvl_end_host, int n_lvl, const int* hole_host, void* out, float* lse, void* stream) {
+    return cvar_attention_impl(qkv, q, dtype, R, H, Lmax, q_off, l, scale, lvl_end_host, n_lvl, hole_host, out, lse, stream, 2);
 }
 
 // ================================================================================================

@@ -57,6 +57,7 @@ struct GemmParams {
     const float* gate_scale;       // optional per-gate-row multiplier (DropPath keep-scale of training)
     int in_dtype;                  // operand dtype (for the split-K epilogue kernel, which is not templated on it)
     int remap_l, remap_L, remap_off;
+    float split_alpha;        // factor on the split columns [0, split_n) (1 = none)
     void* Cs; int split_n; long ld_split;       // column split: columns [0, split_n) -> Cs[m][ld_split] (rows not remapped), the rest -> C at column n - split_n
     int tiles_m, tiles_n;
     int cv_adv, cv_rem;       // conv: a K tile advances (tap, ci) by (KT / Cin, KT % Cin) plus one carry
@@ -655,7 +656,13 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                             orow = (long)sq * p.remap_L + p.remap_off + (m - sq * p.remap_l);
                         }
                         char* cp = c_lane + orow * p.ldc * OES;
-                        if constexpr (remap) { if (in_split) cp = c_lane + (long)m * p.ld_split * OES; }
+                        if constexpr (remap) {
+                            if (in_split) {
+                                cp = c_lane + (long)m * p.ld_split * OES;
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) v[e] *= p.split_alpha;
+                            }
+                        }
                         if constexpr (out_bf) {
                             *(bf16x8_t*)cp = pack_bf16x8(v);
                         } else {
@@ -727,8 +734,9 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
             const float* grow = p.gate ? p.gate + (long)fast_div(m, p.gate_magic, p.gate_shift) * p.ldg : nullptr;
             void* Cdst = Cb;
             long cbase = cz + orow * p.ldc + n;
+            bool scale_split = false;
             if (p.split_n > 0) {
-                if (n < p.split_n) { Cdst = p.Cs; cbase = (long)m * p.ld_split + n; }
+                if (n < p.split_n) { Cdst = p.Cs; cbase = (long)m * p.ld_split + n; scale_split = p.split_alpha != 1.0f; }
                 else cbase -= p.split_n;
             }
             if (vec_ok) {
@@ -737,6 +745,10 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                 if (p.C2) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) st_any(p.C2, ES == 2 ? CVAR_BF16 : CVAR_F32, cz + (long)m * p.ldc + n + e, v[e]);
+                }
+                if (scale_split) {                   // the split rides on vector-aligned launches only (cvar_gemm checks)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= p.split_alpha;
                 }
                 if (p.act == CVAR_ACT_GELU_TANH) {
 #pragma unroll
@@ -1027,7 +1039,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     p.C = d->C; p.out_dtype = d->out_dtype; p.ldc = d->ldc;
     p.C2 = d->pre_act; p.aux = d->aux; p.gate_scale = d->gate_scale; p.in_dtype = d->dtype;
     p.remap_l = d->remap_l; p.remap_L = d->remap_L; p.remap_off = d->remap_off;
-    p.Cs = d->C_split; p.split_n = d->split_n; p.ld_split = d->ld_split;
+    p.Cs = d->C_split; p.split_n = d->split_n; p.ld_split = d->ld_split; p.split_alpha = d->split_alpha == 0.0f ? 1.0f : d->split_alpha;
     p.tiles_m = p.tiles_n = 0;
     p.cv_adv = p.cv_rem = 0; p.conv_bytes = 0;
     make_fast_div(p.remap_l, &p.remap_magic, &p.remap_shift);
@@ -1083,6 +1095,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     if (d->conv && d->dtype == CVAR_BF16 && d->stride == 1 && d->batch == 1 && (d->tile_cfg == 0 || d->tile_cfg == 6) &&
         d->Cin % 32 == 0 && d->Hout % 16 == 0 && d->Wout % 16 == 0 && d->act == CVAR_ACT_NONE && !d->gate && d->alpha == 1.0f &&
         !d->pre_act && !d->aux && !d->gate_scale && d->remap_l == 0 && d->split_n == 0 && d->strideC == 0 && d->ldc == d->N &&
+        d->ldw == d->K &&      // the halo kernel addresses packed [Cout][9 Cin] weights: padded weight rows stay on the implicit-GEMM path
         (!d->bias || (((uintptr_t)d->bias & 15) == 0)) && (long)d->Hin * d->Win * d->Cin * 2 < 0x7fffffffL) {
         const long tiles = (long)(d->M / 256);
         // wide form: Cout a multiple of 160, bf16 output, optional bf16 residual; two workgroups per CU or the implicit-GEMM tiles win (640->640 at 16x16)

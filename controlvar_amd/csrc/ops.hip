@@ -121,7 +121,7 @@ extern "C" int cvar_silu_cast(const float* x, void* out, int out_dtype, int64_t 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void cos_qk_norm_kernel(T* __restrict__ qkv, T* __restrict__ qs, int R, int H, int Lmax, int q_off, int l,
-                                                         const float* __restrict__ scale_mul, float* __restrict__ norms) {
+                                                         const float* __restrict__ scale_mul, float* __restrict__ norms, float q_mul) {
     const int lane = threadIdx.x & 63;
     const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);     // over R*l*H*2
     const long total = (long)R * l * H * 2;
@@ -137,18 +137,18 @@ __global__ __launch_bounds__(256) void cos_qk_norm_kernel(T* __restrict__ qkv, T
     const float v = Elem<T>::ld(p);
     const float nrm = fmaxf(sqrtf(wave_sum(v * v)), 1e-12f);      // F.normalize eps
     float o = v / nrm;
-    if (which == 0) o *= __expf(fminf(scale_mul[h], 4.605170185988092f));
+    if (which == 0) o *= __expf(fminf(scale_mul[h], 4.605170185988092f)) * q_mul;
     Elem<T>::st(p, o);
     if (norms && lane == 0) norms[item] = nrm;                     // [R][l][H][q|k], saved for the backward pass
 }
 
 extern "C" int cvar_cos_qk_norm(void* qkv, void* q, int dtype, int R, int H, int Lmax, int q_off, int l, const float* scale_mul,
-                                float* norms, void* stream) {
+                                float* norms, float q_mul, void* stream) {
     if (!qkv || !scale_mul || R <= 0 || H <= 0 || l <= 0) return CVAR_EINVAL;
     const long total = (long)R * l * H * 2;
     dim3 grid(cdiv(total, 4)), block(256);
-    if (dtype == CVAR_BF16) hipLaunchKernelGGL(cos_qk_norm_kernel<bf16_t>, grid, block, 0, as_stream(stream), (bf16_t*)qkv, (bf16_t*)q, R, H, Lmax, q_off, l, scale_mul, norms);
-    else if (dtype == CVAR_F32) hipLaunchKernelGGL(cos_qk_norm_kernel<float>, grid, block, 0, as_stream(stream), (float*)qkv, (float*)q, R, H, Lmax, q_off, l, scale_mul, norms);
+    if (dtype == CVAR_BF16) hipLaunchKernelGGL(cos_qk_norm_kernel<bf16_t>, grid, block, 0, as_stream(stream), (bf16_t*)qkv, (bf16_t*)q, R, H, Lmax, q_off, l, scale_mul, norms, q_mul);
+    else if (dtype == CVAR_F32) hipLaunchKernelGGL(cos_qk_norm_kernel<float>, grid, block, 0, as_stream(stream), (float*)qkv, (float*)q, R, H, Lmax, q_off, l, scale_mul, norms, q_mul);
     else return CVAR_EUNSUPPORTED;
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;
@@ -652,7 +652,7 @@ extern "C" int cvar_nhwc_to_nchw(const void* in, int dtype, int64_t ld_in, float
     return CVAR_OK;
 }
 
-extern "C" int cvar_abi_version(void) { return 13; }
+extern "C" int cvar_abi_version(void) { return 14; }
 extern "C" const char* cvar_status_str(int status) {
     switch (status) {
         case CVAR_OK: return "ok";

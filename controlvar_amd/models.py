@@ -420,7 +420,7 @@ class VQVAE(nn.Module):
     def _embed(self, idx_Bl: torch.Tensor) -> torch.Tensor:
         """quantize.embedding(idx) -> (B * l, Cvae) fp32 rows (vqvae.py:103)"""
         P = self._pack()
-        _check_index_range(idx_Bl, 0, self.V, 'token ids')
+        _check_index_range(idx_Bl, 0, self.V - 1, 'token ids')           # inclusive bounds: id == V raises like nn.Embedding's IndexError
         out = torch.empty(idx_Bl.numel(), self.Cvae, device=idx_Bl.device, dtype=torch.float32)
         return ops.embed_rows(idx_Bl.to(torch.int32).contiguous(), P['E'], out)
 
@@ -743,15 +743,20 @@ class ControlVAR(nn.Module):
         hbuf = torch.empty(M, hid, device=dev, dtype=T)
         qs = torch.empty(M, C, device=dev, dtype=T)                 # queries of this pass: (R, l, C)
         arena_stride = R * Lmax * 2 * C
+        # bf16 mode: the queries carry softmax scale * log2(e) from the producing epilogue (one rounding of q * c; the attention kernel then
+        # spends no multiply per score - cvar_attention_prescaled).  fp32 parity mode: the exact row-wise kernel, unscaled queries.
+        LOG2E = 1.4426950408889634
+        pre = T == torch.bfloat16
+        q_alpha = (float(cfg.attn_scale) * LOG2E) if (pre and not cfg.uses_cos_attn) else 1.0
         for i in range(cfg.depth):
             a0 = i * 6 * C
             ops.ln_modulate(x, ada, a0 + 2 * C, a0 + 4 * C, n_ada, l, u, M, C, cfg.norm_eps)
             # one GEMM for q | k | v: the q columns land in the scratch, k | v rows straight in their KV-arena slots (row remap)
             ops.gemm(u, P['w_qkv'], arena, M=M, N=3 * C, K=C, w_off=i * 3 * C * C, bias=P['b_qkv'][i], c_off=i * arena_stride,
-                     ldc=2 * C, remap=(l, Lmax, q_off), split=(qs, C, C))
+                     ldc=2 * C, remap=(l, Lmax, q_off), split=(qs, C, C), split_alpha=q_alpha)
             if cfg.uses_cos_attn:
-                ops.cos_qk_norm(arena, R, H, Lmax, q_off, l, P['scale_mul'], qkv_off=i * arena_stride, sm_off=i * H, q=qs)
-            ops.attention(arena, o, R, H, Lmax, q_off, l, float(cfg.attn_scale), lvl_end, qkv_off=i * arena_stride, holes=holes, q=qs)
+                ops.cos_qk_norm(arena, R, H, Lmax, q_off, l, P['scale_mul'], qkv_off=i * arena_stride, sm_off=i * H, q=qs, q_mul=LOG2E if pre else 1.0)
+            ops.attention(arena, o, R, H, Lmax, q_off, l, float(cfg.attn_scale), lvl_end, qkv_off=i * arena_stride, holes=holes, q=qs, prescaled=pre)
             ops.gemm(o, P['w_proj'], x, M=M, N=C, K=C, w_off=i * C * C, bias=P['b_proj'][i], gate=ada, gate_off=a0, ldg=n_ada, gate_rows=l,
                      residual=x)
             ops.ln_modulate(x, ada, a0 + 3 * C, a0 + 5 * C, n_ada, l, u, M, C, cfg.norm_eps)
@@ -1003,10 +1008,16 @@ class ControlVAR(nn.Module):
         torch.cuda.synchronize()
         if self._arena:                                     # the warm-up's K/V arena (arenas are per stream): the capture allocates its own
             self._arena.pop(side.cuda_stream, None)         # in the graph's pool, and two of them do not fit at large batches
-            torch.cuda.empty_cache()
+        ops.release_splitk_workspace(dev, side.cuda_stream)  # ... and the warm-up stream's split-K workspace
+        torch.cuda.empty_cache()
+        ws_before, arena_before = ops.splitk_workspace_keys(), set(self._arena or ())
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             out = self._decode_pair(self._generate_core(B, labels_all, types_all, 0, seed_dev, cfg, top_k, top_p, four_way))
+        # buffers created during the capture live in the GRAPH's memory pool and are baked into its launches: they belong to the graph, not
+        # to the per-stream tables - a later stream that is handed the capture stream's (pooled, reused) handle must not inherit them
+        owned = [ops.take_splitk_workspace(k) for k in ops.splitk_workspace_keys() - ws_before]
+        owned += [self._arena.pop(k) for k in set(self._arena or ()) - arena_before]
 
         def run(label_B, cond_type=None, g_seed=None):
             seed = int(g_seed) if g_seed is not None else int(torch.empty((), dtype=torch.int64).random_().item())
@@ -1019,6 +1030,7 @@ class ControlVAR(nn.Module):
             return out.clone()
 
         run.graph = graph
+        run.owned = owned                                   # dropped together with the graph when `run` goes away
         return run
 
     def _decode_pair(self, f_hat: torch.Tensor) -> torch.Tensor:

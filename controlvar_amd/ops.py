@@ -61,6 +61,31 @@ def ensure_splitk_workspace(device, nbytes: int = 256 << 20) -> torch.Tensor:
     return ws
 
 
+def splitk_workspace_keys() -> set:
+    """(device index, stream handle) keys of the live split-K workspaces"""
+    return set(_SPLITK_WS)
+
+
+def take_splitk_workspace(key) -> Optional[torch.Tensor]:
+    """remove one workspace from the per-stream table and hand it to the caller (models.graphed_generator: a workspace allocated during a
+    graph capture belongs to that graph)"""
+    return _SPLITK_WS.pop(key, None)
+
+
+def release_splitk_workspace(device=None, stream_handle: Optional[int] = None):
+    """Drop split-K workspaces (256 MB each) so the caching allocator can reuse the memory: the one of (device, stream_handle), or - with
+    stream_handle None - every workspace of the device except the current stream's.  Streams come from a pool and their handles are
+    reused; call this when a side stream is retired."""
+    dev = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if stream_handle is not None:
+        _SPLITK_WS.pop((idx, stream_handle), None)
+        return
+    cur = torch.cuda.current_stream(dev).cuda_stream
+    for k in [k for k in _SPLITK_WS if k[0] == idx and k[1] != cur]:
+        del _SPLITK_WS[k]
+
+
 def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, lda: int = 0, ldw: int = 0, ldc: int = 0,
          bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, alpha: float = 1.0,
          gate: Optional[torch.Tensor] = None, ldg: int = 0, gate_rows: int = 1, gate_off: int = 0,
@@ -68,7 +93,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
          remap: Optional[Sequence[int]] = None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0, strideR: int = 0,
          conv: Optional[dict] = None, a_off: int = 0, w_off: int = 0, c_off: int = 0,
          pre_act: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None, gate_scale: Optional[torch.Tensor] = None,
-         split: Optional[tuple] = None):
+         split: Optional[tuple] = None, split_alpha: float = 1.0):
     """C = epilogue(A @ W^T).  Offsets (*_off) are in elements of the respective tensor.
     split = (tensor, split_n, ld_split): result columns [0, split_n) go to ``tensor`` (rows not remapped), the rest to ``out`` at
     column n - split_n (cvar_gemm_desc.C_split; the qkv GEMM of inference: q beside a [R][Lmax][2C] K/V arena)."""
@@ -102,6 +127,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
         if st.dtype != out.dtype:
             raise TypeError('split target and out must share a dtype')
         d.C_split = _ptr(st)
+        d.split_alpha = float(split_alpha)
     ws = _SPLITK_WS.get((A.device.index, _stream()))
     if ws is None:
         ws = ensure_splitk_workspace(A.device)
@@ -156,12 +182,19 @@ def _level_arrays(lvl_end, holes):
 
 def attention(qkv: torch.Tensor, out: torch.Tensor, R: int, H: int, Lmax: int, q_off: int, l: int, scale: float,
               lvl_end: Optional[Sequence[int]] = None, qkv_off: int = 0, rowwise: bool = False, lse: Optional[torch.Tensor] = None,
-              holes: Optional[Sequence[Sequence[int]]] = None, q: Optional[torch.Tensor] = None):
-    """q=None: qkv is the packed arena [R][Lmax][3C]; q given: qkv is a K/V arena [R][Lmax][2C] and q holds the call's queries [R*l][C]"""
+              holes: Optional[Sequence[Sequence[int]]] = None, q: Optional[torch.Tensor] = None, prescaled: bool = False, v1: bool = False):
+    """q=None: qkv is the packed arena [R][Lmax][3C]; q given: qkv is a K/V arena [R][Lmax][2C] and q holds the call's queries [R*l][C].
+    prescaled: the query rows already carry scale * log2(e) (cvar_attention_prescaled; `scale` is then not used).  v1: the round-2 kernel."""
     n, arr, harr = _level_arrays(lvl_end, holes)
-    fn = _lib.load().cvar_attention_rowwise if rowwise else _lib.load().cvar_attention
     if q is not None and (q.dtype != qkv.dtype or q.numel() < R * l * H * 64):
         raise ValueError('q must hold R*l rows of H*64 elements in the arena dtype')
+    if prescaled:
+        if rowwise or q is None:
+            raise ValueError('prescaled queries: K/V-arena form of the MFMA kernel only')
+        check(_lib.load().cvar_attention_prescaled(_ptr(qkv) + qkv_off * qkv.element_size(), _ptr(q), dt(qkv), R, H, Lmax, q_off, l,
+                                                   arr, n, harr, _ptr(out), _ptr(lse), _stream()), 'cvar_attention_prescaled')
+        return out
+    fn = _lib.load().cvar_attention_rowwise if rowwise else (_lib.load().cvar_attention_v1 if v1 else _lib.load().cvar_attention)
     check(fn(_ptr(qkv) + qkv_off * qkv.element_size(), _ptr(q), dt(qkv), R, H, Lmax, q_off, l, scale,
                                      arr, n, harr, _ptr(out), _ptr(lse), _stream()), 'cvar_attention')
     return out
@@ -176,9 +209,9 @@ def attention_bwd(qkv, o, dout, lse, dqkv, ws, R, H, Lmax, l, scale, lvl_end=Non
 
 
 def cos_qk_norm(qkv: torch.Tensor, R: int, H: int, Lmax: int, q_off: int, l: int, scale_mul: torch.Tensor,
-                qkv_off: int = 0, sm_off: int = 0, norms: Optional[torch.Tensor] = None, q: Optional[torch.Tensor] = None):
+                qkv_off: int = 0, sm_off: int = 0, norms: Optional[torch.Tensor] = None, q: Optional[torch.Tensor] = None, q_mul: float = 1.0):
     check(_lib.load().cvar_cos_qk_norm(_ptr(qkv) + qkv_off * qkv.element_size(), _ptr(q), dt(qkv), R, H, Lmax, q_off, l,
-                                       _ptr(scale_mul) + 4 * sm_off, _ptr(norms), _stream()), 'cvar_cos_qk_norm')
+                                       _ptr(scale_mul) + 4 * sm_off, _ptr(norms), float(q_mul), _stream()), 'cvar_cos_qk_norm')
 
 
 def cos_qk_norm_bwd(qkv, dqkv, R, H, Lmax, l, scale_mul, norms, dsm_tok, sm_off: int = 0):

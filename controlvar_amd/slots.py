@@ -15,6 +15,7 @@ path, bfloat16 the throughput path; float16 is not supported (the reference's HP
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -45,20 +46,31 @@ def _autocast_dtype(t: torch.Tensor):
     return torch.get_autocast_dtype(dev) if torch.is_autocast_enabled(dev) else None
 
 
+def _base_of(t: torch.Tensor) -> torch.Tensor:
+    return t._base if t._base is not None else t
+
+
+def _cached(cache: dict, t: torch.Tensor, extra: tuple, make):
+    """memo of make() per tensor VALUE identity: keyed by the python object of the tensor's base (a weak reference - the entry dies with the
+    tensor, so a later tensor that is handed the same address can never inherit it), the view geometry and the version counter"""
+    base = _base_of(t)
+    key = (id(base), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.dtype) + extra
+    ent = cache.get(key)
+    if ent is not None and ent[0]() is base and ent[1] == base._version and ent[2] == t.data_ptr():
+        return ent[3]
+    val = make()
+    cache[key] = (weakref.ref(base, lambda _r, k=key, c=cache: c.pop(k, None)), base._version, t.data_ptr(), val)
+    return val
+
+
 def _cast(t: Optional[torch.Tensor], dtype):
-    """t in `dtype`.  Differentiable for a parameter that needs a gradient; otherwise (inference) the cast copy is cached per
-    (storage, version) the way the autocast dispatcher caches its weight casts, so a weight is converted once, not once per call."""
+    """t in `dtype`.  Differentiable for a parameter that needs a gradient; otherwise (inference) the cast copy is cached per tensor object
+    and version the way the autocast dispatcher caches its weight casts, so a weight is converted once, not once per call."""
     if t is None or dtype is None or t.dtype == dtype or not t.is_floating_point():
         return t
     if t.requires_grad and torch.is_grad_enabled():
         return t.to(dtype)
-    key = (t.data_ptr(), t._version, tuple(t.shape), t.dtype, dtype, t.device)
-    hit = _CAST_CACHE.get(key)
-    if hit is None:
-        if len(_CAST_CACHE) > 4096:
-            _CAST_CACHE.clear()
-        hit = _CAST_CACHE[key] = t.detach().to(dtype)
-    return hit
+    return _cached(_CAST_CACHE, t, (dtype,), lambda: t.detach().to(dtype))
 
 
 # --------------------------------------------------------------------------------------------------------------------- fused MLP
@@ -87,16 +99,10 @@ _LEVELS_CACHE: dict = {}
 
 
 def _prefix_levels(attn_mask: torch.Tensor, Lq: int, Lk: int):
-    """cached front of _prefix_levels_uncached: the reference passes the SAME registered buffer (attn_bias_for_masking, or a row slice of
-    it) on every layer of every step, and decoding it costs a device->host copy (a sync) plus a Python walk over its rows - once per
-    (storage, version, shape) instead of once per layer per forward."""
-    key = (attn_mask.data_ptr(), attn_mask._version, tuple(attn_mask.shape), tuple(attn_mask.stride()), attn_mask.dtype, attn_mask.device, Lq, Lk)
-    hit = _LEVELS_CACHE.get(key)
-    if hit is None:
-        if len(_LEVELS_CACHE) > 256:
-            _LEVELS_CACHE.clear()
-        hit = _LEVELS_CACHE[key] = _prefix_levels_uncached(attn_mask, Lq, Lk)
-    return hit
+    """cached front of _prefix_levels_uncached: the reference passes the SAME registered buffer (attn_bias_for_masking, or a view of it) on
+    every layer of every step, and decoding it costs a device->host copy (a sync) plus a Python walk over its rows - once per (buffer,
+    version, view geometry) instead of once per layer per forward.  See _cached for why the key is the tensor object, not its address."""
+    return _cached(_LEVELS_CACHE, attn_mask, (Lq, Lk), lambda: _prefix_levels_uncached(attn_mask, Lq, Lk))
 
 
 def _prefix_levels_uncached(attn_mask: torch.Tensor, Lq: int, Lk: int):

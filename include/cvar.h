@@ -89,6 +89,10 @@ typedef struct {
      * queries of a scale into a scratch buffer and only k | v into the KV arena [R][Lmax][2C] (the reference caches k, v only:
      * basic_var.py:108-111).  Needs remap_l > 0, no activation / gate / residual, split_n, N, ldc, ld_split multiples of 8. */
     void* C_split; int split_n; int64_t ld_split;
+    /* ABI 14: the values of the split columns [0, split_n) are multiplied by split_alpha after the bias (0 is read as 1).  Inference folds
+     * softmax scale * log2(e) into the query rows here - ONE rounding of q * c instead of a multiply per score in the attention kernel
+     * (cvar_attention_prescaled). */
+    float split_alpha;
 } cvar_gemm_desc;
 int cvar_gemm(const cvar_gemm_desc* d, void* stream);
 
@@ -129,6 +133,15 @@ int cvar_attention(const void* qkv, const void* q, int dtype, int R, int H, int 
  * reference the bf16 MFMA flash kernel is A/B-tested against). */
 int cvar_attention_rowwise(const void* qkv, const void* q, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
                            const int* lvl_end_host, int n_lvl, const int* hole_host, void* out, float* lse, void* stream);
+/* ABI 14, inference form only (K/V arena in `kv` + the call's queries in `q`, bf16): the query rows already hold
+ * q * scale * log2(e) (cvar_gemm_desc.split_alpha on the QKV GEMM, or cvar_cos_qk_norm's q_mul for cos-attention), so
+ * softmax(q k^T scale) v = sum_k 2^(q' k) v / sum_k 2^(q' k)  (basic_var.py:99-117, same function).  The kernel subtracts the running maximum on
+ * the matrix pipe (see attn.hip) - one vector operation less per score than cvar_attention. */
+int cvar_attention_prescaled(const void* kv, const void* q, int dtype, int R, int H, int Lmax, int q_off, int l,
+                             const int* lvl_end_host, int n_lvl, const int* hole_host, void* out, float* lse, void* stream);
+/* the round-2 MFMA kernel behind cvar_attention's contract: kept as the in-library A/B reference of the round-3 kernel (tools/attn_bench.py) */
+int cvar_attention_v1(const void* qkv, const void* q, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
+                      const int* lvl_end_host, int n_lvl, const int* hole_host, void* out, float* lse, void* stream);
 /* backward of the level-masked attention (training forward, control_var.py:626-639 under autograd): given dO and the saved
  * lse, writes dQ | dK | dV into dqkv with the arena layout [R][Lmax][3*H*64].  ws: R*H*l floats.  q_off must be 0. */
 int cvar_attention_bwd(const void* qkv, int dtype, const void* o, const void* dout, const float* lse, int R, int H, int Lmax,
@@ -142,7 +155,8 @@ int cvar_attention_bwd_rowwise(const void* qkv, int dtype, const void* o, const 
  * q = normalize(q) * exp(min(scale_mul[h], log 100)),  k = normalize(k).  q (optional): as for cvar_attention - K/V arena in
  * `qkv` + the call's queries [R][l][H*64] in `q`. */
 int cvar_cos_qk_norm(void* qkv, void* q, int dtype, int R, int H, int Lmax, int q_off, int l, const float* scale_mul,
-                     float* norms /* optional [R][l][H][2] = |q|, |k|, saved for training */, void* stream);
+                     float* norms /* optional [R][l][H][2] = |q|, |k|, saved for training */,
+                     float q_mul /* ABI 14: extra factor on the query side (log2(e) in front of cvar_attention_prescaled; 1 otherwise) */, void* stream);
 /* backward of the pre-pass, in place on dqkv (arena layout, q_off 0): gradients w.r.t. the normalised q, k become gradients
  * w.r.t. the raw projections; dsm_tok[R*l][H] receives d loss / d scale_mul per token (summed over tokens by cvar_colsum). */
 int cvar_cos_qk_norm_bwd(const void* qkv, void* dqkv, int dtype, int R, int H, int Lmax, int l, const float* scale_mul,

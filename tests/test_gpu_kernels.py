@@ -574,3 +574,80 @@ def test_conv3x3_halo_kernel_against_torch_and_the_implicit_gemm(gpu_device, B, 
             assert close(outs[cfg], ref, T, bf16_rel=1e-2), (cfg, (outs[cfg] - ref).abs().max().item())
     # both kernels round the same fp32 sums (different summation order) to bf16: at most one bf16 step apart
     assert ((outs[6] - outs[5]).abs() <= (1e-4 if out_f32 else 2.0 ** -7) * (ref.abs() + 1)).all()
+
+
+# ------------------------------------------------------------------------------------------------ round 3: prescaled queries (ABI 14)
+@pytest.mark.parametrize('H,Lmax,q_off,l,levels,holes', [
+    (2, 1360, 848, 512, None, None),                       # last scale of the pyramid: 4 query blocks, 22 KV tiles
+    (3, 400, 110, 72, None, None),                         # partial query block (waves 3 idles), ragged last KV tile
+    (2, 310, 182, 128, None, None),
+    (1, 70, 60, 2, None, None),                            # two queries
+    (2, 300, 0, 300, [2, 10, 28, 60, 110, 182, 300], None),                                    # teacher-forced level mask, whole sequence
+    (2, 120, 40, 80, [20, 40, 80, 120], [(0, 0), (0, 0), (20, 40), (40, 80)]),                 # level holes (indep), cached form
+])
+def test_attention_prescaled_equals_the_reference_softmax(gpu_device, H, Lmax, q_off, l, levels, holes):
+    """cvar_attention_prescaled (query rows carry scale * log2 e; the running maximum is subtracted by a fifth k-step on the matrix pipe and
+    only moves in bf16 steps) against torch fp64 softmax on the SAME bf16 operands, and against cvar_attention on unscaled queries.  One
+    sample's keys carry a spike that forces the maximum to jump late (the rescale branch), another has all scores far below zero."""
+    R, C = 3, H * 64
+    g = torch.Generator().manual_seed(7)
+    kv = torch.randn(R, Lmax, 2 * C, generator=g)
+    q = torch.randn(R, l, C, generator=g)
+    kv[1, min(Lmax - 1, q_off + l - 1) // 2, :C] *= 12.0                   # a key in the middle of row 1 dominates: m~ jumps at its tile
+    q[2] *= 0.05                                                           # near-uniform attention
+    q[0] = q[0].abs() * 3.0; kv[0, :, :C] = -kv[0, :, :C].abs()            # every score of row 0 far below zero (the first tile must move m~ DOWN)
+    scale = 0.125
+    c2 = scale * 1.4426950408889634
+    kvd = kv.to(torch.bfloat16).to(gpu_device)
+    qd = q.to(torch.bfloat16).to(gpu_device)
+    qpd = (q.to(torch.bfloat16).float() * c2).to(torch.bfloat16).to(gpu_device)
+    out_p = torch.empty(R * l, C, device=gpu_device, dtype=torch.bfloat16)
+    out_u = torch.empty_like(out_p)
+    lse = torch.empty(R, H, l, device=gpu_device)
+    ops.attention(kvd, out_p, R, H, Lmax, q_off, l, scale, levels, holes=holes, q=qpd.view(R * l, C), prescaled=True, lse=lse)
+    ops.attention(kvd, out_u, R, H, Lmax, q_off, l, scale, levels, holes=holes, q=qd.view(R * l, C))
+    # reference on the operands the prescaled kernel saw: s_log2 = q' . k
+    kf = kvd.double().cpu()[:, :, :C].view(R, Lmax, H, 64).permute(0, 2, 1, 3)
+    vf = kvd.double().cpu()[:, :, C:].view(R, Lmax, H, 64).permute(0, 2, 1, 3)
+    qf = qpd.double().cpu().view(R, l, H, 64).permute(0, 2, 1, 3)
+    s2 = qf @ kf.transpose(-1, -2)                                            # (R, H, l, Lmax), log2 domain
+    pos = torch.arange(q_off, q_off + l)
+    keys = torch.arange(Lmax)
+    if levels:
+        ends = torch.tensor(levels)
+        lv = torch.searchsorted(ends, pos, right=True)
+        vis = keys[None, :] < ends[lv][:, None]
+        if holes:
+            hl = torch.tensor(holes)[lv]
+            vis &= ~((keys[None, :] >= hl[:, :1]) & (keys[None, :] < hl[:, 1:]))
+    else:
+        vis = (keys[None, :] < q_off + l).expand(l, Lmax)
+    s2 = s2.masked_fill(~vis, float('-inf'))
+    pr = torch.softmax(s2 * math.log(2.0), dim=-1)
+    ref = (pr @ vf).permute(0, 2, 1, 3).reshape(R * l, C)
+    err = (out_p.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1.2e-2, err                                                  # bf16 P and bf16 output
+    ref_lse = torch.logsumexp(s2 * math.log(2.0), dim=-1)
+    assert (lse.double().cpu() - ref_lse).abs().max() < 2e-2
+    # the two kernels differ only by the rounding of q * c2: same function
+    assert (out_p.float() - out_u.float()).abs().max().item() < 4e-2 * out_u.float().abs().max().item()
+
+
+def test_gemm_split_alpha_scales_only_the_split_columns(gpu_device):
+    """cvar_gemm_desc.split_alpha (ABI 14): (acc + bias) * alpha on the columns that go to C_split, one rounding; the arena columns untouched"""
+    R, l, C, K, Lmax, off = 4, 96, 256, 128, 130, 7
+    M, N = R * l, 3 * C
+    A, W, b = to_dev(rnd(M, K, seed=1), torch.bfloat16, gpu_device), to_dev(rnd(N, K, seed=2), torch.bfloat16, gpu_device), rnd(N, seed=3).to(gpu_device)
+    alpha = 0.03125 * 1.4426950408889634
+    outs = []
+    for a in (1.0, alpha):
+        arena = torch.zeros(R, Lmax, 2 * C, device=gpu_device, dtype=torch.bfloat16)
+        qs = torch.zeros(M, C, device=gpu_device, dtype=torch.bfloat16)
+        ops.gemm(A, W, arena, M=M, N=N, K=K, bias=b, ldc=2 * C, remap=(l, Lmax, off), split=(qs, C, C), split_alpha=a)
+        outs.append((arena, qs))
+    assert torch.equal(outs[0][0], outs[1][0])
+    acc = A.float() @ W.float().t()[:, :C] + b[:C]
+    want = (acc * alpha).to(torch.bfloat16)
+    got = outs[1][1]
+    assert (got.float() - want.float()).abs().max().item() <= 2 ** -7 * want.float().abs().max().item()        # accumulation order only: <= 1 bf16 ulp of the largest value
+    assert (got != want).float().mean().item() < 0.02
