@@ -456,8 +456,11 @@ __device__ __forceinline__ s16x4_t lds_tr16_b64(const char* lds_ptr) {
 template <bool HOLES, bool QPRE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_mfma_bf16_kernel(const AttnParams p) {
     constexpr int D = 64, KT = 64;
-    __shared__ __attribute__((aligned(16))) char Ks[KT * 128];
-    __shared__ __attribute__((aligned(16))) char Vs[KT * 128];
+    // one K and one V tile, two barriers per tile.  (Two buffers and one barrier per tile: 7 % SLOWER - profiles/r03_attn_ab3_lds_double_buffer_rejected.txt.)
+    constexpr int TILE_B = KT * 128;
+    __shared__ __attribute__((aligned(16))) char KVs[2 * TILE_B];
+    char* const Ks = KVs;
+    char* const Vs = KVs + TILE_B;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lrow = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
     // ---- block id -> (query block, pair = row * H + head)
@@ -491,13 +494,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // staging map (K and V alike): thread -> keys k_key and k_key + 32, 16-byte chunk k_chunk of the 128-byte head row
     const int k_key = tid >> 3, k_chunk = tid & 7;
     bf16x8_t kreg[2], vreg[2];
+    // buffer loads: the resource covers rows [0, kv_end) of this (row, head)'s K (V) columns, a lane's offset inside a tile never changes
+    // and the tile's base is a scalar - no vector address arithmetic, no predication (rows past kv_end come back as zeros)
+    const int row_bytes = C3 * 2;
+    const int rec = (kv_end - 1) * row_bytes + 128;
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, rec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, rec, 0x00020000);
+    int ld_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ld_off[i] = (k_key + 32 * i) * row_bytes + k_chunk * 16;
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
     auto load_tile = [&](int kt0) {
+        const int so = kt0 * row_bytes;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int key = kt0 + k_key + 32 * i;
-            bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-            kreg[i] = key < kv_end ? *(const bf16x8_t*)(kbase + (long)key * C3 + k_chunk * 8) : z;
-            vreg[i] = key < kv_end ? *(const bf16x8_t*)(vbase + (long)key * C3 + k_chunk * 8) : z;
+            kreg[i] = __builtin_bit_cast(bf16x8_t, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(k_rsrc, ld_off[i], so, 0));
+            vreg[i] = __builtin_bit_cast(bf16x8_t, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(v_rsrc, ld_off[i], so, 0));
         }
     };
     auto store_tile = [&]() {
@@ -537,38 +549,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         __syncthreads();
         if (kt0 + KT < kv_end) load_tile(kt0 + KT);
         if (active) {
-        // ---- S^T = K Q^T
+        // ---- S^T = K Q^T (+ the bias k-step: - m~), invisible keys -> -inf
         f32x16_t s[2];
+        auto scores = [&]() {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-            if constexpr (QPRE && !decltype(FIRST)::value) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_ones, q_m, s[kb], 0, 0, 0);
+                for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+                if constexpr (QPRE && !decltype(FIRST)::value) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_ones, q_m, s[kb], 0, 0, 0);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8_t kf = *(const bf16x8_t*)(Ks + (32 * kb + lrow) * 128 + (((2 * ks + hi) ^ sw) << 4));
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
-            }
-        }
-        float tmax = -INFINITY;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if constexpr (decltype(MASK)::value) {
-                    const int key = kt0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hi;
-                    if (!vis_key_t<HOLES>(vis, key)) s[kb][i] = -INFINITY;
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8_t kf = *(const bf16x8_t*)(Ks + (32 * kb + lrow) * 128 + (((2 * ks + hi) ^ sw) << 4));
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
                 }
-                tmax = fmaxf(tmax, s[kb][i]);
             }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            if constexpr (decltype(MASK)::value) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = kt0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hi;
+                        if (!vis_key_t<HOLES>(vis, key)) s[kb][i] = -INFINITY;
+                    }
+            }
+        };
+        auto row_max = [&]() {
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, s[kb][i]);
+            return fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        };
         bf16x8_t pf[2][2];
+        scores();
         if constexpr (QPRE) {
-            // the accumulators hold s - m~ (log2 domain).  m~ follows the maximum only when a tile exceeds it by more than THR (always on
-            // the first tile, which sets it): then everything still at the old shift - this tile's scores, O, the row sum - moves by
-            // the same delta = m~_new - m~_old (both bf16 values: the fp32 difference is exact)
-            const bool need = decltype(FIRST)::value ? true : tmax > 2.0f + fabsf(m) * 0.015625f;
-            if (decltype(FIRST)::value || __any(need)) {
+            // The accumulators hold s - m~ (log2 domain) and P = 2^that.  m~ is set by the first tile (its exact maximum, rounded to bf16) and
+            // moves later only when a tile's maximum exceeds it by more than 2 + |m~|/64; everything still at the old shift - the tile's
+            // scores, O, the row sum - then moves by the same delta = m~_new - m~_old (both bf16 values: the fp32 difference is exact).
+            auto shift = [&](bool always) {
+                const float tmax = row_max();
+                const bool need = always || tmax > 2.0f + fabsf(m) * 0.015625f;
                 const float m_new = need ? bf16_to_f32(f32_to_bf16(m + tmax)) : m;
                 const float delta = m_new - m;
                 const float alpha = __builtin_amdgcn_exp2f(-delta);
@@ -583,7 +604,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     for (int i = 0; i < 16; ++i) s[kb][i] -= delta;
                 m = m_new;
                 q_m[0] = hi == 0 ? (short)f32_to_bf16(-m_new) : (short)0;
-            }
+            };
+            // (Tried and rejected, profiles/r03_attn_ab4_optimistic_max_rejected.txt: no maximum at all on the hot path - P is bounded by the
+            // tile's row sum, a wave-uniform test of the sum sends the rare tile through a careful second pass.  16 v_max3 fewer per tile,
+            // but the second copy of the tile body costs registers (spills around the loops) and the short scales lose 20-30 %.)
+            if (decltype(FIRST)::value) shift(true);
+            else if (__any(row_max() > 2.0f + fabsf(m) * 0.015625f)) shift(false);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -598,6 +624,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 }
         } else {
             // softmax bookkeeping in the exp2 domain: p = 2^(s*c - m), c = scale*log2(e)  (one fma + one v_exp_f32 per score)
+            const float tmax = row_max();
             const float m_new = fmaxf(m, tmax * c2);            // c2 > 0; finite from the first tile on (key 0 is always visible)
             if (!__all(m_new == m)) {                           // rescale only when some row's running max moved (exact skip)
                 const float alpha = __builtin_amdgcn_exp2f(m - m_new);

@@ -989,7 +989,7 @@ __global__ __launch_bounds__(256) void cvar_splitk_epilogue_kernel(const float* 
             if (grow) x *= grow[n + e] * (p.gate_scale ? p.gate_scale[fast_div(m, p.gate_magic, p.gate_shift)] : 1.0f);
             if (p.residual) x += ld_any(p.residual, p.res_dtype, (long)m * p.ldr + n + e);
             if (p.split_n > 0) {
-                if (n < p.split_n) st_any(p.Cs, p.out_dtype, (long)m * p.ld_split + n + e, x);
+                if (n < p.split_n) st_any(p.Cs, p.out_dtype, (long)m * p.ld_split + n + e, x * p.split_alpha);
                 else st_any(p.C, p.out_dtype, orow * p.ldc + (n - p.split_n) + e, x);
             } else st_any(p.C, p.out_dtype, orow * p.ldc + n + e, x);
         }

@@ -633,9 +633,13 @@ def test_attention_prescaled_equals_the_reference_softmax(gpu_device, H, Lmax, q
     assert (out_p.float() - out_u.float()).abs().max().item() < 4e-2 * out_u.float().abs().max().item()
 
 
-def test_gemm_split_alpha_scales_only_the_split_columns(gpu_device):
+@pytest.mark.parametrize('R,l,C,K', [(4, 96, 256, 128),          # 128x128 tiles (generic epilogue)
+                                     (2, 9, 768, 768),           # small M: split-K slices + the split-K epilogue kernel
+                                     (8, 512, 768, 768)])        # 256x256 tiles (specialised remap epilogue)
+def test_gemm_split_alpha_scales_only_the_split_columns(gpu_device, R, l, C, K):
     """cvar_gemm_desc.split_alpha (ABI 14): (acc + bias) * alpha on the columns that go to C_split, one rounding; the arena columns untouched"""
-    R, l, C, K, Lmax, off = 4, 96, 256, 128, 130, 7
+    ops.ensure_splitk_workspace(gpu_device)
+    Lmax, off = l + 34, 7
     M, N = R * l, 3 * C
     A, W, b = to_dev(rnd(M, K, seed=1), torch.bfloat16, gpu_device), to_dev(rnd(N, K, seed=2), torch.bfloat16, gpu_device), rnd(N, seed=3).to(gpu_device)
     alpha = 0.03125 * 1.4426950408889634
