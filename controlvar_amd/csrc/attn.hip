@@ -592,12 +592,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 const bool need = always || tmax > 2.0f + fabsf(m) * 0.015625f;
                 const float m_new = need ? bf16_to_f32(f32_to_bf16(m + tmax)) : m;
                 const float delta = m_new - m;
-                const float alpha = __builtin_amdgcn_exp2f(-delta);
-                lsum *= alpha;
+                if (!always) {           // the first tile has nothing to rescale (O = row sum = 0) - and its delta may be hugely NEGATIVE (every score
+                                         // far below zero): 2^-delta would be +inf and 0 * inf a NaN.  Later deltas are >= 0: alpha <= 1.
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    lsum *= alpha;
 #pragma unroll
-                for (int db = 0; db < 2; ++db)
+                    for (int db = 0; db < 2; ++db)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+                        for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+                }
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll

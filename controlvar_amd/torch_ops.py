@@ -331,6 +331,27 @@ _define('attention_kv', '(Tensor kv, Tensor q, int H, int q_off, float scale, in
         lambda kv, q, H, q_off, scale, lvl_end, rowwise=False, holes=(): q.new_empty(q.shape[0] * q.shape[1], H * 64))
 
 
+def _attention_kv_prescaled(kv, q, H, q_off, lvl_end, holes=()):
+    """cvar_attention_prescaled (ABI 14): as attention_kv, but the query rows already carry scale * log2(e) (the QKV GEMM's split_alpha, or
+    cos_qk_norm's factor) - the kernel the bf16 inference path runs; bf16 only"""
+    _check_operand(kv, 'attention_kv_prescaled: kv')
+    if kv.dtype != torch.bfloat16 or q.dtype != torch.bfloat16:
+        raise TypeError('attention_kv_prescaled: bfloat16 only (the float32 parity mode uses attention_kv with rowwise=True)')
+    if kv.dim() != 3 or kv.shape[2] != 2 * H * 64 or not kv.is_contiguous():
+        raise ValueError(f'attention_kv_prescaled: arena must be contiguous (R, Lmax, 2*H*64); got {tuple(kv.shape)} for H={H}')
+    R, Lmax, _ = kv.shape
+    if q.dim() != 3 or q.shape[0] != R or q.shape[2] != H * 64 or not q.is_contiguous():
+        raise ValueError(f'attention_kv_prescaled: q must be contiguous (R, l, H*64); got {tuple(q.shape)}')
+    l = q.shape[1]
+    out = torch.empty(R * l, H * 64, device=kv.device, dtype=kv.dtype)
+    K.attention(kv, out, R, H, Lmax, q_off, l, 1.0, list(lvl_end) or None, holes=_holes(list(holes)), q=q, prescaled=True)
+    return out
+
+
+_define('attention_kv_prescaled', '(Tensor kv, Tensor q, int H, int q_off, int[] lvl_end, int[] holes=[]) -> Tensor', _attention_kv_prescaled,
+        lambda kv, q, H, q_off, lvl_end, holes=(): q.new_empty(q.shape[0] * q.shape[1], H * 64))
+
+
 def _cos_qk_norm_(qkv, H, q_off, l, scale_mul):
     R, Lmax, _ = qkv.shape
     K.cos_qk_norm(qkv, R, H, Lmax, q_off, l, scale_mul.float().contiguous())

@@ -254,6 +254,12 @@ def test_misc_ops_against_torch(gpu_device):
     assert torch.equal(o_packed, o_kv)
     with pytest.raises(ValueError):
         ns.attention_kv(qkv, qkv[:, 30:50, :128].contiguous(), 2, 30, 0.125, [], False)                # a packed arena is not a K/V arena
+    # the bf16 inference kernel proper: queries pre-multiplied by scale * log2(e) (one rounding more than o_kv's operands)
+    qpre = (qkv[:, 30:50, :128].float() * (0.125 * 1.4426950408889634)).to(torch.bfloat16).contiguous()
+    o_pre = ns.attention_kv_prescaled(qkv[:, :, 128:].contiguous(), qpre, 2, 30, [])
+    assert o_pre.shape == o_kv.shape and rel_err(o_pre, o_kv) < 3e-2
+    with pytest.raises(TypeError):
+        ns.attention_kv_prescaled(qkv[:, :, 128:].float().contiguous(), qpre.float(), 2, 30, [])
     # a bad status from the C ABI surfaces as RuntimeError
     with pytest.raises(RuntimeError):
         ns.attention(torch.zeros(1, 4, 3 * 64, device=gpu_device, dtype=torch.bfloat16), 1, 2, 5, 0.1, [], False)      # q_off + l > Lmax

@@ -95,6 +95,39 @@ for case in range(n_cases):
         bad += 1
         print('FAIL', case, 'K/V-arena form differs from the packed form', (out2.float() - out.float()).abs().max().item(), flush=True)
         continue
+    # the inference path proper (round 3): queries pre-multiplied by scale * log2 e, maximum subtracted by the bias k-step.  Checked against the
+    # exact row-wise kernel run on the SAME prescaled (re-rounded) queries with scale = ln 2, i.e. the identical function of identical operands.
+    qps_buf = torch.full((R * l * Cq + 2 * pad,), float('nan'), device=dev, dtype=T)
+    qps = qps_buf[pad:pad + R * l * Cq].view(R, l, Cq)
+    qps.copy_((qs.float() * (scale * 1.4426950408889634)).to(T))
+    out3, ref3 = torch.empty_like(out), torch.empty_like(out)
+    ops.attention(kv, out3, R, H, Lmax, q_off, l, scale, levels, holes=holes, q=qps, prescaled=True)
+    ops.attention(kv, ref3, R, H, Lmax, q_off, l, 0.6931471805599453, levels, holes=holes, q=qps, rowwise=True)
+    a3, b3 = out3.float(), ref3.float()
+    err3 = ((a3 - b3).abs() / (b3.abs() + 0.05 * max(1.0, amp))).max().item() if torch.isfinite(a3).all() and torch.isfinite(b3).all() else float('nan')
+    if not (err3 < 0.12):
+        # two kernels that both round P to bf16 can differ by the SUM of their errors on near-one-hot rows (|logit| ~ 50-100 at scale 1, amplitude
+        # 2.5): the judge is the exact softmax (float64) of the same operands - each kernel alone must stay inside the bound
+        kz = kv.clone(); kz[~torch.isfinite(kz)] = 0
+        kk = kz[:, :, :Cq].double().view(R, Lmax, H, 64).permute(0, 2, 1, 3)
+        vv = kz[:, :, Cq:].double().view(R, Lmax, H, 64).permute(0, 2, 1, 3)
+        qq = qps.double().view(R, l, H, 64).permute(0, 2, 1, 3)
+        nk = q_off + l
+        sc = torch.matmul(qq, kk[:, :, :nk].transpose(-1, -2)) * 0.6931471805599453
+        if levels is not None:
+            sc = sc.masked_fill(~visible(Lmax, levels, holes)[q_off:q_off + l, :nk].to(dev), float('-inf'))
+        ex = torch.matmul(torch.softmax(sc, -1), vv[:, :, :nk]).transpose(1, 2).reshape(R * l, Cq).float()
+        e_m = ((a3 - ex).abs() / (ex.abs() + 0.05 * max(1.0, amp))).max().item() if torch.isfinite(a3).all() else float('nan')
+        e_r = ((b3 - ex).abs() / (ex.abs() + 0.05 * max(1.0, amp))).max().item()
+        if not (e_m < 0.15):            # measured over 1 500 cases (seeds 11-13): worst 0.123 at scale 1.0 (|logit| ~ 100: one bf16 ulp of a near-zero output); the row-wise kernel's worst 0.09
+            bad += 1
+            print('FAIL', case, 'prescaled kernel vs exact softmax of the same operands', dict(R=R, H=H, Lmax=Lmax, l=l, q_off=q_off, scale=scale, amp=amp),
+                  'mfma', e_m, 'row-wise', e_r, 'mfma vs row-wise', err3, flush=True)
+            continue
+    if not (torch.isfinite(qps_buf[:pad]).sum() == 0 and torch.isfinite(qps_buf[pad + R * l * Cq:]).sum() == 0):
+        bad += 1
+        print('FAIL', case, 'fence around the prescaled queries damaged', flush=True)
+        continue
     a, b = out.float(), ref.float()
     err = ((a - b).abs() / (b.abs() + 0.05 * max(1.0, amp))).max().item() if torch.isfinite(a).all() and torch.isfinite(b).all() else float('nan')
     ok = err == err and err < 0.12          # bf16 P vs exact fp32 softmax; near one-hot rows (scale 1.0, large logits) sit at 0.07-0.09
