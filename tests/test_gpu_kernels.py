@@ -585,7 +585,8 @@ def test_conv3x3_halo_kernel_against_torch_and_the_implicit_gemm(gpu_device, B, 
     (2, 300, 0, 300, [2, 10, 28, 60, 110, 182, 300], None),                                    # teacher-forced level mask, whole sequence
     (2, 120, 40, 80, [20, 40, 80, 120], [(0, 0), (0, 0), (20, 40), (40, 80)]),                 # level holes (indep), cached form
 ])
-def test_attention_prescaled_equals_the_reference_softmax(gpu_device, H, Lmax, q_off, l, levels, holes):
+@pytest.mark.parametrize('scale', [0.125, 1.0])        # 1.0: row 0's scores sit near -180 in the log2 domain - the first tile's shift is < -128 (round-3 NaN: 0 * 2^180)
+def test_attention_prescaled_equals_the_reference_softmax(gpu_device, H, Lmax, q_off, l, levels, holes, scale):
     """cvar_attention_prescaled (query rows carry scale * log2 e; the running maximum is subtracted by a fifth k-step on the matrix pipe and
     only moves in bf16 steps) against torch fp64 softmax on the SAME bf16 operands, and against cvar_attention on unscaled queries.  One
     sample's keys carry a spike that forces the maximum to jump late (the rescale branch), another has all scores far below zero."""
@@ -596,7 +597,6 @@ def test_attention_prescaled_equals_the_reference_softmax(gpu_device, H, Lmax, q
     kv[1, min(Lmax - 1, q_off + l - 1) // 2, :C] *= 12.0                   # a key in the middle of row 1 dominates: m~ jumps at its tile
     q[2] *= 0.05                                                           # near-uniform attention
     q[0] = q[0].abs() * 3.0; kv[0, :, :C] = -kv[0, :, :C].abs()            # every score of row 0 far below zero (the first tile must move m~ DOWN)
-    scale = 0.125
     c2 = scale * 1.4426950408889634
     kvd = kv.to(torch.bfloat16).to(gpu_device)
     qd = q.to(torch.bfloat16).to(gpu_device)
@@ -626,11 +626,12 @@ def test_attention_prescaled_equals_the_reference_softmax(gpu_device, H, Lmax, q
     pr = torch.softmax(s2 * math.log(2.0), dim=-1)
     ref = (pr @ vf).permute(0, 2, 1, 3).reshape(R * l, C)
     err = (out_p.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
-    assert err < 1.2e-2, err                                                  # bf16 P and bf16 output
+    assert torch.isfinite(out_p.float()).all() and err < (1.2e-2 if scale < 1 else 3e-2), err      # bf16 P and bf16 output; scale 1: near-one-hot rows
     ref_lse = torch.logsumexp(s2 * math.log(2.0), dim=-1)
     assert (lse.double().cpu() - ref_lse).abs().max() < 2e-2
     # the two kernels differ only by the rounding of q * c2: same function
-    assert (out_p.float() - out_u.float()).abs().max().item() < 4e-2 * out_u.float().abs().max().item()
+    if scale < 1:                                                             # (at |logit| ~ 100 the re-rounded query moves near-ties: compared with the exact softmax above only)
+        assert (out_p.float() - out_u.float()).abs().max().item() < 4e-2 * out_u.float().abs().max().item()
 
 
 @pytest.mark.parametrize('R,l,C,K', [(4, 96, 256, 128),          # 128x128 tiles (generic epilogue)
