@@ -70,7 +70,7 @@ SIGNATURES = {
     'cvar_groupnorm_ws_bytes': (c_l, [c_i, c_i, c_i]),
     'cvar_groupnorm_silu': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p]),
     'cvar_softmax_rows': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
-    'cvar_gemm_tn': (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_p]),
+    'cvar_gemm_tn': (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_p, c_p]),
     'cvar_embed_rows': (c_i, [c_p, c_p, c_i, c_p, c_l, c_i, c_p]),
     'cvar_resample_sep': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     'cvar_transpose': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_l, c_l, c_p]),

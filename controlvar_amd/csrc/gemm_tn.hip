@@ -18,6 +18,7 @@ struct GemmTnParams {
     int tiles_k;                 // column tiles of C
     int steps_per_split, nsteps; // K steps (32 tokens) per grid.z slice, total
     long split_stride;           // elements between the partial outputs of consecutive slices (0: single slice writes C directly)
+    float* colsum; long cs_stride;   // optional: colsum[n] = sum_t A[t][n] (the bias gradient of the layer whose dY is A); per-slice stride (0: single slice)
 };
 
 constexpr int TN_BM = 128, TN_BN = 256, TN_BK = 32;
@@ -100,6 +101,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmTnParams
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // bias gradient: column sums of A on the matrix pipe.  Only the workgroups of the first column tile (tk == 0) and in them the waves of the first
+    // column half (wn == 0) carry it: A fragments x a B operand of ones -> every column of the 32x32 result holds sum_t A[t][n]; 4 extra MFMAs per step
+    // for 1 / (2 tiles_k) of the waves instead of a separate pass that re-reads dY (colsum_vec_kernel: 2.3 % of a d24 training step)
+    const bool do_cs = p.colsum != nullptr && tk == 0 && wn == 0;
+    f32x16_t accb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accb[i][r] = 0.f;
+    const bf16x8_t ones8 = {(short)0x3f80, (short)0x3f80, (short)0x3f80, (short)0x3f80, (short)0x3f80, (short)0x3f80, (short)0x3f80, (short)0x3f80};
+
     if (nstep > 0) issue(0, 0);
     if (nstep > 1) issue(1, 1);
     for (int s = 0; s < nstep; ++s) {
@@ -137,6 +149,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmTnParams
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tn_pack(ar[0][i][0], ar[0][i][1]), tn_pack(br[0][j][0], br[0][j][1]), acc[i][j], 0, 0, 0);
+        if (do_cs) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tn_pack(ar[0][i][0], ar[0][i][1]), ones8, accb[i], 0, 0, 0);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(ar[1][0][0]), "+v"(ar[1][0][1]), "+v"(ar[1][1][0]), "+v"(ar[1][1][1]), "+v"(br[1][0][0]), "+v"(br[1][0][1]), "+v"(br[1][1][0]),
                        "+v"(br[1][1][1]), "+v"(br[1][2][0]), "+v"(br[1][2][1]), "+v"(br[1][3][0]), "+v"(br[1][3][1]));
@@ -145,6 +161,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmTnParams
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tn_pack(ar[1][i][0], ar[1][i][1]), tn_pack(br[1][j][0], br[1][j][1]), acc[i][j], 0, 0, 0);
+        if (do_cs) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tn_pack(ar[1][i][0], ar[1][i][1]), ones8, accb[i], 0, 0, 0);
+        }
     }
 
     // D[n][k]: lane holds column k = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 hi of the 32x32 block -> 128-byte row segments per store
@@ -160,10 +180,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmTnParams
                 const int k = k0 + 128 * wn + 32 * j + lrow;
                 cbase[(long)n * p.ldc + k] = acc[i][j][r];
             }
+    if (do_cs && lrow == 0) {                       // column 0 of the block: lanes 0 (hi = 0) and 32 (hi = 1) hold the 32 row sums between them
+        float* cs = p.colsum + (long)blockIdx.z * p.cs_stride;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cs[n0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi] = accb[i][r];
+    }
 }
 
 // out[i] = sum_s part[s][i] in slice order (fixed -> bit-reproducible); row-major [Nn][Kk] partials -> C with leading dimension ldc
-__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, long ldc, int Nn, int Kk, int nsplit) {
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, long ldc, int Nn, int Kk, int nsplit,
+                                                             const float* __restrict__ cs_part, float* __restrict__ cs_out) {
+    if (cs_out && blockIdx.x == 0) {                // the slices' column sums, same fixed order
+        for (int n = threadIdx.x; n < Nn; n += 256) {
+            float v = cs_part[n];
+            for (int s = 1; s < nsplit; ++s) v += cs_part[(long)s * Nn + n];
+            cs_out[n] = v;
+        }
+    }
     const long nvec = (long)Nn * (Kk / 4);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
         const int n = (int)(i / (Kk / 4)), k = (int)(i % (Kk / 4)) * 4;
@@ -178,9 +213,10 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __rest
 }
 
 /* C[Nn][Kk] (fp32, leading dimension ldc) = A^T B with A = [T][lda] (Nn columns used), B = [T][ldb] (Kk columns used), both bf16.
- * Nn % 128 == 0, Kk % 256 == 0; lda, ldb multiples of 8 (any T: the last K step is zero-filled); ws: caller workspace for the token-split partials (may be NULL: one slice). */
+ * Nn % 128 == 0, Kk % 256 == 0; lda, ldb multiples of 8 (any T: the last K step is zero-filled); ws: caller workspace for the token-split partials (may be NULL: one slice).
+ * colsum_a (optional, ABI 14): colsum_a[n] = sum_t A[t][n], the bias gradient of the same layer, from the A fragments the kernel holds anyway. */
 extern "C" int cvar_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int T, int Nn, int Kk,
-                            float* ws, int64_t ws_bytes, void* stream) {
+                            float* ws, int64_t ws_bytes, float* colsum_a, void* stream) {
     if (!A || !B || !C || T <= 0 || Nn <= 0 || Kk <= 0) return CVAR_EINVAL;
     if (Nn % TN_BM || Kk % TN_BN || lda % 8 || ldb % 8 || ldc % 4 || lda < Nn || ldb < Kk || ldc < Kk) return CVAR_EUNSUPPORTED;
     if ((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) || (long)T * lda * 2 >= 0x7fffffffL || (long)T * ldb * 2 >= 0x7fffffffL) return CVAR_EUNSUPPORTED;
@@ -195,7 +231,7 @@ extern "C" int cvar_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
         double best_cost = 1e30;
         for (int sp = 1; sp <= 16; ++sp) {
             if (p.nsteps / sp < 24 && sp > 1) break;
-            if (sp > 1 && (size_t)sp * Nn * Kk * sizeof(float) > (size_t)ws_bytes) break;
+            if (sp > 1 && (size_t)sp * ((size_t)Nn * Kk + (colsum_a ? Nn : 0)) * sizeof(float) > (size_t)ws_bytes) break;
             const double cost = (double)((tiles * sp + 511) / 512) / sp + 0.004 * sp;       // rounds per slice + a price for the partial traffic
             if (cost < best_cost) { best_cost = cost; best = sp; }
         }
@@ -204,13 +240,14 @@ extern "C" int cvar_gemm_tn(const void* A, int64_t lda, const void* B, int64_t l
     const int nsplit = (p.nsteps + p.steps_per_split - 1) / p.steps_per_split;
     hipStream_t st = as_stream(stream);
     if (nsplit == 1) {
-        p.C = C; p.split_stride = 0;
+        p.C = C; p.split_stride = 0; p.colsum = colsum_a; p.cs_stride = 0;
         hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(tiles, 1, 1), dim3(256), 0, st, p);
     } else {
-        p.C = ws; p.ldc = Kk; p.split_stride = (long)Nn * Kk;
+        float* cs_part = colsum_a ? ws + (size_t)nsplit * Nn * Kk : nullptr;          // behind the partial tiles
+        p.C = ws; p.ldc = Kk; p.split_stride = (long)Nn * Kk; p.colsum = cs_part; p.cs_stride = Nn;
         hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(tiles, 1, nsplit), dim3(256), 0, st, p);
         const long nvec = (long)Nn * (Kk / 4);
-        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)min((long)2048, (nvec + 255) / 256)), dim3(256), 0, st, ws, C, (long)ldc, Nn, Kk, nsplit);
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)min((long)2048, (nvec + 255) / 256)), dim3(256), 0, st, ws, C, (long)ldc, Nn, Kk, nsplit, cs_part, colsum_a);
     }
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;

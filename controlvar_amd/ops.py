@@ -145,12 +145,15 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
     return out
 
 
-def gemm_tn(A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, T: int, Nn: int, Kk: int, lda: int = 0, ldb: int = 0, ldc: int = 0, c_off: int = 0):
-    """out[n, k] (fp32) = sum_t A[t, n] * B[t, k] - the weight gradient dW = dY^T X on token-major bf16 operands (cvar_gemm_tn)"""
+def gemm_tn(A: torch.Tensor, B: torch.Tensor, out: torch.Tensor, *, T: int, Nn: int, Kk: int, lda: int = 0, ldb: int = 0, ldc: int = 0, c_off: int = 0,
+            colsum: Optional[torch.Tensor] = None, colsum_off: int = 0):
+    """out[n, k] (fp32) = sum_t A[t, n] * B[t, k] - the weight gradient dW = dY^T X on token-major bf16 operands (cvar_gemm_tn).
+    colsum (fp32, optional): colsum[colsum_off + n] = sum_t A[t, n] - the bias gradient - from the same pass"""
     ws = _SPLITK_WS.get((A.device.index, _stream()))
     if ws is None:
         ws = ensure_splitk_workspace(A.device)
-    check(_lib.load().cvar_gemm_tn(_ptr(A), lda or Nn, _ptr(B), ldb or Kk, _ptr(out) + 4 * c_off, ldc or Kk, T, Nn, Kk, ws.data_ptr(), ws.numel(), _stream()),
+    cs = (_ptr(colsum) + 4 * colsum_off) if colsum is not None else None
+    check(_lib.load().cvar_gemm_tn(_ptr(A), lda or Nn, _ptr(B), ldb or Kk, _ptr(out) + 4 * c_off, ldc or Kk, T, Nn, Kk, ws.data_ptr(), ws.numel(), cs, _stream()),
           'cvar_gemm_tn')
     return out
 

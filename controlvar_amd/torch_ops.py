@@ -97,9 +97,7 @@ def _linear_grads(x, weight, dy, want_bias):
     dw = torch.empty(N, Kd, device=dev, dtype=torch.float32)
     db = torch.empty(N, device=dev, dtype=torch.float32) if want_bias else None
     if T == torch.bfloat16 and N % 128 == 0 and Kd % 256 == 0 and 2 * M * max(N, Kd) < 2 ** 31 - 1:
-        K.gemm_tn(dy2, x2, dw, T=M, Nn=N, Kk=Kd)                       # token-major operands read in place (cvar_gemm_tn): no transposed copies
-        if want_bias:
-            K.colsum(dy2, N, db, M, N, torch.empty(64 * N + 16, device=dev, dtype=torch.float32))
+        K.gemm_tn(dy2, x2, dw, T=M, Nn=N, Kk=Kd, colsum=db)             # token-major operands read in place (cvar_gemm_tn): no transposed copies; db from the same pass
         return dx.view_as(x), dw, db
     ta = torch.zeros(N, Mp, device=dev, dtype=T)
     tb = torch.zeros(Kd, Mp, device=dev, dtype=T)

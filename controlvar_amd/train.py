@@ -370,9 +370,8 @@ class TrainEngine:
         M, Mp = self.M, self.Mp
         if (dY.dtype == torch.bfloat16 and X.dtype == torch.bfloat16 and n_out % 128 == 0 and k_in % 256 == 0
                 and 2 * M * max(n_out, k_in) < 2 ** 31 - 1):
-            ops.gemm_tn(dY, X, G, T=M, Nn=n_out, Kk=k_in, c_off=w_off)
-            if b_off is not None:
-                ops.colsum(dY, n_out, G, M, n_out, self.ws, out_off=b_off)
+            # the bias gradient (column sums of dY) rides on the same pass: ones-operand MFMAs on the dY fragments (round 3; a separate colsum pass before)
+            ops.gemm_tn(dY, X, G, T=M, Nn=n_out, Kk=k_in, c_off=w_off, colsum=G if b_off is not None else None, colsum_off=b_off or 0)
             return
         ops.transpose(dY, self.TA, 1, M, n_out, n_out, ld_out=Mp)
         ops.transpose(X, self.TB, 1, M, k_in, k_in, ld_out=Mp)

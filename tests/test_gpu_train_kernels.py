@@ -282,10 +282,19 @@ def test_gemm_tn_weight_gradient(gpu_device, T, Nn, Kk, lda, ldb):
         ops.gemm(TA, TB, old, M=Nn, N=Kk, K=T)
         assert torch.isfinite(got).all()
         assert ((got - old.cpu()).abs() <= 2e-5 * (old.cpu().abs() + math.sqrt(T))).all()
-    # run-to-run bit-reproducible (the token split is summed in a fixed order)
+    # run-to-run bit-reproducible (the token split is summed in a fixed order); round 3: the bias gradient (column sums of A) from the same pass -
+    # it must not change dW, must equal the exact column sums of the bf16 operand, and must stay inside its Nn floats
     out2 = torch.empty_like(out)
-    ops.gemm_tn(Ad, Bd, out2, T=T, Nn=Nn, Kk=Kk, lda=lda, ldb=ldb, ldc=Kk + 8)
+    csbuf = torch.full((Nn + 64,), float('nan'), device=gpu_device)
+    ops.gemm_tn(Ad, Bd, out2, T=T, Nn=Nn, Kk=Kk, lda=lda, ldb=ldb, ldc=Kk + 8, colsum=csbuf, colsum_off=32)
     assert torch.equal(out2[:Nn, :Kk].cpu(), got)
+    assert torch.isnan(csbuf[:32]).all() and torch.isnan(csbuf[32 + Nn:]).all()
+    cs_ref = A.double().sum(0)
+    cs = csbuf[32:32 + Nn].double().cpu()
+    assert torch.isfinite(cs).all() and ((cs - cs_ref).abs() <= 1e-5 * (cs_ref.abs() + math.sqrt(T))).all(), (cs - cs_ref).abs().max().item()
+    csbuf2 = torch.full_like(csbuf, float('nan'))
+    ops.gemm_tn(Ad, Bd, out2, T=T, Nn=Nn, Kk=Kk, lda=lda, ldb=ldb, ldc=Kk + 8, colsum=csbuf2, colsum_off=32)
+    assert torch.equal(csbuf2[32:32 + Nn], csbuf[32:32 + Nn])
     from controlvar_amd._lib import CvarError
     with pytest.raises(CvarError):
         ops.gemm_tn(Ad, Bd, out, T=T, Nn=Nn - 64, Kk=Kk, lda=lda, ldb=ldb, ldc=Kk + 8)      # Nn must be a multiple of the 128-row tile

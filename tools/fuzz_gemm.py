@@ -34,11 +34,18 @@ def one_tn(case):
     Bw = torch.full((T, ldb), float('nan')); Bw[:, :Kk] = b
     A, B = arena(Aw, torch.bfloat16), arena(Bw, torch.bfloat16)
     out = arena(torch.zeros(Nn, Kk), torch.float32)
-    ops.gemm_tn(A, B, out, T=T, Nn=Nn, Kk=Kk, lda=lda, ldb=ldb)
+    with_cs = rng.random() < 0.5
+    cs = arena(torch.zeros(Nn), torch.float32) if with_cs else None
+    ops.gemm_tn(A, B, out, T=T, Nn=Nn, Kk=Kk, lda=lda, ldb=ldb, colsum=cs)
     ref = a.to(torch.bfloat16).double().t() @ b.to(torch.bfloat16).double()
     got = out.double().cpu()
     err = ((got - ref).abs() / (ref.abs() + math.sqrt(T))).max().item() if torch.isfinite(got).all() else float('nan')
-    return err == err and err < 1e-4, f'gemm_tn T={T} {Nn}x{Kk} lda={lda} ldb={ldb}: err {err:.3e}'
+    if with_cs:                                           # bias gradient from the same pass (ones-operand MFMAs)
+        cref = a.to(torch.bfloat16).double().sum(0)
+        cgot = cs.double().cpu()
+        e2 = ((cgot - cref).abs() / (cref.abs() + math.sqrt(T))).max().item() if torch.isfinite(cgot).all() else float('nan')
+        err = max(err, e2) if e2 == e2 else float('nan')
+    return err == err and err < 1e-4, f'gemm_tn T={T} {Nn}x{Kk} lda={lda} ldb={ldb} colsum={with_cs}: err {err:.3e}'
 
 
 def one(case):
