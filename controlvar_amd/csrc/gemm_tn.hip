@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmTnParams
 // out[i] = sum_s part[s][i] in slice order (fixed -> bit-reproducible); row-major [Nn][Kk] partials -> C with leading dimension ldc
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ C, long ldc, int Nn, int Kk, int nsplit,
                                                              const float* __restrict__ cs_part, float* __restrict__ cs_out) {
-    if (cs_out && blockIdx.x == 0) {                // the slices' column sums, same fixed order
-        for (int n = threadIdx.x; n < Nn; n += 256) {
+    if (cs_out) {                                   // the slices' column sums, same fixed order; spread over the grid (one block doing all of it was the launch's straggler)
+        for (long n = (long)blockIdx.x * 256 + threadIdx.x; n < Nn; n += (long)gridDim.x * 256) {
             float v = cs_part[n];
             for (int s = 1; s < nsplit; ++s) v += cs_part[(long)s * Nn + n];
             cs_out[n] = v;
