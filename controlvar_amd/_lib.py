@@ -83,6 +83,8 @@ SIGNATURES = {
     'cvar_gelu_bwd': (c_i, [c_p, c_p, c_i, c_l, c_p]),
     'cvar_ln_modulate_bwd': (c_i, [c_p, c_p, c_i, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_p, c_p]),
     'cvar_colsum': (c_i, [c_p, c_i, c_l, c_p, c_l, c_i, c_i, c_p, c_p]),
+    'cvar_wordembed_grad_ws_bytes': (c_l, [c_l, c_i]),
+    'cvar_wordembed_grad': (c_i, [c_p, c_l, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     'cvar_rowsum': (c_i, [c_p, c_i, c_l, c_p, c_i, c_i, c_i, c_p]),
     'cvar_ce_fwd_bwd': (c_i, [c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_l, c_i, c_p]),
     'cvar_scatter_add_rows': (c_i, [c_p, c_l, c_p, c_p, c_i, c_i, c_p]),

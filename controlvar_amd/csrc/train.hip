@@ -371,6 +371,68 @@ __global__ void colsum_finalize_kernel(const float* __restrict__ partial, float*
     out[n] = accumulate ? out[n] + a : a;
 }
 // ws: 64 * N floats
+// ------------------------------------------------------------------------------------------------
+// Gradient of word_embed = nn.Linear(Cvae = 32, C) (control_var.py:74) from the token-major tensors as they lie in memory:
+//   dW[c][j] = sum_t dX[row(t)][c] * tok[t][j],   db[c] = sum_t dX[row(t)][c],   t < B * n  (row(t) skips the first `skip` rows of every sample).
+// Round 2 did this with B transposes of dX into a [C][tokens] buffer, one transpose of tok, an fp32 GEMM with a 12-tile grid and K = 43 520
+// (2.5 ms: no parallelism), and B column-sum launches for the bias - 3.9 ms = 1.3 % of a d24 training step.  Here: grid = (C / 64) x slices over the
+// tokens; thread = (tok column j, group of 8 channels); per token 3 loads (tok[t][j] coalesced over j, 2 x 16 B of dX broadcast over j) and 8 fma;
+// the slices' partials are summed in slice order by a second launch (fixed order: bit-reproducible).  fp32 throughout.
+// ------------------------------------------------------------------------------------------------
+constexpr int WEG_CT = 64;          // channels per workgroup
+__global__ __launch_bounds__(256) void wordembed_grad_kernel(const float* __restrict__ dx, long ldx, int rows_per_sample, int skip, const float* __restrict__ tok,
+                                                             int n, long ntok, int C, int tok_per_slice, float* __restrict__ part) {
+    const int j = threadIdx.x & 31, cg = threadIdx.x >> 5;             // 8 channel groups x 8 channels
+    const int c0 = blockIdx.x * WEG_CT + cg * 8;
+    const long t0 = (long)blockIdx.y * tok_per_slice, t1 = min(ntok, t0 + tok_per_slice);
+    float acc[8], accb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { acc[e] = 0.f; accb[e] = 0.f; }
+    int b = (int)(t0 / n), r = (int)(t0 - (long)b * n);
+    const float* xrow = dx + ((long)b * rows_per_sample + skip + r) * ldx + c0;
+    for (long t = t0; t < t1; ++t) {
+        const float w = tok[t * 32 + j];
+        const f32x4_t x0 = *(const f32x4_t*)xrow, x1 = *(const f32x4_t*)(xrow + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[e] = fmaf(x0[e], w, acc[e]); acc[4 + e] = fmaf(x1[e], w, acc[4 + e]); accb[e] += x0[e]; accb[4 + e] += x1[e]; }
+        xrow += ldx;
+        if (++r == n) { r = 0; ++b; xrow = dx + ((long)b * rows_per_sample + skip) * ldx + c0; }
+    }
+    // partials: [slice][C][33] (column 32 = the bias sum, written by the j == 0 lanes)
+    float* o = part + ((long)blockIdx.y * C + c0) * 33;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o[e * 33 + j] = acc[e];
+        if (j == 0) o[e * 33 + 32] = accb[e];
+    }
+}
+__global__ __launch_bounds__(256) void wordembed_grad_reduce_kernel(const float* __restrict__ part, int nslice, int C, float* __restrict__ dW, float* __restrict__ db) {
+    const long total = (long)C * 33;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        float v = part[i];
+        for (int s2 = 1; s2 < nslice; ++s2) v += part[(long)s2 * total + i];
+        const int c = (int)(i / 33), jj = (int)(i % 33);
+        if (jj < 32) dW[(long)c * 32 + jj] = v; else db[c] = v;
+    }
+}
+extern "C" int64_t cvar_wordembed_grad_ws_bytes(int64_t ntok, int C) {
+    const int64_t nslice = ntok >= 32768 ? 32 : (ntok >= 4096 ? 16 : (ntok >= 256 ? 4 : 1));
+    return nslice * (int64_t)C * 33 * (int64_t)sizeof(float);
+}
+extern "C" int cvar_wordembed_grad(const float* dx, int64_t ldx, int rows_per_sample, int skip, const float* tok, int n_per_sample, int B, int C, int Cvae,
+                                   float* dW, float* db, float* ws, void* stream) {
+    if (!dx || !tok || !dW || !db || !ws || B <= 0 || n_per_sample <= 0 || C <= 0 || rows_per_sample < skip + n_per_sample) return CVAR_EINVAL;
+    if (Cvae != 32 || C % WEG_CT || (ldx & 3) || (((uintptr_t)dx | (uintptr_t)ws) & 15)) return CVAR_EUNSUPPORTED;
+    const long ntok = (long)B * n_per_sample;
+    const int nslice = ntok >= 32768 ? 32 : (ntok >= 4096 ? 16 : (ntok >= 256 ? 4 : 1));
+    const int per = (int)((ntok + nslice - 1) / nslice);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(wordembed_grad_kernel, dim3(C / WEG_CT, nslice), dim3(256), 0, st, dx, (long)ldx, rows_per_sample, skip, tok, n_per_sample, ntok, C, per, ws);
+    hipLaunchKernelGGL(wordembed_grad_reduce_kernel, dim3((unsigned)min((long)256, ((long)C * 33 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nslice, C, dW, db);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
 extern "C" int cvar_colsum(const void* A, int dtype, int64_t lda, float* out, int64_t M, int N, int accumulate, float* ws, void* stream) {
     if (!A || !out || !ws || M <= 0 || N <= 0) return CVAR_EINVAL;
     const int nseg = (int)min((int64_t)64, max((int64_t)1, M / 64));

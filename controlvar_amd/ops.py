@@ -333,6 +333,16 @@ def colsum(A, lda, out, M, N, ws, accumulate=False, a_off: int = 0, out_off: int
     check(_lib.load().cvar_colsum(_ptr(A) + a_off * A.element_size(), dt(A), lda, _ptr(out) + 4 * out_off, M, N, int(accumulate), _ptr(ws), _stream()), 'cvar_colsum')
 
 
+def wordembed_grad(dx, ldx: int, rows_per_sample: int, skip: int, tok, n_per_sample: int, B: int, Cdim: int, Cvae: int, out, w_off: int, b_off: int,
+                   dx_off: int = 0):
+    """dW (Cdim x Cvae at out[w_off:]) and db (out[b_off:]) of word_embed from the token-major fp32 tensors (cvar_wordembed_grad)"""
+    lib = _lib.load()
+    nb = lib.cvar_wordembed_grad_ws_bytes(B * n_per_sample, Cdim)
+    ws = torch.empty(nb, device=dx.device, dtype=torch.uint8)
+    check(lib.cvar_wordembed_grad(_ptr(dx) + 4 * dx_off, ldx, rows_per_sample, skip, _ptr(tok), n_per_sample, B, Cdim, Cvae,
+                                  _ptr(out) + 4 * w_off, _ptr(out) + 4 * b_off, _ptr(ws), _stream()), 'cvar_wordembed_grad')
+
+
 def rowsum(A, lda, out, nrows, ncols, accumulate=False, out_off: int = 0):
     check(_lib.load().cvar_rowsum(_ptr(A), dt(A), lda, _ptr(out) + 4 * out_off, nrows, ncols, int(accumulate), _stream()), 'cvar_rowsum')
 

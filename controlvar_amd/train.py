@@ -490,6 +490,10 @@ class TrainEngine:
         src = self.dX if src is None else src
         rows = L if src_has_first else L - fl
         skip = fl if src_has_first else 0
+        if cfg.cvae == 32 and C % 64 == 0 and tok.dtype == torch.float32 and src.dtype == torch.float32:
+            # one pass over the token-major tensors (round 3): dW and db together, no transposes, no per-sample launches
+            ops.wordembed_grad(src, C, rows, skip, tok, L - fl, B, C, cfg.cvae, Gm, mo['w_we'][0], mo['b_we'][0])
+            return
         for b in range(B):      # gradient rows of sample b -> columns [b*(L-fl), (b+1)*(L-fl)) of TA32 ([C][Mtp])
             ops.transpose(src, self.TA32[b * (L - fl):], 1, L - fl, C, C, in_off=(b * rows + skip) * C, ld_out=Mtp)
         ops.transpose(tok, self.TB32, 1, Mt, cfg.cvae, cfg.cvae, ld_out=Mtp)
@@ -659,8 +663,13 @@ class Trainer:
     @torch.no_grad()
     def tokenize(self, images: torch.Tensor, masks: torch.Tensor, mask_first: bool = True):
         """frozen tokenizer + 'interleave_append' (mask first unless bidirectional drew image first): train_control_var_hpu.py:157-204"""
-        mi = self.vae.img_to_idxBl(masks); mh = self.vae.idxBl_to_h(mi)
-        ii = self.vae.img_to_idxBl(images); ih = self.vae.idxBl_to_h(ii)
+        # one tokenizer pass over [masks ; images] (the reference makes two calls, :160-176; every image is quantised on its own, so the ids are the
+        # same): the ten-scale residual quantiser is one latency-bound launch of ~2.7 ms whatever the batch, and the conv stack sees twice the tiles
+        B = masks.shape[0]
+        both = self.vae.img_to_idxBl(torch.cat((masks, images), dim=0))
+        hboth = self.vae.idxBl_to_h(both)
+        mi, ii = [t[:B] for t in both], [t[B:] for t in both]
+        mh, ih = [t[:B] for t in hboth], [t[B:] for t in hboth]
         if not mask_first:
             mi, ii, mh, ih = ii, mi, ih, mh
         x = torch.cat([torch.cat((a, b), 1) for a, b in zip(mh, ih)], dim=1)

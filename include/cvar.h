@@ -255,6 +255,13 @@ int cvar_gelu_bwd(const void* a, void* dh, int dtype, int64_t n, void* stream); 
 int cvar_ln_modulate_bwd(const float* x, const void* dy, int dtype, const float* scale, int64_t ld_ada, int rows_per,
                          const float* dx_in, float* dx_out, float* dscale, float* dshift, int64_t ldo,
                          int M, int C, float eps, float* ws, void* stream);
+/* ABI 14.  Gradient of word_embed = nn.Linear(Cvae, C) (control_var.py:74; its input is the token tensor of idxBl_to_var_input) from the token-major
+ * fp32 tensors in place: dW[c][j] = sum_t dx[row(t)][c] * tok[t][j], db[c] = sum_t dx[row(t)][c], t < B * n_per_sample, row(t) = (t / n) *
+ * rows_per_sample + skip + t % n (the first `skip` positions of every sample are not word-embedded).  Cvae == 32, C % 64 == 0.
+ * ws: cvar_wordembed_grad_ws_bytes(B * n_per_sample, C) bytes (per-slice partials, summed in a fixed order). */
+int64_t cvar_wordembed_grad_ws_bytes(int64_t ntok, int C);
+int cvar_wordembed_grad(const float* dx, int64_t ldx, int rows_per_sample, int skip, const float* tok, int n_per_sample, int B, int C, int Cvae,
+                        float* dW, float* db, float* ws, void* stream);
 /* out[n] (+)= sum_m A[m,n]  (bias gradients).  ws: 64*N floats. */
 int cvar_colsum(const void* A, int dtype, int64_t lda, float* out, int64_t M, int N, int accumulate, float* ws, void* stream);
 /* out[r] (+)= sum_j A[r][j], j < ncols (16-byte aligned rows): the same bias gradient read from the transposed dY that the

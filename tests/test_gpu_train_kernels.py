@@ -298,3 +298,27 @@ def test_gemm_tn_weight_gradient(gpu_device, T, Nn, Kk, lda, ldb):
     from controlvar_amd._lib import CvarError
     with pytest.raises(CvarError):
         ops.gemm_tn(Ad, Bd, out, T=T, Nn=Nn - 64, Kk=Kk, lda=lda, ldb=ldb, ldc=Kk + 8)      # Nn must be a multiple of the 128-row tile
+
+
+@pytest.mark.parametrize('B,n,rows,skip,C', [(3, 50, 52, 2, 128), (4, 1358, 1360, 2, 192), (2, 7, 7, 0, 64), (32, 1358, 1360, 2, 1536)])
+def test_wordembed_grad_against_torch(gpu_device, B, n, rows, skip, C):
+    """cvar_wordembed_grad (ABI 14): dW = dX^T tok and db = column sums of dX over the word-embedded rows of every sample (the first `skip` rows
+    of a sample are not), straight from the token-major fp32 tensors, against float64; the skipped rows are NaN so that a wrong row map shows."""
+    g = torch.Generator().manual_seed(B * 1000 + n)
+    dx = torch.randn(B, rows, C, generator=g)
+    tok = torch.randn(B * n, 32, generator=g)
+    dxd = dx.clone()
+    dxd[:, :skip] = float('nan')
+    dxd = dxd.to(gpu_device)
+    out = torch.full((C * 32 + C + 16,), float('nan'), device=gpu_device)
+    ops.wordembed_grad(dxd.view(B * rows, C), C, rows, skip, tok.to(gpu_device), n, B, C, 32, out, 8, 8 + C * 32)
+    used = dx[:, skip:skip + n].reshape(B * n, C).double()
+    dW = used.t() @ tok.double()
+    db = used.sum(0)
+    got_w, got_b = out[8:8 + C * 32].view(C, 32).double().cpu(), out[8 + C * 32:8 + C * 32 + C].double().cpu()
+    assert torch.isnan(out[:8]).all() and torch.isnan(out[8 + C * 32 + C:]).all()
+    tol = 2e-6 * math.sqrt(B * n)
+    assert (got_w - dW).abs().max() < tol * max(1.0, dW.abs().max().item()) and (got_b - db).abs().max() < tol * max(1.0, db.abs().max().item())
+    out2 = torch.empty_like(out)
+    ops.wordembed_grad(dxd.view(B * rows, C), C, rows, skip, tok.to(gpu_device), n, B, C, 32, out2, 8, 8 + C * 32)
+    assert torch.equal(out2[8:8 + C * 33], out[8:8 + C * 33])                    # fixed summation order
