@@ -4,7 +4,23 @@
 // All reductions are two-level with a fixed order (no atomics): results are bit-reproducible.
 #include "cvar_common.h"
 
-constexpr int RED_S = 8;      // row segments of the per-sequence column reductions
+constexpr int RED_S = 8;      // row segments of the per-sequence column reductions (scalar fallbacks)
+// The vector kernels split every sequence into red_segments(R, l) row segments so that R * segments blocks fill the chip
+// (8 segments x 32 sequences left 3/4 of the wave slots empty and the kernels ran at 2.2-2.8 TB/s).
+#ifndef CVAR_RED_TARGET
+#define CVAR_RED_TARGET 512       // ln_modulate_bwd: blocks of 4 waves at 2 waves per SIMD -> 512 blocks are exactly one resident round
+#endif
+#ifndef CVAR_GG_TARGET
+#define CVAR_GG_TARGET 256        // gated_grad: x ceil(C/512) blocks of 2 waves
+#endif
+constexpr int RED_S_MAX = 64;
+static inline int red_segments(int R, int l, int target) { return max(1, min(min(RED_S_MAX, (target + R - 1) / max(R, 1)), (l + 3) / 4)); }
+static inline int red_segments_max(int R) { return max(RED_S, red_segments(R, 1 << 20, max(CVAR_RED_TARGET, CVAR_GG_TARGET))); }
+// floats of workspace the per-sequence reductions (cvar_gated_grad, cvar_ln_modulate_bwd) may use for M = R * l rows
+extern "C" int64_t cvar_train_ws_floats(int64_t M, int R, int C) {
+    if (M <= 0 || R <= 0 || C <= 0) return 0;
+    return 2 * M + 2 * (int64_t)red_segments_max(R) * R * C;
+}
 
 // x[m,c] += gate[r,c] * rowscale[r] * f[m,c]          (x + drop_path(gamma * f(x)), basic_var.py:208-209)
 template <typename T>
@@ -90,11 +106,11 @@ __global__ __launch_bounds__(256) void gated_grad_kernel(const float* __restrict
 // four channels per thread (16-byte dx loads, 8-byte f / df accesses); per-channel summation order over the tokens is unchanged -> bit-identical
 __global__ __launch_bounds__(128) void gated_grad_vec_kernel(const float* __restrict__ dx, const bf16_t* __restrict__ f, const float* __restrict__ gate,
                                                             long ldg, const float* __restrict__ rowscale, bf16_t* __restrict__ df,
-                                                            float* __restrict__ partial, int R, int l, int C) {
+                                                            float* __restrict__ partial, int R, int l, int C, int nseg) {
     const int c = (blockIdx.x * 128 + threadIdx.x) * 4;
     const int r = blockIdx.y, s = blockIdx.z;
     if (c >= C) return;
-    const int seg = (l + RED_S - 1) / RED_S;
+    const int seg = (l + nseg - 1) / nseg;
     const int t0 = s * seg, t1 = min(l, t0 + seg);
     const float rs = rowscale ? rowscale[r] : 1.0f;
     const f32x4_t g4 = *(const f32x4_t*)(gate + (long)r * ldg + c);
@@ -132,12 +148,13 @@ extern "C" int cvar_gated_grad(const float* dx, const void* f, int dtype, const 
     dim3 grid(cdiv(C, 256), R, RED_S), block(256);
     const bool vec = dtype == CVAR_BF16 && C % 4 == 0 && ldg % 4 == 0 && ((((uintptr_t)dx | (uintptr_t)gate | (uintptr_t)ws) & 15) == 0) &&
                      ((((uintptr_t)f | (uintptr_t)df) & 7) == 0);
-    if (vec) hipLaunchKernelGGL(gated_grad_vec_kernel, dim3(cdiv(C, 512), R, RED_S), dim3(128), 0, as_stream(stream), dx, (const bf16_t*)f, gate, (long)ldg, rowscale,
-                                (bf16_t*)df, ws, R, l, C);
+    const int nseg = vec ? red_segments(R, l, CVAR_GG_TARGET) : RED_S;
+    if (vec) hipLaunchKernelGGL(gated_grad_vec_kernel, dim3(cdiv(C, 512), R, nseg), dim3(128), 0, as_stream(stream), dx, (const bf16_t*)f, gate, (long)ldg, rowscale,
+                                (bf16_t*)df, ws, R, l, C, nseg);
     else if (dtype == CVAR_BF16) hipLaunchKernelGGL(gated_grad_kernel<bf16_t>, grid, block, 0, as_stream(stream), dx, (const bf16_t*)f, gate, (long)ldg, rowscale, (bf16_t*)df, ws, R, l, C);
     else if (dtype == CVAR_F32) hipLaunchKernelGGL(gated_grad_kernel<float>, grid, block, 0, as_stream(stream), dx, (const float*)f, gate, (long)ldg, rowscale, (float*)df, ws, R, l, C);
     else return CVAR_EUNSUPPORTED;
-    hipLaunchKernelGGL(red_finalize_kernel, dim3(cdiv(C, 256), R), block, 0, as_stream(stream), ws, dgate, (long)ldo, rowscale, R, C, RED_S);
+    hipLaunchKernelGGL(red_finalize_kernel, dim3(cdiv(C, 256), R), block, 0, as_stream(stream), ws, dgate, (long)ldo, rowscale, R, C, nseg);
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;
 }
@@ -276,11 +293,11 @@ __global__ __launch_bounds__(256) void ln_bwd_col_kernel(const float* __restrict
 }
 // four channels per thread; same per-channel order over the tokens -> bit-identical to ln_bwd_col_kernel
 __global__ __launch_bounds__(128) void ln_bwd_col_vec_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy, const float* __restrict__ stats,
-                                                            float* __restrict__ partial, int R, int l, int C) {
+                                                            float* __restrict__ partial, int R, int l, int C, int nseg) {
     const int c = (blockIdx.x * 128 + threadIdx.x) * 4;
     const int r = blockIdx.y, s = blockIdx.z;
     if (c >= C) return;
-    const int seg = (l + RED_S - 1) / RED_S;
+    const int seg = (l + nseg - 1) / nseg;
     const int t0 = s * seg, t1 = min(l, t0 + seg);
     float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
@@ -300,16 +317,149 @@ __global__ __launch_bounds__(128) void ln_bwd_col_vec_kernel(const float* __rest
     *(f32x4_t*)(partial + (((long)s * R + r) * 2 + 0) * C + c) = a4;
     *(f32x4_t*)(partial + (((long)s * R + r) * 2 + 1) * C + c) = b4;
 }
-__global__ void ln_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dscale, float* __restrict__ dshift, long ldo, int R, int C) {
+
+#ifndef CVAR_LNF_LEAN
+#define CVAR_LNF_LEAN 0
+#endif
+// Row and column parts in ONE pass (bf16 dy): a block owns a row segment of one sequence, its four waves stride over the rows
+// with the row in registers as above and keep the column sums (dy * xhat, dy) of their rows in registers; the waves are
+// folded through LDS in a fixed order and the block writes partial[s][r][{0,1}][c] for ln_bwd_finalize_kernel.
+// x, dy and dx_in are read once (the two-kernel form read x and dy twice: 670 MB instead of 469 MB per call at 21760 x 1536).
+template <int NV, bool TAIL>
+__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy, const float* __restrict__ scale,
+                                                          long ld_ada, int rows_per, const float* __restrict__ dx_in, float* __restrict__ dx_out,
+                                                          float* __restrict__ partial, int R, int C, float eps, int seg_rows) {
+    __shared__ f32x4_t red[3][2][NV * 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int s = blockIdx.x, r = blockIdx.y;
+    const int t0 = s * seg_rows, t1 = min(rows_per, t0 + seg_rows);
+    const float* sc = scale + (long)r * ld_ada;
+    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t s1[NV], ca[NV], cb[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        const bool ok = !(TAIL && i == NV - 1) || c < C;
+        const f32x4_t s4 = ok ? *(const f32x4_t*)(sc + c) : zero4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s1[i][e] = 1.0f + s4[e];
+        ca[i] = zero4; cb[i] = zero4;
+    }
+    for (int t = t0 + w; t < t1; t += 4) {
+        const long row = (long)r * rows_per + t;
+        const float* xr = x + row * C;
+        const bf16_t* dyr = dy + row * C;
+        f32x4_t xv[NV], dv[NV];
+#if !CVAR_LNF_LEAN
+        f32x4_t din[NV];
+#endif
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            const bool ok = !(TAIL && i == NV - 1) || c < C;
+            xv[i] = ok ? *(const f32x4_t*)(xr + c) : zero4;
+            bf16x4_t dq = {0, 0, 0, 0};
+            if (ok) dq = *(const bf16x4_t*)(dyr + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dv[i][e] = bf16_to_f32((bf16_t)dq[e]);
+#if !CVAR_LNF_LEAN
+            din[i] = (ok && dx_in) ? *(const f32x4_t*)(dx_in + row * C + c) : zero4;
+#endif
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sum += (xv[i][0] + xv[i][1]) + (xv[i][2] + xv[i][3]);
+        const float mu = wave_sum(sum) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            const bool ok = !(TAIL && i == NV - 1) || c < C;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xv[i][e] = ok ? xv[i][e] - mu : 0.f; q += xv[i][e] * xv[i][e]; }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xv[i][e] *= rstd;
+                const float g = dv[i][e] * s1[i][e];
+                sg += g; sgx += g * xv[i][e];
+                ca[i][e] += dv[i][e] * xv[i][e];
+                cb[i][e] += dv[i][e];
+            }
+        const float mg = wave_sum(sg) / (float)C, mgx = wave_sum(sgx) / (float)C;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (TAIL && i == NV - 1 && c >= C) continue;
+            f32x4_t o;
+#if CVAR_LNF_LEAN
+            const f32x4_t dn = dx_in ? *(const f32x4_t*)(dx_in + row * C + c) : zero4;
+#else
+            const f32x4_t dn = din[i];
+#endif
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = dn[e] + rstd * (dv[i][e] * s1[i][e] - mg - xv[i][e] * mgx);
+            *(f32x4_t*)(dx_out + row * C + c) = o;
+        }
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { red[w - 1][0][i * 64 + lane] = ca[i]; red[w - 1][1][i * 64 + lane] = cb[i]; }
+    }
+    __syncthreads();
+    if (w == 0) {
+        float* pa = partial + (((long)s * R + r) * 2 + 0) * C;
+        float* pb = partial + (((long)s * R + r) * 2 + 1) * C;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (TAIL && i == NV - 1 && c >= C) continue;
+            f32x4_t a = ca[i], b = cb[i];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const f32x4_t ra = red[k][0][i * 64 + lane], rb = red[k][1][i * 64 + lane];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] += ra[e]; b[e] += rb[e]; }
+            }
+            *(f32x4_t*)(pa + c) = a;
+            *(f32x4_t*)(pb + c) = b;
+        }
+    }
+}
+static bool ln_bwd_fused_launch(const float* x, const bf16_t* dy, const float* scale, long ld_ada, int rows_per, const float* dx_in, float* dx_out,
+                                float* partial, int R, int C, float eps, int nseg, hipStream_t st) {
+    if (C % 4 || C > 2048 || ld_ada % 4 || (((uintptr_t)x | (uintptr_t)scale | (uintptr_t)dx_out | (uintptr_t)dx_in | (uintptr_t)partial) & 15) ||
+        ((uintptr_t)dy & 7)) return false;
+    const int nv = (C + 255) / 256;
+    const bool tail = (C % 256) != 0;
+    const int seg_rows = (rows_per + nseg - 1) / nseg;
+    const dim3 grid(nseg, R), block(256);
+#define CVAR_LNF(NVV)                                                                                                                                    \
+    case NVV:                                                                                                                                            \
+        if (tail) hipLaunchKernelGGL((ln_bwd_fused_kernel<NVV, true>), grid, block, 0, st, x, dy, scale, ld_ada, rows_per, dx_in, dx_out, partial, R, C, eps, seg_rows); \
+        else hipLaunchKernelGGL((ln_bwd_fused_kernel<NVV, false>), grid, block, 0, st, x, dy, scale, ld_ada, rows_per, dx_in, dx_out, partial, R, C, eps, seg_rows);     \
+        return true;
+    switch (nv) { CVAR_LNF(1) CVAR_LNF(2) CVAR_LNF(3) CVAR_LNF(4) CVAR_LNF(5) CVAR_LNF(6) CVAR_LNF(7) CVAR_LNF(8) default: return false; }
+#undef CVAR_LNF
+}
+__global__ void ln_bwd_finalize_kernel(const float* __restrict__ partial, float* __restrict__ dscale, float* __restrict__ dshift, long ldo, int R, int C,
+                                       int nseg) {
     const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
     if (c >= C) return;
     float a = 0.f, b = 0.f;
-    for (int s = 0; s < RED_S; ++s) { a += partial[(((long)s * R + r) * 2 + 0) * C + c]; b += partial[(((long)s * R + r) * 2 + 1) * C + c]; }
+    for (int s = 0; s < nseg; ++s) { a += partial[(((long)s * R + r) * 2 + 0) * C + c]; b += partial[(((long)s * R + r) * 2 + 1) * C + c]; }
     dscale[(long)r * ldo + c] = a;
     dshift[(long)r * ldo + c] = b;
 }
 
-// ws: M*2 floats (row stats) + RED_S*R*2*C floats
+// ws: cvar_train_ws_floats(M, R, C) floats (row stats of the two-kernel form + the segment partials)
+#ifndef CVAR_LN_BWD_FUSED
+#define CVAR_LN_BWD_FUSED 1
+#endif
 extern "C" int cvar_ln_modulate_bwd(const float* x, const void* dy, int dtype, const float* scale, int64_t ld_ada, int rows_per,
                                     const float* dx_in, float* dx_out, float* dscale, float* dshift, int64_t ldo,
                                     int M, int C, float eps, float* ws, void* stream) {
@@ -318,19 +468,27 @@ extern "C" int cvar_ln_modulate_bwd(const float* x, const void* dy, int dtype, c
     float* stats = ws;
     float* partial = ws + 2 * (size_t)M;
     dim3 b256(256);
+    int nseg = RED_S;
     if (dtype == CVAR_BF16) {
-        if (!ln_bwd_row_vec_launch<bf16_t>(x, (const bf16_t*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps, as_stream(stream)))
-            hipLaunchKernelGGL(ln_bwd_row_kernel<bf16_t>, dim3(cdiv(M, 4)), b256, 0, as_stream(stream), x, (const bf16_t*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps);
-        if (C % 4 == 0 && ((((uintptr_t)x | (uintptr_t)partial) & 15) == 0) && (((uintptr_t)dy & 7) == 0))
-            hipLaunchKernelGGL(ln_bwd_col_vec_kernel, dim3(cdiv(C, 512), R, RED_S), dim3(128), 0, as_stream(stream), x, (const bf16_t*)dy, stats, partial, R, rows_per, C);
-        else
-            hipLaunchKernelGGL(ln_bwd_col_kernel<bf16_t>, dim3(cdiv(C, 256), R, RED_S), b256, 0, as_stream(stream), x, (const bf16_t*)dy, stats, partial, R, rows_per, C);
+        const int nv = red_segments(R, rows_per, CVAR_RED_TARGET);
+        if (CVAR_LN_BWD_FUSED && ln_bwd_fused_launch(x, (const bf16_t*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, partial, R, C, eps, nv, as_stream(stream))) {
+            nseg = nv;
+        } else {
+            if (!ln_bwd_row_vec_launch<bf16_t>(x, (const bf16_t*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps, as_stream(stream)))
+                hipLaunchKernelGGL(ln_bwd_row_kernel<bf16_t>, dim3(cdiv(M, 4)), b256, 0, as_stream(stream), x, (const bf16_t*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps);
+            if (C % 4 == 0 && ((((uintptr_t)x | (uintptr_t)partial) & 15) == 0) && (((uintptr_t)dy & 7) == 0)) {
+                nseg = nv;
+                hipLaunchKernelGGL(ln_bwd_col_vec_kernel, dim3(cdiv(C, 512), R, nseg), dim3(128), 0, as_stream(stream), x, (const bf16_t*)dy, stats, partial, R, rows_per, C, nseg);
+            } else {
+                hipLaunchKernelGGL(ln_bwd_col_kernel<bf16_t>, dim3(cdiv(C, 256), R, RED_S), b256, 0, as_stream(stream), x, (const bf16_t*)dy, stats, partial, R, rows_per, C);
+            }
+        }
     } else if (dtype == CVAR_F32) {
         if (!ln_bwd_row_vec_launch<float>(x, (const float*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps, as_stream(stream)))
             hipLaunchKernelGGL(ln_bwd_row_kernel<float>, dim3(cdiv(M, 4)), b256, 0, as_stream(stream), x, (const float*)dy, scale, (long)ld_ada, rows_per, dx_in, dx_out, stats, M, C, eps);
         hipLaunchKernelGGL(ln_bwd_col_kernel<float>, dim3(cdiv(C, 256), R, RED_S), b256, 0, as_stream(stream), x, (const float*)dy, stats, partial, R, rows_per, C);
     } else return CVAR_EUNSUPPORTED;
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(cdiv(C, 256), R), b256, 0, as_stream(stream), partial, dscale, dshift, (long)ldo, R, C);
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(cdiv(C, 256), R), b256, 0, as_stream(stream), partial, dscale, dshift, (long)ldo, R, C, nseg);
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;
 }
@@ -585,7 +743,7 @@ extern "C" int cvar_clip_coef(const double* partials, int64_t count, float pre_s
 // ---- multi-tensor forms: one launch over a device table of tensors instead of one launch per parameter (a d24 model has ~830
 // parameters; 2 x 830 tiny launches were 3 % of the training step).  Per tensor the arithmetic and the summation order are
 // exactly those of cvar_sumsq / cvar_adamw (blockIdx.y selects the tensor, blockIdx.x plays the single-tensor grid).
-struct AdamTensor { float* p; const float* g; float* m; float* v; long n; int group; int pad; };
+struct AdamTensor { float* p; const float* g; float* m; float* v; long n; int group; int pad; bf16_t* w16; };
 
 __global__ __launch_bounds__(256) void sumsq_multi_kernel(const AdamTensor* __restrict__ tab, double* __restrict__ out) {
     __shared__ double red[4];
@@ -618,6 +776,7 @@ __global__ void adamw_multi_kernel(const AdamTensor* __restrict__ tab, const Ada
         const float vv = b2 * t.v[i] + (1.0f - b2) * g * g;
         pv -= (lr / bc1) * mv / (sqrtf(vv) / bc2_sqrt + eps);
         t.p[i] = pv; t.m[i] = mv; t.v[i] = vv;
+        if (t.w16) t.w16[i] = f32_to_bf16(pv);      // the GEMM-ready bf16 copy of a weight matrix, refreshed while the value is in a register
     }
 }
 extern "C" int cvar_adamw_multi(const void* table_dev, int n_tensors, const float* lr_by_group_host, const float* wd_by_group_host, int n_groups,

@@ -594,12 +594,39 @@ class ControlVAR(nn.Module):
     def _state_sig(self):
         return _tensor_sig(self)
 
-    def _pack(self, check: bool = False):
+    def _matrix_copies(self) -> Tuple[Dict[str, torch.Tensor], Tuple[str, ...]]:
+        """(state_dict key -> the contiguous slice of the packed copies that holds exactly this weight matrix, the packed keys those
+        slices cover completely).  The fused optimizer writes the rounded update straight into the slices (cvar_adam_tensor.w16)
+        and then calls _pack(fresh=keys); bf16 compute only (the fp32 form keeps no separate rounding)."""
+        P, cfg = self._pack(), self.cfg
+        C, depth = cfg.C, cfg.depth
+        if self.compute_dtype != torch.bfloat16:
+            return {}, ()
+        out: Dict[str, torch.Tensor] = {}
+        keys = ['w_qkv', 'w_proj', 'w_fc1', 'w_fc2', 'w_head']
+        for i in range(depth):
+            for key, name in (('w_qkv', 'attn.mat_qkv.weight'), ('w_proj', 'attn.proj.weight'), ('w_fc1', 'ffn.fc1.weight'), ('w_fc2', 'ffn.fc2.weight')):
+                out[f'blocks.{i}.{name}'] = P[key][i]
+        if not cfg.sa_block and not cfg.shared_aln:       # the other two forms derive w_ada (zeros / one shared matrix per block)
+            for i in range(depth):
+                out[f'blocks.{i}.ada_lin.1.weight'] = P['w_ada'][i * 6 * C:(i + 1) * 6 * C]
+            out['head_nm.ada_lin.1.weight'] = P['w_ada'][depth * 6 * C:]
+            keys.append('w_ada')
+        hw = 'head.1.weight' if cfg.sa_block else 'head.weight'
+        out[hw] = P['w_head'][:cfg.head_out]
+        return out, tuple(keys)
+
+    def _pack(self, check: bool = False, fresh: Sequence[str] = ()):
         """GEMM-ready device copies of the weights (stacked per kind, compute dtype).  check=True (every public entry point and
         the training engine's forward): rebuild when any parameter changed since - torch.optim steps through the autograd bridge,
-        manual in-place edits, .data swaps (the copies used to go stale on that path)."""
-        if self._packed is not None and (not check or self._packed_sig == self._state_sig()):
+        manual in-place edits, .data swaps (the copies used to go stale on that path).
+        fresh: keys of the current copies that are already up to date (the fused optimizer updated them in its own pass) - those tensors
+        are kept, everything else is rebuilt from the parameters."""
+        if not fresh and self._packed is not None and (not check or self._packed_sig == self._state_sig()):
             return self._packed
+        old = self._packed if fresh else None
+        if fresh and old is None:
+            raise RuntimeError('_pack(fresh=...) without packed copies to keep')
         dev, T, cfg = self.device, self.compute_dtype, self.cfg
         if dev.type != 'cuda':
             raise RuntimeError('controlvar_amd models compute on the GPU only; call .to("cuda") first')
@@ -608,14 +635,14 @@ class ControlVAR(nn.Module):
         C, depth = cfg.C, cfg.depth
         P: Dict[str, Any] = {}
         blk = lambda i, s: sd[f'blocks.{i}.{s}']
-        P['w_qkv'] = torch.stack([blk(i, 'attn.mat_qkv.weight') for i in range(depth)]).to(T).contiguous()
+        P['w_qkv'] = old['w_qkv'] if 'w_qkv' in fresh else torch.stack([blk(i, 'attn.mat_qkv.weight') for i in range(depth)]).to(T).contiguous()
         P['b_qkv'] = torch.stack([torch.cat((blk(i, 'attn.q_bias'), torch.zeros_like(blk(i, 'attn.q_bias')), blk(i, 'attn.v_bias')))
                                   for i in range(depth)]).float().contiguous()
-        P['w_proj'] = torch.stack([blk(i, 'attn.proj.weight') for i in range(depth)]).to(T).contiguous()
+        P['w_proj'] = old['w_proj'] if 'w_proj' in fresh else torch.stack([blk(i, 'attn.proj.weight') for i in range(depth)]).to(T).contiguous()
         P['b_proj'] = torch.stack([blk(i, 'attn.proj.bias') for i in range(depth)]).float().contiguous()
-        P['w_fc1'] = torch.stack([blk(i, 'ffn.fc1.weight') for i in range(depth)]).to(T).contiguous()
+        P['w_fc1'] = old['w_fc1'] if 'w_fc1' in fresh else torch.stack([blk(i, 'ffn.fc1.weight') for i in range(depth)]).to(T).contiguous()
         P['b_fc1'] = torch.stack([blk(i, 'ffn.fc1.bias') for i in range(depth)]).float().contiguous()
-        P['w_fc2'] = torch.stack([blk(i, 'ffn.fc2.weight') for i in range(depth)]).to(T).contiguous()
+        P['w_fc2'] = old['w_fc2'] if 'w_fc2' in fresh else torch.stack([blk(i, 'ffn.fc2.weight') for i in range(depth)]).to(T).contiguous()
         P['b_fc2'] = torch.stack([blk(i, 'ffn.fc2.bias') for i in range(depth)]).float().contiguous()
         # every ada_lin of the model in ONE weight: rows [i*6C,(i+1)*6C) = block i, last 2C rows = head_nm
         head_w, head_b = ('head.1.weight', 'head.1.bias') if cfg.sa_block else ('head.weight', 'head.bias')
@@ -638,16 +665,17 @@ class ControlVAR(nn.Module):
             w_blk = [blk(i, 'ada_lin.1.weight') for i in range(depth)]
             b_blk = [blk(i, 'ada_lin.1.bias') for i in range(depth)]
         if not cfg.sa_block:
-            w_all = torch.cat(w_blk + [sd['head_nm.ada_lin.1.weight']])
+            w_all = None if 'w_ada' in fresh else torch.cat(w_blk + [sd['head_nm.ada_lin.1.weight']])
             b_all = torch.cat(b_blk + [sd['head_nm.ada_lin.1.bias']])
-        P['w_ada'] = w_all.to(T).contiguous()
+        P['w_ada'] = old['w_ada'] if 'w_ada' in fresh else w_all.to(T).contiguous()
         P['b_ada'] = b_all.float().contiguous()
         P['n_ada'] = depth * 6 * C + 2 * C
         hw, hb = sd[head_w], sd[head_b].float()
         if cfg.head_ld != hw.shape[0]:               # separator: V + 18 = 4114 columns -> padded to 4120 (zero weight, -1e30 bias: softmax weight exactly 0)
-            hw = torch.cat((hw, hw.new_zeros(cfg.head_ld - hw.shape[0], hw.shape[1])))
+            if 'w_head' not in fresh:
+                hw = torch.cat((hw, hw.new_zeros(cfg.head_ld - hw.shape[0], hw.shape[1])))
             hb = torch.cat((hb, hb.new_full((cfg.head_ld - hb.shape[0],), -1e30)))
-        P['w_head'] = hw.to(T).contiguous()
+        P['w_head'] = old['w_head'] if 'w_head' in fresh else hw.to(T).contiguous()
         P['b_head'] = hb.contiguous()
         P['special'] = sd['special_embed.weight'].float().contiguous() if cfg.separator else None
         P['sp_rows'] = {}

@@ -309,6 +309,11 @@ def gate_residual(x, f, gate, gate_off, ldg, gate_rows, rowscale, M, Cdim):
     check(_lib.load().cvar_gate_residual(_ptr(x), _ptr(f), dt(f), _ptr(gate) + 4 * gate_off, ldg, gate_rows, _ptr(rowscale), M, Cdim, _stream()), 'cvar_gate_residual')
 
 
+def train_ws_floats(M: int, R: int, Cdim: int) -> int:
+    """floats of workspace cvar_gated_grad / cvar_ln_modulate_bwd may use for M = R x l rows (cvar_train_ws_floats)"""
+    return int(_lib.load().cvar_train_ws_floats(M, R, Cdim))
+
+
 def gated_grad(dx, f, gate, gate_off, ldg, rowscale, df, dgate, dgate_off, ldo, R, l, Cdim, ws):
     check(_lib.load().cvar_gated_grad(_ptr(dx), _ptr(f), dt(f), _ptr(gate) + 4 * gate_off, ldg, _ptr(rowscale), _ptr(df), _ptr(dgate) + 4 * dgate_off, ldo,
                                       R, l, Cdim, _ptr(ws), _stream()), 'cvar_gated_grad')
@@ -369,10 +374,14 @@ def sumsq(x, partial, slot):
 
 
 def adam_table(entries, device) -> torch.Tensor:
-    """device table of cvar_adam_tensor {p, g, m, v, n, group, pad} (6 x int64 per entry) for the multi-tensor optimizer calls"""
+    """device table of cvar_adam_tensor {p, g, m, v, n, group, pad, w16} (7 x int64 per entry) for the multi-tensor optimizer calls;
+    an entry is (p, g, m, v, group) or (p, g, m, v, group, w16) with w16 a contiguous bf16 tensor of p's size (or None)"""
     rows = []
-    for (p, g, m, v, group) in entries:
-        rows.append([p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), int(group) & 0xffffffff])
+    for (p, g, m, v, group, *rest) in entries:
+        w16 = rest[0] if rest else None
+        if w16 is not None and (w16.dtype != torch.bfloat16 or w16.numel() != p.numel() or not w16.is_contiguous()):
+            raise ValueError('adam_table: the bf16 copy must be a contiguous bfloat16 tensor of the size of the parameter')
+        rows.append([p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), int(group) & 0xffffffff, w16.data_ptr() if w16 is not None else 0])
     return torch.tensor(rows, dtype=torch.int64).to(device)
 
 

@@ -198,7 +198,7 @@ def _ln_modulate_bwd(x, dy, scale, rows_per, eps):
     dev = x.device
     dx = torch.empty(M, C, device=dev, dtype=torch.float32)
     dada = torch.zeros(R, 2 * C, device=dev, dtype=torch.float32)
-    ws = torch.empty(2 * M + 16 * R * C + 16, device=dev, dtype=torch.float32)
+    ws = torch.empty(K.train_ws_floats(M, R, C) + 16, device=dev, dtype=torch.float32)
     K.ln_modulate_bwd(x2, dy2, sc, 0, C if R > 1 else 0, rows_per, None, dx, dada, 0, C, 2 * C, M, C, eps, ws)
     return dx.view_as(x), dada[:, :C].contiguous(), dada[:, C:].contiguous()
 

@@ -158,7 +158,7 @@ class TrainEngine:
         self.TA32 = torch.zeros(C * _pad8(B * self.ncode), **f32)
         self.TB32 = torch.zeros(cfg.cvae * _pad8(B * self.ncode), **f32)
         self.dada = torch.zeros(B, n_ada, **f32)
-        self.ws = torch.empty(max(2 * M + 16 * B * C, 64 * max(hid, 3 * C, V, n_ada), L * C, B * cfg.H * L,
+        self.ws = torch.empty(max(ops.train_ws_floats(M, B, C), 64 * max(hid, 3 * C, V, n_ada), L * C, B * cfg.H * L,
                                   6 * C * C if cfg.shared_aln else 0) + 16, **f32)
         # gradient slabs: [layer][w_qkv | w_proj | w_fc1 | w_fc2 | b_qkv | b_proj | b_fc1 | b_fc2]
         self.slab_off = {}
@@ -569,6 +569,7 @@ class FusedAdamW:
         self._out2 = None
         self._table = None
         self._table_sig = None
+        self.fuse_copies = True                                  # False: rebuild every packed copy from the fp32 parameters after a step
 
     @torch.no_grad()
     def step(self, grads: Dict[str, torch.Tensor], max_norm: float = 0.0, world: int = 1) -> torch.Tensor:
@@ -581,9 +582,15 @@ class FusedAdamW:
         # one launch over a device table of (param, grad, m, v) instead of 2 x ~830 per-tensor launches; the table is rebuilt
         # only when a buffer moved (new batch geometry -> new gradient slabs, .to(), load_state_dict)
         group_of = {name: gi for gi, g in enumerate(self.param_groups) for name in g['names']}
-        sig = tuple(p.data_ptr() for _, p in self.named) + tuple(grads[name].data_ptr() for name, _ in self.named)
+        # bf16 compute: the update kernel also writes the rounded value of every weight MATRIX into its slot of the stacked GEMM-ready
+        # copies (models.VAR._matrix_copies), so the step does not re-read the fp32 masters to rebuild them (stack + cast were 3.4 ms)
+        copies, fresh = self.var._matrix_copies() if self.fuse_copies and hasattr(self.var, '_matrix_copies') else ({}, ())
+        if not set(copies) <= {name for name, _ in self.named}:
+            copies, fresh = {}, ()
+        sig = (tuple(p.data_ptr() for _, p in self.named) + tuple(grads[name].data_ptr() for name, _ in self.named) +
+               tuple(c.data_ptr() for c in copies.values()))
         if self._table is None or self._table_sig != sig:
-            entries = [(p.data, grads[name], self.state[name][0], self.state[name][1], group_of[name]) for name, p in self.named]
+            entries = [(p.data, grads[name], self.state[name][0], self.state[name][1], group_of[name], copies.get(name)) for name, p in self.named]
             self._table = ops.adam_table(entries, dev)
             self._table_sig = sig
         ops.sumsq_multi(self._table, n, self._partial)
@@ -592,7 +599,10 @@ class FusedAdamW:
         coef = self._out2[1:]
         ops.adamw_multi(self._table, n, [float(g['lr']) for g in self.param_groups], [float(g['weight_decay']) for g in self.param_groups],
                         self.betas[0], self.betas[1], self.eps, self.steps, coef, 1.0 / world)
-        self.var._packed = None                                  # GEMM-ready copies are refreshed lazily
+        if fresh:
+            self.var._pack(fresh=fresh)                          # the matrices are current; biases / tables are rebuilt from the parameters
+        else:
+            self.var._packed = None                              # GEMM-ready copies are refreshed lazily
         return self._out2
 
     # ---- wire format of torch.optim.AdamW.state_dict() (what train_control_var_hpu.py:420-447 saves and resumes)

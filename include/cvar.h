@@ -245,13 +245,17 @@ int cvar_resample_sep(const float* in, const float* wy, const float* wx, float* 
  * x[m,:] += gate[m / gate_rows,:] * rowscale[m / gate_rows] * f[m,:]   (x + drop_path(gamma * f), basic_var.py:208-209) */
 int cvar_gate_residual(float* x, const void* f, int dtype, const float* gate, int64_t ldg, int gate_rows,
                        const float* rowscale, int64_t M, int C, void* stream);
-/* df = dx * gate * rowscale;  dgate[r,:] = rowscale[r] * sum_{m in r} dx[m,:] * f[m,:].  ws: 8*R*C floats. */
+/* floats of workspace the two per-sequence reductions below may use for M = R * l rows (row statistics + one partial row per row
+ * segment: the sequences are cut into enough segments that R * segments blocks fill the 256 CUs) */
+int64_t cvar_train_ws_floats(int64_t M, int R, int C);
+/* df = dx * gate * rowscale;  dgate[r,:] = rowscale[r] * sum_{m in r} dx[m,:] * f[m,:].  ws: cvar_train_ws_floats(R*l, R, C) floats. */
 int cvar_gated_grad(const float* dx, const void* f, int dtype, const float* gate, int64_t ldg, const float* rowscale,
                     void* df, float* dgate, int64_t ldo, int R, int l, int C, float* ws, void* stream);
 int cvar_gelu(const void* a, void* h, int dtype, int64_t n, void* stream);            /* h = gelu_tanh(a) */
 int cvar_gelu_bwd(const void* a, void* dh, int dtype, int64_t n, void* stream);       /* dh *= gelu_tanh'(a) */
 /* backward of cvar_ln_modulate: dx_out = dx_in + dLN(dy * (1+scale)); dscale[r,:] = sum dy*xhat; dshift[r,:] = sum dy.
- * ws: (2*M + 16*R*C) floats. */
+ * bf16 dy: ONE pass over x, dy, dx_in (row in registers, column sums carried per wave, folded through LDS in a fixed order).
+ * ws: cvar_train_ws_floats(M, M / rows_per, C) floats. */
 int cvar_ln_modulate_bwd(const float* x, const void* dy, int dtype, const float* scale, int64_t ld_ada, int rows_per,
                          const float* dx_in, float* dx_out, float* dscale, float* dshift, int64_t ldo,
                          int M, int C, float eps, float* ws, void* stream);
@@ -285,7 +289,9 @@ int cvar_clip_coef(const double* partials, int64_t count, float pre_scale, float
 /* Multi-tensor forms of the two above: ONE launch over a device table of cvar_adam_tensor (a d24 model has ~830 parameters).
  * Per tensor the arithmetic and summation order are exactly cvar_sumsq's / cvar_adamw's; partials is [n_tensors][256];
  * lr / weight decay come per parameter group (<= 8 groups, utils/lr_control.py:67-101) as small host arrays. */
-typedef struct { float* p; const float* g; float* m; float* v; int64_t n; int32_t group; int32_t pad; } cvar_adam_tensor;
+/* w16 (may be NULL): a bf16 array of n elements that receives the rounded (nearest-even) updated parameter in the same pass - the
+ * stacked GEMM-ready copy of a weight matrix, so a step does not re-read 4 GB of fp32 masters to rebuild 2 GB of bf16 weights. */
+typedef struct { float* p; const float* g; float* m; float* v; int64_t n; int32_t group; int32_t pad; uint16_t* w16; } cvar_adam_tensor;
 int cvar_sumsq_multi(const void* table_dev /* cvar_adam_tensor[n_tensors] */, int n_tensors, double* partials, void* stream);
 int cvar_adamw_multi(const void* table_dev, int n_tensors, const float* lr_by_group_host, const float* wd_by_group_host, int n_groups,
                      float beta1, float beta2, float eps, int step, const float* gscale_dev, float gscale, void* stream);

@@ -274,3 +274,33 @@ def test_resume_from_checkpoint_continues_bit_identically(gpu_device, tmp_path):
     assert got['loss'].item() == want['loss'].item() and got['lr'] == want['lr']
     for k, v in m2.state_dict().items():
         assert torch.equal(v, want_sd[k]), k
+
+
+@pytest.mark.parametrize('tag', ['d2', 'd2v', 'd2sa'])
+def test_optimizer_written_weight_copies_equal_a_full_repack(gpu_device, tag):
+    """The fused AdamW writes the bf16 GEMM-ready copy of every weight matrix in its own pass (cvar_adam_tensor.w16) and only the small
+    tensors are rebuilt from the parameters.  Three steps that way == three steps with every copy rebuilt from the fp32 masters (losses
+    and parameters bit-identical), and the copies it leaves are exactly what a full repack produces (adaLN, shared-adaLN, SABlock forms)."""
+    cfg = FIXTURE_CASES[tag][0]
+    images, masks = synth_images(2, 256, seed=6).to(gpu_device), synth_images(2, 256, seed=7).to(gpu_device)
+    cls, types = torch.tensor([17, 403]), torch.tensor([2, 0])
+    kw = dict(peak_lr=2e-3, weight_decay=0.05, weight_decay_end=0.01, sche='lin0', warmup_it=2, max_it=50, clip=2.0, drop_path=False)
+    runs = []
+    for fuse in (True, False):
+        vae, m = make(cfg, torch.bfloat16, gpu_device)
+        m.eval()
+        tr = T.Trainer(m, vae, **kw)
+        tr.opt.fuse_copies = fuse
+        losses = [tr.step(images, masks, cls, types)['loss'].item() for _ in range(3)]
+        runs.append((m, losses))
+    (ma, la), (mb, lb) = runs
+    assert la == lb
+    for (k, a), b in zip(ma.state_dict().items(), mb.state_dict().values()):
+        assert torch.equal(a, b), k
+    kept = ma._packed
+    assert kept is not None and ma._matrix_copies()[1][:4] == ('w_qkv', 'w_proj', 'w_fc1', 'w_fc2')
+    ma._packed = None
+    full = ma._pack()
+    for k, v in full.items():
+        if torch.is_tensor(v):
+            assert torch.equal(v, kept[k]), k

@@ -44,7 +44,7 @@ def test_gate_residual_and_gated_grad(gpu_device, dtype):
     dx = rnd(R * l, C, seed=4)
     df = torch.empty(R * l, C, device=gpu_device, dtype=dtype)
     dgate = torch.zeros(R, 3 * C, device=gpu_device)
-    ws = torch.empty(8 * R * C, device=gpu_device)
+    ws = torch.empty(ops.train_ws_floats(R * l, R, C), device=gpu_device)
     ops.gated_grad(dx.to(gpu_device), fd, ada.to(gpu_device), C, 4 * C, rs.to(gpu_device), df, dgate, 2 * C, 3 * C, R, l, C, ws)
     assert close(df, dx * g, dtype)
     ref = (dx * ff).view(R, l, C).sum(1) * rs[:, None]
@@ -68,9 +68,10 @@ def test_gelu_fwd_bwd(gpu_device, dtype):
 
 
 @pytest.mark.parametrize('dtype', [F32, BF16])
-@pytest.mark.parametrize('C', [128, 1536])
-def test_ln_modulate_bwd(gpu_device, dtype, C):
-    R, l = 2, 37
+@pytest.mark.parametrize('C,R,l', [(128, 2, 37), (1536, 2, 37), (1000, 3, 70), (1024, 5, 3), (1536, 2, 680), (2048, 1, 9)])
+def test_ln_modulate_bwd(gpu_device, dtype, C, R, l):
+    """row part (dx) and the per-sequence column sums (d scale, d shift); bf16 takes the one-pass kernel (row tails C % 256 != 0, fewer rows
+    than waves, many segments), fp32 the two-kernel form"""
     M = R * l
     x = (rnd(M, C, seed=1, scale=1.7) + 0.3).requires_grad_(True)
     ada = rnd(R, 6 * C, seed=2, scale=0.4)
@@ -83,10 +84,17 @@ def test_ln_modulate_bwd(gpu_device, dtype, C):
     dx_in = rnd(M, C, seed=4)
     dx_out = torch.empty(M, C, device=gpu_device)
     dada = torch.zeros(R, 6 * C, device=gpu_device)
-    ws = torch.empty(2 * M + 16 * R * C, device=gpu_device)
+    ws = torch.empty(ops.train_ws_floats(M, R, C), device=gpu_device)
     ops.ln_modulate_bwd(x.detach().to(gpu_device), dyd, ada.to(gpu_device), 2 * C, 6 * C, l, dx_in.to(gpu_device), dx_out, dada, 3 * C, 5 * C, 6 * C, M, C, 1e-6, ws)
     assert close(dx_out, dx_in + x.grad, F32, 2e-4)
     assert close(dada[:, 3 * C:4 * C], sc.grad, F32, 2e-4) and close(dada[:, 5 * C:], sh.grad, F32, 2e-4)
+    assert dada[:, :3 * C].abs().max() == 0 and dada[:, 4 * C:5 * C].abs().max() == 0
+    # in place (dx_in is dx_out: how the step accumulates the residual stream's gradient) and without an incoming gradient
+    acc = dx_in.to(gpu_device).clone()
+    ops.ln_modulate_bwd(x.detach().to(gpu_device), dyd, ada.to(gpu_device), 2 * C, 6 * C, l, acc, acc, dada, 3 * C, 5 * C, 6 * C, M, C, 1e-6, ws)
+    assert torch.equal(acc, dx_out)
+    ops.ln_modulate_bwd(x.detach().to(gpu_device), dyd, ada.to(gpu_device), 2 * C, 6 * C, l, None, acc, dada, 3 * C, 5 * C, 6 * C, M, C, 1e-6, ws)
+    assert close(acc, x.grad, F32, 2e-4)
 
 
 @pytest.mark.parametrize('dtype', [F32, BF16])
