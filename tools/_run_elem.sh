@@ -1,5 +1,8 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_gpu_train.py tests/test_gpu_train_kernels.py tests/test_torch_ops_slots.py -x -q -m gpu > gpurun_out/train_tests.log 2>&1; tail -5 gpurun_out/train_tests.log
-timeout 300 python tools/elem_bench.py > gpurun_out/elem_bench.log 2>&1; grep -v amdgpu.ids gpurun_out/elem_bench.log
-for i in 1 2; do timeout 600 python bench.py --mode train --steps 6 --warmup 2 --no-extras 2>&1 | tail -1; done
+CVAR_LIB=ab/libcvar_ppair.so timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "gemm or linear" > gpurun_out/pp_tests.log 2>&1; tail -2 gpurun_out/pp_tests.log
+for v in default ppair ppair0 default ppair; do
+  if [ $v = default ]; then unset CVAR_LIB; else export CVAR_LIB=ab/libcvar_$v.so; fi
+  echo "== $v"
+  timeout 600 python tools/gemm_insitu.py 24 128 2>&1 | grep -v amdgpu.ids | head -6 | cut -c1-150
+done
