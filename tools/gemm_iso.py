@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Isolated timing of the d24 GEMM shapes (plain bf16 epilogue; no data-dependent consumers, so timing-only probe builds are safe here).
+Usage: gemm_iso.py [M=131072] [iters=10]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from controlvar_amd import ops
+dev = torch.device('cuda:0'); T = torch.bfloat16
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+print(f'lib {os.environ.get("CVAR_LIB", "default")}')
+for N, K in ((4608, 1536), (6144, 1536), (1536, 6144), (1536, 1536)):
+    A = torch.randn(M, K, device=dev).to(T); W = (torch.randn(N, K, device=dev) / K ** 0.5).to(T)
+    out = torch.empty(M, N, device=dev, dtype=T)
+    best = 1e9
+    for rep in range(3):
+        ops.gemm(A, W, out, M=M, N=N, K=K); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters): ops.gemm(A, W, out, M=M, N=N, K=K)
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / iters)
+    print(f'M={M} N={N} K={K}: {best:.3f} ms  {2.0 * M * N * K / best / 1e9:.0f} TFLOP/s', flush=True)
