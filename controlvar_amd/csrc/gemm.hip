@@ -367,6 +367,21 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+#ifndef CVAR_GEMM_M16
+#define CVAR_GEMM_M16 1
+#endif
+    // M16: the K loop runs on v_mfma_f32_16x16x32_bf16 (two per 32x32x16's worth of flops, 16 cycles each).  Same fragment bytes out of LDS,
+    // but an accumulator register is read and written once per 32 k instead of once per 16: the chip is POWER-limited under this kernel
+    // (all-zero operands run the identical instruction stream 30 % faster, profiles/r03_gemm_power.txt) and the narrower tile moves less
+    // accumulator state per flop.  W fragment first (as TRANS): lane & 15 = output row, the 4 registers = 4 consecutive output columns.
+    constexpr bool M16 = (CVAR_GEMM_M16 != 0) && ES == 2 && FRAG_PIPE && TRANS && !CONV;
+    constexpr int MI16 = M16 ? SUB_M / 16 : 1, NJ16 = M16 ? SUB_N / 16 : 1;
+    f32x4_t acc4[MI16][NJ16];
+#pragma unroll
+    for (int i = 0; i < MI16; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ16; ++j) acc4[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
     const int lrow = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
     const int nk_all = (p.K + KT - 1) / KT;
     const int kt_lo = p.split_tiles > 0 ? (int)blockIdx.y * p.split_tiles : 0;
@@ -408,7 +423,46 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
         if (FAST && CONV) conv_next();
         const char* As = smem + cur * STAGE + (wm * SUB_M + lrow) * 128;
         const char* Bs = smem + cur * STAGE + BM * 128 + (wn * SUB_N + lrow) * 128;
-        if constexpr (ES == 2 && FRAG_PIPE) {
+        if constexpr (M16) {
+            typedef __attribute__((ext_vector_type(8))) __bf16 bfv8;
+            const int l15 = lane & 15, kq = lane >> 4, sw16 = (l15 >> 1) & 7;
+            const char* A16 = smem + cur * STAGE + (wm * SUB_M + l15) * 128;
+            const char* B16 = smem + cur * STAGE + BM * 128 + (wn * SUB_N + l15) * 128;
+            // registers: a ring of 3 A fragments (one feeds NJ16 MFMAs = 64 cycles, the read two ahead has 128 cycles to arrive) and the W
+            // fragments of both 32-deep k-steps (the second set is read during the first step)
+            bf16x8_t a3[3], bw[2][NJ16];
+            auto rd_a = [&](int s32, int i) { a3[(s32 * MI16 + i) % 3] = *(const bf16x8_t*)(A16 + i * 16 * 128 + (((4 * s32 + kq) ^ sw16) * 16)); };   // ring slot = running fragment number % 3
+            auto rd_b = [&](int s32, int j) { bw[s32][j] = *(const bf16x8_t*)(B16 + j * 16 * 128 + (((4 * s32 + kq) ^ sw16) * 16)); };
+#pragma unroll
+            for (int j = 0; j < NJ16; ++j) rd_b(0, j);
+            rd_a(0, 0); rd_a(0, 1);
+            constexpr int NM16 = MI16 * NJ16;                   // MFMAs per 32-deep k-step
+#pragma unroll
+            for (int s32 = 0; s32 < 2; ++s32) {
+#pragma unroll
+                for (int i = 0; i < MI16; ++i) {
+#pragma unroll
+                    for (int j = 0; j < NJ16; ++j) {
+                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfv8, bw[s32][j]), __builtin_bit_cast(bfv8, a3[(s32 * MI16 + i) % 3]), acc4[i][j], 0, 0, 0);
+                        const int m = (s32 * MI16 + i) * NJ16 + j;          // MFMA index inside the K tile, 0 .. 2 NM16 - 1
+                        if (j == 0) {                                        // A fragment two ahead (the slot freed by fragment i - 1)
+                            const int in = i + 2;
+                            if (in < MI16) rd_a(s32, in);
+                            else if (s32 == 0) rd_a(1, in - MI16);
+                        }
+                        if (s32 == 0 && j == 2 && i >= MI16 - NJ16) rd_b(1, i - (MI16 - NJ16));     // next k-step's W fragments, one per A fragment
+                        // DMA pieces of the next tile behind every (NM16 / NL)-th MFMA of the first quarter (two waves per SIMD) / half of the tile
+                        {
+                            constexpr int SPAN16 = NW >= 8 ? NM16 / 2 : NM16;
+#pragma unroll
+                            for (int t = 0; t < NL; ++t)
+                                if (max(((t + 1) * SPAN16) / NL - 1, 0) == m) issue_one(ktn, nxt, t);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        } else if constexpr (ES == 2 && FRAG_PIPE) {
             // one wave per SIMD (accumulators in AGPRs): nothing else hides the ds_read -> MFMA latency, so the fragments of
             // k-step ks+1 are fetched into a second register set before the MFMAs of k-step ks are issued
             bf16x8_t a[2][MI], b[2][NJ];
@@ -512,7 +566,14 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     // rows of block i land in the staging region: the whole transposed block at once (4 x b128 per 32 columns), or - tiles whose
     // pipeline LDS is too small for 32 staged rows per wave keep the plain MFMA layout (lane = column) - 16 rows as b32 stores
     auto stage_block = [&](int i, int half) {
-        if (FULL32) {
+        if constexpr (M16) {                  // 16x16 blocks: lane & 15 = row inside the block, lane >> 4 selects 4 of its 16 columns
+            if (half != 0) return;
+            const int l15 = lane & 15, cq = lane >> 4;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < NJ16; ++j) *(f32x4_t*)(stg + (16 * t + l15) * EROW + j * 16 + 4 * cq) = acc4[2 * i + t][j];
+        } else if (FULL32) {
             if (half != 0) return;
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
