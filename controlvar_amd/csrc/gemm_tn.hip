@@ -170,6 +170,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const GemmTnParams
     // D[n][k]: lane holds column k = lane & 31, rows (r & 3) + 8 (r >> 2) + 4 hi of the 32x32 block -> 128-byte row segments per store
     float* cbase = p.C + (long)blockIdx.z * p.split_stride;
     const int lrow = lane & 31;
+    // Kk may end in the middle of the last column tile (Kk % 128 == 0: d30's C = 1920 = 7.5 tiles): that tile's second wave column holds sums over
+    // whatever the B rows continue with - never stored
+    if (k0 + 128 * wn < p.Kk)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -213,16 +216,16 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __rest
 }
 
 /* C[Nn][Kk] (fp32, leading dimension ldc) = A^T B with A = [T][lda] (Nn columns used), B = [T][ldb] (Kk columns used), both bf16.
- * Nn % 128 == 0, Kk % 256 == 0; lda, ldb multiples of 8 (any T: the last K step is zero-filled); ws: caller workspace for the token-split partials (may be NULL: one slice).
+ * Nn % 128 == 0, Kk % 128 == 0 (column tiles are 256 wide; a half-filled last one stores its first 128 columns); lda, ldb multiples of 8 (any T: the last K step is zero-filled); ws: caller workspace for the token-split partials (may be NULL: one slice).
  * colsum_a (optional, ABI 14): colsum_a[n] = sum_t A[t][n], the bias gradient of the same layer, from the A fragments the kernel holds anyway. */
 extern "C" int cvar_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, int T, int Nn, int Kk,
                             float* ws, int64_t ws_bytes, float* colsum_a, void* stream) {
     if (!A || !B || !C || T <= 0 || Nn <= 0 || Kk <= 0) return CVAR_EINVAL;
-    if (Nn % TN_BM || Kk % TN_BN || lda % 8 || ldb % 8 || ldc % 4 || lda < Nn || ldb < Kk || ldc < Kk) return CVAR_EUNSUPPORTED;
+    if (Nn % TN_BM || Kk % (TN_BN / 2) || lda % 8 || ldb % 8 || ldc % 4 || lda < Nn || ldb < Kk || ldc < Kk) return CVAR_EUNSUPPORTED;
     if ((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) || (long)T * lda * 2 >= 0x7fffffffL || (long)T * ldb * 2 >= 0x7fffffffL) return CVAR_EUNSUPPORTED;
     GemmTnParams p;
     p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.T = T; p.Nn = Nn; p.Kk = Kk;
-    p.tiles_k = Kk / TN_BN;
+    p.tiles_k = (Kk + TN_BN - 1) / TN_BN;
     p.nsteps = (T + TN_BK - 1) / TN_BK;          // token rows past T lie outside the buffer resources: the DMA writes zeros for them
     const int tiles = (Nn / TN_BM) * p.tiles_k;
     // slices over the tokens: fill whole rounds of the 512 workgroup slots (two per CU), at least 24 K steps per slice, workspace permitting

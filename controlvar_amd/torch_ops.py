@@ -96,7 +96,7 @@ def _linear_grads(x, weight, dy, want_bias):
     K.gemm(dy2, wt, dx, M=M, N=Kd, K=N)
     dw = torch.empty(N, Kd, device=dev, dtype=torch.float32)
     db = torch.empty(N, device=dev, dtype=torch.float32) if want_bias else None
-    if T == torch.bfloat16 and N % 128 == 0 and Kd % 256 == 0 and 2 * M * max(N, Kd) < 2 ** 31 - 1:
+    if T == torch.bfloat16 and N % 128 == 0 and Kd % 128 == 0 and 2 * M * max(N, Kd) < 2 ** 31 - 1:
         K.gemm_tn(dy2, x2, dw, T=M, Nn=N, Kk=Kd, colsum=db)             # token-major operands read in place (cvar_gemm_tn): no transposed copies; db from the same pass
         return dx.view_as(x), dw, db
     ta = torch.zeros(N, Mp, device=dev, dtype=T)

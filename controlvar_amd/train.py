@@ -368,7 +368,7 @@ class TrainEngine:
         token-major operands in place (LDS transpose-read) - no transposed copies; shapes it does not take (a dimension that is not a
         multiple of its tile, the fp32 parity mode) go through two HBM transposes + `cvar_gemm` as in round 1."""
         M, Mp = self.M, self.Mp
-        if (dY.dtype == torch.bfloat16 and X.dtype == torch.bfloat16 and n_out % 128 == 0 and k_in % 256 == 0
+        if (dY.dtype == torch.bfloat16 and X.dtype == torch.bfloat16 and n_out % 128 == 0 and k_in % 128 == 0
                 and 2 * M * max(n_out, k_in) < 2 ** 31 - 1):
             # the bias gradient (column sums of dY) rides on the same pass: ones-operand MFMAs on the dY fragments (round 3; a separate colsum pass before)
             ops.gemm_tn(dY, X, G, T=M, Nn=n_out, Kk=k_in, c_off=w_off, colsum=G if b_off is not None else None, colsum_off=b_off or 0)

@@ -98,7 +98,7 @@ int cvar_gemm(const cvar_gemm_desc* d, void* stream);
 
 /* Weight-gradient GEMM on token-major operands (ABI 13): C[n][k] = sum_t A[t][n] * B[t][k], A = [T][lda], B = [T][ldb] bf16, C fp32 [Nn][ldc]
  * (dW = dY^T X, the parameter gradients of every nn.Linear under autograd, train_control_var_hpu.py:231).  No transposed copies: the fragments
- * are read from the [t][column] LDS tiles with gfx950's transpose-read.  Nn % 128 == 0, Kk % 256 == 0, lda / ldb % 8 == 0 (any T).
+ * are read from the [t][column] LDS tiles with gfx950's transpose-read.  Nn % 128 == 0, Kk % 128 == 0 (a half-filled last 256-wide column tile stores its first 128 columns: d30's C = 1920), lda / ldb % 8 == 0 (any T).
  * ws (optional, 16-byte aligned, ws_bytes): fp32 partial tiles of the token split, summed in a fixed order; NULL: one slice per tile.
  * colsum_a (optional, ABI 14): colsum_a[n] = sum_t A[t][n] for n < Nn - the bias gradient of the same nn.Linear (dY summed over the tokens),
  * taken from the A fragments on the matrix pipe instead of a second pass over dY (cvar_colsum). */

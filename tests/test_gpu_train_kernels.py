@@ -257,7 +257,10 @@ def test_gemm_fused_gelu_forward_keeps_preactivation_and_gelu_grad_epilogue(gpu_
                                             (1360, 384, 512, 384, 512),           # several tiles, token split through the workspace
                                             (1000, 256, 256, 640, 768),           # T % 32 != 0 (zero-filled tail step), operands are column windows
                                             (50, 128, 256, 128, 256),             # fewer tokens than two K steps
-                                            (43520, 1536, 1536, 1536, 1536)])     # the d24 proj weight gradient at B = 32
+                                            (777, 256, 384, 256, 384),            # Kk ends in the middle of a 256-wide column tile (ldb == Kk: the idle half reads the next token's row)
+                                            (1360, 384, 128, 392, 144),           # a single half-filled column tile, NaN columns right behind the window
+                                            (43520, 1536, 1536, 1536, 1536),      # the d24 proj weight gradient at B = 32
+                                            (10880, 1920, 1920, 1920, 1920)])     # d30 (C = 1920 = 7.5 column tiles) at B = 8
 def test_gemm_tn_weight_gradient(gpu_device, T, Nn, Kk, lda, ldb):
     """cvar_gemm_tn: dW[n, k] = sum_t dY[t, n] X[t, k] read token-major (LDS transpose-read, no transposed copies) against torch on the
     bf16-rounded operands.  The operands sit inside NaN-filled buffers and, where lda > Nn, inside wider NaN rows: every element outside
