@@ -378,7 +378,9 @@ def main_infer(a):
             out['roofline'] = {'bound': 'mfma', 'kernel': 'cvar_gemm_kernel + conv3x3_halo_bf16_kernel (every cvar_gemm launch: GEMMs and 3x3 convs)',
                                'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                                'traffic': traffic, 'traffic_source': tsrc, 'launches': len(prof), 'avg_launch_ms': round(ms / len(prof), 4),
-                               'gemm_share_of_step': round(ms * 1e-3 / dt, 3)}
+                               'gemm_share_of_step': round(ms * 1e-3 / dt, 3),
+                               'peak_note': 'dense bf16 MFMA peak at 2.4 GHz; this kernel is power-limited on random operands (the same instruction stream runs '
+                                            '~30 % faster on constant operands: profiles/r03_gemm_power.txt), so the clock under load is ~1.85 GHz'}
         prof = None
         if world == 1 and not a.no_extras:
             try:
