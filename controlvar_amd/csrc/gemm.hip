@@ -1029,10 +1029,19 @@ __global__ __launch_bounds__(256) void cvar_splitk_epilogue_kernel(const float* 
         const int m = (int)(i / (p.N / 4));
         const int n = (int)(i % (p.N / 4)) * 4;
         f32x4_t v = *(const f32x4_t*)(part + (long)m * p.N + n);
-        for (int s = 1; s < nsplit; ++s) {
-            const f32x4_t w = *(const f32x4_t*)(part + (long)s * p.M * p.N + (long)m * p.N + n);
+        // the slices are added in slice order (bit-reproducible), but their loads are independent: eight in flight at a time - the one-load-one-add loop was a
+        // chain of up to 15 memory latencies in a kernel with 3 workgroups (7.2 us per launch, 849 launches in a B = 1 generation)
+        for (int s0 = 1; s0 < nsplit; s0 += 8) {
+            f32x4_t w[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += w[e];
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < nsplit) w[u] = *(const f32x4_t*)(part + (long)(s0 + u) * p.M * p.N + (long)m * p.N + n);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < nsplit) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += w[u][e];
+                }
         }
         long orow = m;
         if (p.remap_l > 0) {

@@ -206,10 +206,17 @@ __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __rest
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
         const int n = (int)(i / (Kk / 4)), k = (int)(i % (Kk / 4)) * 4;
         f32x4_t v = *(const f32x4_t*)(part + (long)n * Kk + k);
-        for (int s = 1; s < nsplit; ++s) {
-            const f32x4_t w = *(const f32x4_t*)(part + (long)s * Nn * Kk + (long)n * Kk + k);
+        for (int s0 = 1; s0 < nsplit; s0 += 8) {             // slice order kept, loads of eight slices in flight
+            f32x4_t w[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += w[e];
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < nsplit) w[u] = *(const f32x4_t*)(part + (long)(s0 + u) * Nn * Kk + (long)n * Kk + k);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < nsplit) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += w[u][e];
+                }
         }
         *(f32x4_t*)(C + (long)n * ldc + k) = v;
     }
