@@ -68,3 +68,21 @@ def ids_parity(got, ref, margin, tol, what, strict=True):
     elif n:
         assert worst < tol, f'{what}: {n} id mismatches, largest reference margin at a mismatch {worst:.3e} >= {tol:.3e}'
     return n, rows_ok
+
+
+def maxabs_on(diff, rows_ok):
+    """max |diff| over the batch rows without an id flip; 0.0 when no row qualifies (a tolerated flip in every row must not turn into
+    'max of an empty tensor')"""
+    import torch
+    ok = torch.as_tensor(np.asarray(rows_ok), dtype=torch.bool)
+    if not bool(ok.any()):
+        return 0.0
+    return float(diff[ok].abs().max())
+
+
+def rows_ok_per_sample(rows_ok, n_samples):
+    """ids rows of a CFG run are laid out branch-major ([branch][sample], control_var.py:270-283: the branches are concatenated along
+    the batch dimension): a sample counts as clean only if all of its branches are.  Checks the layout assumption it relies on."""
+    ok = np.asarray(rows_ok)
+    assert ok.ndim == 1 and ok.size % n_samples == 0, (ok.shape, n_samples)
+    return ok.reshape(-1, n_samples).all(axis=0)

@@ -687,6 +687,17 @@ def case_generate_d30():
     save('gen_d30_cmask', c_ids=torch.cat(c_ids, dim=1).to(torch.int16), **r)
 
 
+def case_generate_d24():
+    """The headline model itself (BASELINE metric: 256^2 autoregressive_infer_cfg, d24): d24 ControlVAR (C=1536, 24 heads) at FULL
+    width + full VQVAE (ch=160), B=2, greedy, cfg 4, cond_type=[0,1] recorded from the reference (control_var.py:356-565)."""
+    vae = make_vae(160)
+    m = make_cvar(vae, VarConfig(depth=24))
+    t0 = time.time()
+    r = _run_generate(m, ref_cv, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]))
+    print(f'  d24 B=2 reference generate {time.time() - t0:.1f}s')
+    save('gen_d24_b2', **r)
+
+
 def case_train_step_d24():
     """BASELINE config 3 anchor: one reference training step at d24 width (C=1536, 24 blocks), B=2, tiny VQVAE for the tokens."""
     case_train_step(VarConfig(depth=24), 'd24', 0)
@@ -830,6 +841,7 @@ CASES = {
     'fwd_d12_bf16ref': case_forward_d12_bf16ref,
     'gen_d12_bf16ref': case_generate_d12_bf16ref,
     'gen_d30': case_generate_d30,
+    'gen_d24': case_generate_d24,
     'train_d24': case_train_step_d24,
 }
 

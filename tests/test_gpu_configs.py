@@ -18,7 +18,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from conftest import golden, ids_parity, record  # noqa: E402
+from conftest import golden, ids_parity, maxabs_on, record, rows_ok_per_sample  # noqa: E402
 from controlvar_amd import models  # noqa: E402
 from controlvar_amd import train as T  # noqa: E402
 from controlvar_amd.spec import DEFAULT_PATCH_NUMS as PN, VarConfig  # noqa: E402
@@ -71,7 +71,8 @@ def test_forward_d12_fp32_matches_reference(gpu_device):
 def test_generate_d12_bf16_config2(gpu_device, B):
     """bf16 d12 generation, teacher-forced with the oracle's ids on the rows the fixture covers (labels arange(B), types
     arange(B) % 4: the first min(B, 8) rows are the fixture's rows): per-scale CFG logits within BF16_REL_BOUND of the bf16-emulating
-    oracle, greedy ids equal wherever the oracle's top-1 margin exceeds 4x the measured logit error; rows ride in batches of 1, 8
+    oracle, greedy ids equal wherever the oracle's top-1 margin exceeds 2 x BF16_REL_MEASURED x max|logit| of the scale (two logits, each off by at
+    most the round-2 measured error: a constant, not this run's own error); rows ride in batches of 1, 8
     and 64 (different GEMM tilings / split-K partitions) with the same bound."""
     g = golden('gen_d12_bf16emu')
     vae, m = build(12, BF16, gpu_device)
@@ -99,7 +100,7 @@ def test_generate_d12_bf16_config2(gpu_device, B):
         err = (got - ref).abs().max().item()
         rel = err / float(g['absmax_per_scale'][si])
         worst_rel = max(worst_rel, rel)
-        check_ids(tr['idx'][si][:nref].cpu(), ref_ids[si][:nref], margin[:nref, o:o + l].numpy(), 4 * err + 1e-6, f'd12 bf16 vs emulation B={B} scale {si}', strict=False)
+        check_ids(tr['idx'][si][:nref].cpu(), ref_ids[si][:nref], margin[:nref, o:o + l].numpy(), 2 * BF16_REL_MEASURED * float(g['absmax_per_scale'][si]), f'd12 bf16 vs emulation B={B} scale {si}', strict=False)
         o += l
     print(f'd12 bf16 B={B}: worst per-scale logit error relative to max|logit| = {worst_rel:.3e} (bound {BF16_REL_BOUND:.1e}; north_star 1e-3)')
     assert worst_rel < BF16_REL_BOUND
@@ -203,10 +204,10 @@ def _gen_check(m, g, B, labels, scale, types, what, four=False, c_mask=None, tol
         img = m.autoregressive_infer_cfg(B, labels, g_seed=0, cfg=scale, top_k=1, cond_type=types, _trace=True)
     ids = torch.cat(m.last_trace['idx'], dim=1).cpu()
     nm, ok = check_ids(ids[:t(g['ids']).shape[0]], g['ids'], g['margin'], tol, what)
-    ok = ok.reshape(-1, img.shape[0]).all(axis=0)
+    ok = rows_ok_per_sample(ok, img.shape[0])
     img = img.cpu()
-    assert (img[:, :, 100:116, 60:76] - t(g['img_crop']))[ok].abs().max() < 5e-3
-    assert (img.mean(dim=(2, 3)) - t(g['img_mean']))[ok].abs().max() < 5e-4
+    assert maxabs_on(img[:, :, 100:116, 60:76] - t(g['img_crop']), ok) < 5e-3
+    assert maxabs_on(img.mean(dim=(2, 3)) - t(g['img_mean']), ok) < 5e-4
     return img
 
 
@@ -220,6 +221,13 @@ def test_d30_full_width_fp32_matches_reference(gpu_device):
     g2 = golden('gen_d30_cmask')
     c_ids = split(t(g2['c_ids']).long(), mf=1)
     _gen_check(m, g2, 2, torch.tensor([5, 6]), (4.0, 4.0, 4.0), torch.tensor([2, 3]), 'd30 conditional_infer_cfg', four=True, c_mask=c_ids)
+
+
+def test_d24_full_width_fp32_matches_reference(gpu_device):
+    """The headline model itself (BASELINE metric: d24, C=1536, 24 heads, 24 blocks) + the full VQVAE, fp32 mode, token for token against
+    the reference's recorded greedy trace (gen_d24_b2.npz: B=2, cfg 4, cond_type=[0,1]; control_var.py:356-565), image crops and means."""
+    vae, m = build(24, F32, gpu_device)
+    _gen_check(m, golden('gen_d24_b2'), 2, torch.tensor([3, 7]), 4.0, torch.tensor([0, 1]), 'd24 B=2 (headline model, full width)')
 
 
 def test_d30_full_width_bf16_properties(gpu_device):

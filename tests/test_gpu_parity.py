@@ -12,7 +12,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from conftest import golden, ids_parity, record  # noqa: E402
+from conftest import golden, ids_parity, maxabs_on, record, rows_ok_per_sample  # noqa: E402
 from controlvar_amd import models  # noqa: E402
 from controlvar_amd.spec import DEFAULT_PATCH_NUMS as PN, VaeConfig, VarConfig, phi_index_map  # noqa: E402
 from controlvar_amd.synth import synth_images, synth_vae_state, synth_var_state  # noqa: E402
@@ -68,8 +68,8 @@ def test_ms_encode_bit_exact_on_reference_features(gpu_device, tag, ch):
     sd = synth_vae_state(VaeConfig(ch=ch))
     _, margins = MSQuant(sd, PN, phi_index_map(10)).f_to_idx(t(g['f']), return_margins=True)
     n, ok = assert_ids(idx.cpu(), g['ids'], torch.cat(margins, 1).numpy(), 1e-4, f'ms_encode {tag}')
-    assert (fh.cpu() - t(g['fhat_last']))[ok].abs().max() < 1e-4
-    assert (mg.cpu() - torch.cat(margins, 1))[ok].abs().max() < 1e-3
+    assert maxabs_on(fh.cpu() - t(g['fhat_last']), ok) < 1e-4
+    assert maxabs_on(mg.cpu() - torch.cat(margins, 1), ok) < 1e-3
 
 
 @pytest.mark.parametrize('B,amp,seed', [(1, 0.5, 1), (3, 1.0, 2), (5, 3.0, 3)])
@@ -99,16 +99,16 @@ def test_tokenizer_with_caller_chosen_scale_lists(gpu_device):
         ids = vae.img_to_idxBl(img, v_patch_nums=pns)
         assert [tuple(i.shape) for i in ids] == [(2, p * p) for p in pns]
         got = torch.cat(ids, dim=1).cpu().numpy()
-        mism = got != g[f'ids_{tag}'].astype(np.int64)
-        assert mism.mean() < 0.005, f'{tag}: {mism.sum()} of {mism.size} ids differ'        # fp32 conv-stack noise may flip a near-tie
-        if not mism.any():
-            rec = vae.img_to_recon(img, v_patch_nums=pns, last_one=True).cpu()
-            assert (rec[:, :, 100:116, 60:76] - t(g[f'rec_crop_{tag}'])).abs().max() < 2e-3
-            recs = vae.img_to_recon(img, v_patch_nums=pns, last_one=False)                  # per-scale reconstructions of the chosen list
-            assert len(recs) == len(pns)
-            for si, r in enumerate(recs):
-                assert (r[:, :, 100:116, 60:76].cpu() - t(g[f'recs_crop_{tag}'][si])).abs().max() < 2e-3, (tag, si)
-                assert (r.mean(dim=(2, 3)).cpu() - t(g[f'recs_mean_{tag}'][si])).abs().max() < 3e-4, (tag, si)
+        # strict since round 4 (was: < 0.5 % flips tolerated and the float checks skipped behind `if not mism.any()`): the fp32 encoder +
+        # quantiser reproduce the reference's ids of both scale lists exactly; the margin argument only labels a failure message
+        nm, ok = assert_ids(got, g[f'ids_{tag}'], np.zeros(got.shape, np.float32), 0.0, f'img_to_idxBl v_patch_nums={pns}', strict=True)
+        rec = vae.img_to_recon(img, v_patch_nums=pns, last_one=True).cpu()
+        assert maxabs_on(rec[:, :, 100:116, 60:76] - t(g[f'rec_crop_{tag}']), ok) < 2e-3
+        recs = vae.img_to_recon(img, v_patch_nums=pns, last_one=False)                  # per-scale reconstructions of the chosen list
+        assert len(recs) == len(pns)
+        for si, r in enumerate(recs):
+            assert maxabs_on(r[:, :, 100:116, 60:76].cpu() - t(g[f'recs_crop_{tag}'][si]), ok) < 2e-3, (tag, si)
+            assert maxabs_on(r.mean(dim=(2, 3)).cpu() - t(g[f'recs_mean_{tag}'][si]), ok) < 3e-4, (tag, si)
     with pytest.raises(AssertionError):
         vae.img_to_idxBl(img, v_patch_nums=(1, 2, 4, 8))
     assert all(torch.equal(a, b) for a, b in zip(vae.img_to_idxBl(img, v_patch_nums=PN), vae.img_to_idxBl(img)))
@@ -191,6 +191,53 @@ def test_tokenizer_fp32_against_reference(gpu_device, tag, ch):
     assert (rec.mean(dim=(2, 3)) - t(g['rec_mean'])).abs().max() < 2e-4
 
 
+def test_tokenizer_bf16_encoder_ids_against_reference(gpu_device):
+    """Throughput mode of A11 (vqvae.py:73-75 behind train_control_var_hpu.py:159-167): the ENCODER runs in bf16, the quantiser in
+    fp32.  (i) the quantiser is exact on whatever features it gets: ids == the oracle quantiser applied to the HIP bf16 features,
+    strict; (ii) against the reference's fp32 ids (tokenizer_ch160.npz): agreement rate recorded; a flip can only come from the
+    feature error, so at the first scale of an image that has a flip (later scales quantise a different residual and are not
+    comparable) every flipped token's reference margin d2 - d1 must be below 2 |dz| |e1 - e2| <= 2 sqrt(C) max|df| diam(E), with
+    max|df| MEASURED in this test (area pooling does not increase a max error)."""
+    g = golden('tokenizer_ch160')
+    vae = make_vae(160, BF16, gpu_device)
+    img = synth_images(int(g['nimg']), 256, seed=1).to(gpu_device)
+    f = vae._encode_f(img).float().cpu()
+    fref = t(g['f'])
+    err_f = float((f - fref).abs().max())
+    ids = torch.cat(vae.img_to_idxBl(img), dim=1).cpu()
+    sd = synth_vae_state(VaeConfig(ch=160))
+    q = MSQuant(sd, PN, phi_index_map(10))
+    own = torch.cat(q.f_to_idx(f), dim=1)
+    assert_ids(ids, own.numpy(), np.zeros(tuple(own.shape), np.float32), 0.0, 'bf16 encoder: ids vs oracle quantiser on the HIP features', strict=True)
+    _, margins = q.f_to_idx(fref, return_margins=True)
+    margins = torch.cat(margins, 1).numpy()
+    ref = g['ids'].astype(np.int64)
+    mism = ids.numpy() != ref
+    E = q.E
+    diam = float(torch.cdist(E, E).max())
+    bound = 2.0 * float(np.sqrt(E.shape[1])) * err_f * diam
+    bounds = np.cumsum([0] + [p * p for p in PN])
+    first_scale, comparable, flips_cmp, worst = [], 0, 0, 0.0
+    for b in range(ref.shape[0]):
+        fs = next((si for si in range(len(PN)) if mism[b, bounds[si]:bounds[si + 1]].any()), len(PN))
+        first_scale.append(fs)
+        hi = bounds[min(fs + 1, len(PN))]
+        comparable += int(hi)
+        flips_cmp += int(mism[b, :hi].sum())
+        if fs < len(PN):
+            sl = slice(bounds[fs], bounds[fs + 1])
+            worst = max(worst, float(margins[b, sl][mism[b, sl]].max()))
+    agree = 1.0 - float(mism.mean())
+    print(f'[parity] bf16 encoder ids vs reference fp32 ids: max|df| {err_f:.3e} (max|f| {float(fref.abs().max()):.2f}); agreement {agree:.4f} over all '
+          f'{mism.size} ids; first flipped scale per image {first_scale}; {flips_cmp} flips among the {comparable} comparable ids, '
+          f'largest reference margin at one {worst:.3e} (bound {bound:.3e})')
+    record('img_to_idxBl ch160 bf16 encoder vs reference fp32 ids', kind='ids', flips=int(mism.sum()), total=int(mism.size), agreement=agree,
+           comparable=comparable, flips_comparable=flips_cmp, worst_margin_at_flip=worst, margin_bound=bound, err_f=err_f,
+           first_flipped_scale=first_scale, strict=False, tol=bound)
+    assert err_f < 0.05 * max(1.0, float(fref.abs().max()))
+    assert worst < bound
+
+
 def test_decoder_bf16_against_emulated_oracle(gpu_device):
     """Throughput mode: the bf16 decoder (bf16 NHWC activations, fp32 accumulate) against the fp32 reference math
     and against the oracle with the same bf16 storage points.  ~60 sequentially rounded layers random-walk to ~1.5 %
@@ -252,9 +299,9 @@ def test_generate_fp32_matches_reference_tokens(gpu_device, name):
     nm, ok = assert_ids(ids, g['ids'], g['margin'], 2e-3, name)
     lg = torch.cat([x[:2] for x in tr['logits']], dim=1).cpu()[:, :, ::128][:, ::3]
     assert (lg - t(g['logit_samples']))[ok[:2]].abs().max() < 3e-3 * max(1.0, float(np.abs(g['logit_samples']).max()))
-    assert (img[:, :, 100:116, 60:76] - t(g['img_crop']))[ok].abs().max() < 2e-3
-    assert (img[:, :, -20:-4, 200:216] - t(g['img_crop2']))[ok].abs().max() < 2e-3
-    assert (img.mean(dim=(2, 3)) - t(g['img_mean']))[ok].abs().max() < 2e-4
+    assert maxabs_on(img[:, :, 100:116, 60:76] - t(g['img_crop']), ok) < 2e-3
+    assert maxabs_on(img[:, :, -20:-4, 200:216] - t(g['img_crop2']), ok) < 2e-3
+    assert maxabs_on(img.mean(dim=(2, 3)) - t(g['img_mean']), ok) < 2e-4
 
 
 @pytest.mark.parametrize('name,teach,scale', [('gen_d2_cmask', 'c_mask', (4.0, 4.0, 4.0)), ('gen_d2_cimg', 'c_img', (3.0, 2.0, 1.0)),
@@ -271,9 +318,9 @@ def test_conditional_infer_fp32_matches_reference_tokens(gpu_device, name, teach
                                   **{teach: c_ids}).cpu()
     ids = torch.cat(m.last_trace['idx'], dim=1).cpu()
     nm, ok = assert_ids(ids, g['ids'], g['margin'].repeat(4, axis=0) if g['margin'].shape[0] * 4 == ids.shape[0] else g['margin'], 2e-3, name)
-    ok = ok.reshape(-1, img.shape[0]).all(axis=0)
-    assert (img[:, :, 100:116, 60:76] - t(g['img_crop']))[ok].abs().max() < 2e-3
-    assert (img.mean(dim=(2, 3)) - t(g['img_mean']))[ok].abs().max() < 2e-4
+    ok = rows_ok_per_sample(ok, img.shape[0])
+    assert maxabs_on(img[:, :, 100:116, 60:76] - t(g['img_crop']), ok) < 2e-3
+    assert maxabs_on(img.mean(dim=(2, 3)) - t(g['img_mean']), ok) < 2e-4
 
 
 def test_generate_d12_config1_fp32(gpu_device):
@@ -285,8 +332,8 @@ def test_generate_d12_config1_fp32(gpu_device):
     img = _run(m, case).cpu()
     ids = torch.cat(m.last_trace['idx'], dim=1).cpu()
     nm, ok = assert_ids(ids, g['ids'], g['margin'], 2e-3, 'gen_d12_b2 (BASELINE config 1)')
-    assert (img[:, :, 100:116, 60:76] - t(g['img_crop']))[ok].abs().max() < 3e-3
-    assert (img.mean(dim=(2, 3)) - t(g['img_mean']))[ok].abs().max() < 3e-4
+    assert maxabs_on(img[:, :, 100:116, 60:76] - t(g['img_crop']), ok) < 3e-3
+    assert maxabs_on(img.mean(dim=(2, 3)) - t(g['img_mean']), ok) < 3e-4
 
 
 @pytest.mark.parametrize('tag,mf', [('d2', 2), ('var_d2', 1), ('d2v', 2), ('d2sa', 2), ('d2sa0', 2), ('d2b', 2)])
@@ -374,8 +421,8 @@ def test_full_size_d24_properties(gpu_device):
     """BASELINE metric configuration (d24 ControlVAR + ch160 VQVAE, bf16) through size-independent properties - the oracle
     needs ~10 s per image at this size, so parity here is structural: (1) bit-reproducible; (2) the KV-cache decode and the
     masked teacher-forced forward agree on the logits of every scale; (3) rows are independent of the batch they ride in;
-    (4) tokenizer round trip: decoding the ids of an image and re-encoding gives back the same first-scale ids, and
-    idxBl_to_img of img_to_idxBl is a bounded-error reconstruction."""
+    (4) tokenizer at full size: img_to_idxBl is deterministic, its ids are in range, idxBl_to_img of them is finite and
+    image-shaped (the bf16 encoder's ids against the reference's are measured in test_tokenizer_bf16_encoder_ids_against_reference)."""
     cfg = VarConfig(depth=24)
     vae = make_vae(160, BF16, gpu_device)
     m = make_var(vae, cfg, BF16, gpu_device)

@@ -277,6 +277,13 @@ def test_generate_d12_config1():
     _gen_check('gen_d12_b2', VarConfig(depth=12), 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]), vae_ch=160)
 
 
+@pytest.mark.slow
+def test_generate_d24_headline_model():
+    """The model the BASELINE metric is quoted on, full width (d24 + ch160 VQVAE), B=2 greedy: the oracle (what bench.py's cpu_baseline
+    leg times and what smoke() checks against) reproduces the reference's recorded trace token for token."""
+    _gen_check('gen_d24_b2', VarConfig(depth=24), 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]), vae_ch=160)
+
+
 def test_sampler_masks():
     g = golden('sampler')
     gen = torch.Generator().manual_seed(77)
