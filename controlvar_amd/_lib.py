@@ -11,7 +11,7 @@ import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CVAR_LIB') or os.path.join(HERE, 'libcvar_hip.so')      # CVAR_LIB: A/B runs against another build
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 CVAR_F32, CVAR_BF16 = 0, 1
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_GRAD = 0, 1, 2
@@ -79,10 +79,10 @@ SIGNATURES = {
     # training step
     'cvar_gate_residual': (c_i, [c_p, c_p, c_i, c_p, c_l, c_i, c_p, c_l, c_i, c_p]),
     'cvar_train_ws_floats': (c_l, [c_l, c_i, c_i]),
-    'cvar_gated_grad': (c_i, [c_p, c_p, c_i, c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p]),
+    'cvar_gated_grad': (c_i, [c_p, c_p, c_i, c_p, c_l, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_p]),
     'cvar_gelu': (c_i, [c_p, c_p, c_i, c_l, c_p]),
     'cvar_gelu_bwd': (c_i, [c_p, c_p, c_i, c_l, c_p]),
-    'cvar_ln_modulate_bwd': (c_i, [c_p, c_p, c_i, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_p, c_p]),
+    'cvar_ln_modulate_bwd': (c_i, [c_p, c_p, c_i, c_p, c_l, c_i, c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_p, c_l, c_p]),
     'cvar_colsum': (c_i, [c_p, c_i, c_l, c_p, c_l, c_i, c_i, c_p, c_p]),
     'cvar_wordembed_grad_ws_bytes': (c_l, [c_l, c_i]),
     'cvar_wordembed_grad': (c_i, [c_p, c_l, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),

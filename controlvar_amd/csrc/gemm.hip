@@ -37,6 +37,10 @@ static __device__ __attribute__((aligned(16))) unsigned int cvar_zero_chunk[4] =
 #ifdef CVAR_GEMM_TIMING
 __device__ unsigned long long cvar_gemm_dbg[64 * 8 * 8];
 __device__ unsigned long long cvar_gemm_dbg_tot[8];
+// workgroup timeline (round 4): per workgroup {s_memrealtime at entry, at the first MFMA, at the end of the K loop, at exit, HW_ID | XCC_ID << 32}
+#define CVAR_DBG_WG_MAX 16384
+__device__ unsigned long long cvar_gemm_dbg_wg[CVAR_DBG_WG_MAX * 5];
+extern "C" int cvar_gemm_dbg_wg_read(unsigned long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cvar_gemm_dbg_wg), sizeof(unsigned long long) * 5 * (size_t)(n < CVAR_DBG_WG_MAX ? n : CVAR_DBG_WG_MAX)); }
 extern "C" int cvar_gemm_dbg_tot_read(unsigned long long* host, int reset) { int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cvar_gemm_dbg_tot), 64); if (reset) { unsigned long long z[8] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(cvar_gemm_dbg_tot), z, 64); } return rc; }
 extern "C" int cvar_gemm_dbg_read(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cvar_gemm_dbg), sizeof(unsigned long long) * 64 * 8 * 8); }
 #endif
@@ -126,6 +130,9 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     // accumulator blocks are kept transposed (swapped MFMA operands) when a 32-row staging region per wave fits the pipeline LDS
     constexpr bool TRANS = NW * 32 * (SUB_N + 4) * 4 <= NSTAGE * STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef CVAR_GEMM_TIMING
+    const unsigned long long dbg_rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -370,6 +377,9 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #ifndef CVAR_GEMM_M16
 #define CVAR_GEMM_M16 1
 #endif
+#ifndef CVAR_GEMM_XB
+#define CVAR_GEMM_XB 1
+#endif
     // M16: the K loop runs on v_mfma_f32_16x16x32_bf16 (two per 32x32x16's worth of flops, 16 cycles each).  Same fragment bytes out of LDS,
     // but an accumulator register is read and written once per 32 k instead of once per 16: the chip is POWER-limited under this kernel
     // (all-zero operands run the identical instruction stream 30 % faster, profiles/r03_gemm_power.txt) and the narrower tile moves less
@@ -393,27 +403,83 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     // (counted vmcnt before the barrier) and (b) every wave has finished reading tile kt-1, whose stage is the one the
     // pieces issued in this iteration overwrite.
     constexpr int PF = NSTAGE - 1;
-#pragma unroll
-    for (int t = 0; t < PF; ++t) {
-        if (FAST && CONV) conv_next();
-#pragma unroll
-        for (int idx = 0; idx < NL; ++idx) issue_one(min(kt_lo + t, nk - 1), t, idx);
-    }
+    // XB (round 4; the schedule hipBLASLt's MT256x256x64 kernel runs, profiles/r04_gemm_isa_vs_hipblaslt.txt): the K-tile boundary is software-
+    // pipelined ACROSS the barrier.  Before, every K tile started with  vmcnt(0) - barrier - ten fragment reads - lgkmcnt(0)  in front of its
+    // first MFMA: the matrix pipe idled for the LDS latency of a whole fragment set plus the barrier skew, once per 64 k (s_memtime: 2 380 +
+    // 160 cycles per tile against 2 048 of MFMA issue).  Now the barrier of tile kt sits in front of its last two A-fragment rows (Pm): by then a
+    // wave has issued every LDS read of tile kt, so passing it means (a) everybody's DMA pieces of tile kt+1 have landed (vmcnt(0) before it) and
+    // (b) nobody reads tile kt's stage any more.  Behind it, under the tile's remaining MFMAs, the wave reads the FIRST fragments of tile kt+1 out
+    // of the other stage and starts the DMA of tile kt+2 into the stage just released (one piece per two MFMAs, running over into the next
+    // tile's first MFMAs), so the MFMA stream continues through the loop edge.  Two LDS stages, two tiles in flight, one barrier per tile.
+    constexpr bool XB2 = M16 && NSTAGE == 2 && (CVAR_GEMM_XB == 2 || (CVAR_GEMM_XB == 3 && NW < 8));   // see the XB2 loop below
+    constexpr bool XB = M16 && NSTAGE == 2 && (CVAR_GEMM_XB != 0) && !XB2;
+    constexpr int RING = XB ? 4 : 3;                              // A-fragment ring: 2 MI16 % RING == 0 keeps the slot numbering across tiles
+    constexpr int NM16 = MI16 * NJ16;                             // MFMAs per 32-deep k-step
+    constexpr int XB_PM = (2 * MI16 - 2) * NJ16;                  // first MFMA behind the barrier
+    static_assert(!XB || (2 * MI16) % RING == 0, "fragment ring must divide the tile");
+    // piece t of the next-next tile is issued behind MFMA XB_PM + 1 + 2 t of the tile (positions past the tile's end wrap into the next tile)
+    auto xb_pos = [](int t) { return (XB_PM + 1 + 2 * t) % (2 * NM16); };
+    auto xb_same_iter = [](int t) { return XB_PM + 1 + 2 * t < 2 * NM16; };
+    constexpr int XB_N2 = NL < NJ16 ? NL : NJ16;                  // pieces with xb_same_iter: 2 NM16 - XB_PM = 2 NJ16 MFMAs lie behind the barrier
+    bf16x8_t a3[RING], bw[2][M16 ? NJ16 : 1];
+    bf16x8_t fa[2][XB2 ? MI16 : 1], fb[2][XB2 ? NJ16 : 1];      // XB2: complete fragment sets of both k-steps
     int cur = 0;
+    if constexpr (XB2) {
+        // tiles kt_lo and kt_lo + 1 in flight; the first tile's k-step-0 fragments are read before the loop
+#pragma unroll
+        for (int idx = 0; idx < NL; ++idx) issue_one(kt_lo, 0, idx);
+#pragma unroll
+        for (int idx = 0; idx < NL; ++idx) issue_one(min(kt_lo + 1, nk - 1), 1, idx);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+        __builtin_amdgcn_s_barrier();
+        const int l15 = lane & 15, kq = lane >> 4, sw16 = (l15 >> 1) & 7;
+        const char* A16 = smem + (wm * SUB_M + l15) * 128;
+        const char* B16 = smem + BM * 128 + (wn * SUB_N + l15) * 128;
+#pragma unroll
+        for (int j = 0; j < NJ16; ++j) fb[0][j] = *(const bf16x8_t*)(B16 + j * 16 * 128 + ((kq ^ sw16) * 16));
+#pragma unroll
+        for (int i = 0; i < MI16; ++i) fa[0][i] = *(const bf16x8_t*)(A16 + i * 16 * 128 + ((kq ^ sw16) * 16));
+    } else if constexpr (XB) {
+#pragma unroll
+        for (int idx = 0; idx < NL; ++idx) issue_one(kt_lo, 0, idx);
+#pragma unroll
+        for (int t = 0; t < NL; ++t)
+            if (xb_same_iter(t)) issue_one(min(kt_lo + 1, nk - 1), 1, t);
+        // the pieces of the first tile have landed when at most the XB_N2 later ones are outstanding (vmcnt retires in order)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XB_N2) : "memory");
+        __builtin_amdgcn_s_barrier();
+        {
+            const int l15 = lane & 15, kq = lane >> 4, sw16 = (l15 >> 1) & 7;
+            const char* A16 = smem + (wm * SUB_M + l15) * 128;
+            const char* B16 = smem + BM * 128 + (wn * SUB_N + l15) * 128;
+#pragma unroll
+            for (int j = 0; j < NJ16; ++j) bw[0][j] = *(const bf16x8_t*)(B16 + j * 16 * 128 + ((kq ^ sw16) * 16));
+            a3[0] = *(const bf16x8_t*)(A16 + ((kq ^ sw16) * 16));
+            a3[1] = *(const bf16x8_t*)(A16 + 16 * 128 + ((kq ^ sw16) * 16));
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < PF; ++t) {
+            if (FAST && CONV) conv_next();
+#pragma unroll
+            for (int idx = 0; idx < NL; ++idx) issue_one(min(kt_lo + t, nk - 1), t, idx);
+        }
+    }
 #ifdef CVAR_GEMM_TIMING
     unsigned long long dbg_comp = 0, dbg_vm = 0, dbg_bar = 0, dbg_last = 0, dbg_ew = 0;
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long dbg_rt_loop = __builtin_amdgcn_s_memrealtime();
 #endif
     for (int kt = kt_lo; kt < nk; ++kt) {
         const int ktn = min(kt + PF, nk - 1);
 #ifdef CVAR_GEMM_TIMING
         const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
 #endif
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * NL) : "memory");   // uniform: dead pieces keep the count regular
+        if constexpr (!XB && !XB2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * NL) : "memory");   // uniform: dead pieces keep the count regular
 #ifdef CVAR_GEMM_TIMING
         const unsigned long long tq1 = __builtin_amdgcn_s_memtime();
 #endif
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!XB && !XB2) __builtin_amdgcn_s_barrier();
 #ifdef CVAR_GEMM_TIMING
         const unsigned long long tq2 = __builtin_amdgcn_s_memtime();
         if (kt > kt_lo) dbg_comp += tq0 - dbg_last;
@@ -423,36 +489,106 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
         if (FAST && CONV) conv_next();
         const char* As = smem + cur * STAGE + (wm * SUB_M + lrow) * 128;
         const char* Bs = smem + cur * STAGE + BM * 128 + (wn * SUB_N + lrow) * 128;
-        if constexpr (M16) {
+        if constexpr (XB2) {
+            // XB2 = hipBLASLt's register plan (profiles/r04_gemm_isa_vs_hipblaslt.txt): BOTH k-steps' complete fragment sets live in registers.
+            // k-step 0 computes on set 0 while set 1 is read out of this tile's stage (all reads issued in its first three quarters, in order of
+            // use); the barrier sits at the k-step boundary - every LDS read of the tile is done by then - and k-step 1 computes on set 1 while
+            // the NEXT tile's set 0 is read out of the other stage and the DMA of tile kt+2 refills this one.  No wait inside a k-step except
+            // the ones the compiler derives for first uses; one barrier per tile; DMA pieces fly for a whole tile.
             typedef __attribute__((ext_vector_type(8))) __bf16 bfv8;
             const int l15 = lane & 15, kq = lane >> 4, sw16 = (l15 >> 1) & 7;
             const char* A16 = smem + cur * STAGE + (wm * SUB_M + l15) * 128;
             const char* B16 = smem + cur * STAGE + BM * 128 + (wn * SUB_N + l15) * 128;
-            // registers: a ring of 3 A fragments (one feeds NJ16 MFMAs = 64 cycles, the read two ahead has 128 cycles to arrive) and the W
-            // fragments of both 32-deep k-steps (the second set is read during the first step)
-            bf16x8_t a3[3], bw[2][NJ16];
-            auto rd_a = [&](int s32, int i) { a3[(s32 * MI16 + i) % 3] = *(const bf16x8_t*)(A16 + i * 16 * 128 + (((4 * s32 + kq) ^ sw16) * 16)); };   // ring slot = running fragment number % 3
-            auto rd_b = [&](int s32, int j) { bw[s32][j] = *(const bf16x8_t*)(B16 + j * 16 * 128 + (((4 * s32 + kq) ^ sw16) * 16)); };
-#pragma unroll
-            for (int j = 0; j < NJ16; ++j) rd_b(0, j);
-            rd_a(0, 0); rd_a(0, 1);
-            constexpr int NM16 = MI16 * NJ16;                   // MFMAs per 32-deep k-step
+            const char* A16n = smem + nxt * STAGE + (wm * SUB_M + l15) * 128;
+            const char* B16n = smem + nxt * STAGE + BM * 128 + (wn * SUB_N + l15) * 128;
+            constexpr int NR = MI16 + NJ16;
+            // read r of a set: W fragments first (every MFMA row needs all of them), then the A fragments in row order
+            auto rd_set = [&](int set, const char* Ab, const char* Bb, int s32, int r) {
+                const int c = ((4 * s32 + kq) ^ sw16) * 16;
+                if (r < NJ16) fb[set][r] = *(const bf16x8_t*)(Bb + r * 16 * 128 + c);
+                else fa[set][r - NJ16] = *(const bf16x8_t*)(Ab + (r - NJ16) * 16 * 128 + c);
+            };
+            constexpr int RSPAN = (3 * NM16) / 4;                // reads of the other set go behind the first RSPAN MFMAs of a k-step
 #pragma unroll
             for (int s32 = 0; s32 < 2; ++s32) {
 #pragma unroll
                 for (int i = 0; i < MI16; ++i) {
 #pragma unroll
                     for (int j = 0; j < NJ16; ++j) {
-                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfv8, bw[s32][j]), __builtin_bit_cast(bfv8, a3[(s32 * MI16 + i) % 3]), acc4[i][j], 0, 0, 0);
+                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfv8, fb[s32][j]), __builtin_bit_cast(bfv8, fa[s32][i]), acc4[i][j], 0, 0, 0);
+                        const int q = i * NJ16 + j;                 // MFMA index inside the k-step
+#pragma unroll
+                        for (int r = 0; r < NR; ++r)
+                            if ((r * RSPAN) / NR == q) {
+                                if (s32 == 0) rd_set(1, A16, B16, 1, r);          // this tile's k-step 1
+                                else rd_set(0, A16n, B16n, 0, r);                 // next tile's k-step 0 (behind the barrier)
+                            }
+                        if (s32 == 1) {
+#pragma unroll
+                            for (int t = 0; t < NL; ++t)
+                                if ((t * (NM16 - 2)) / NL + 1 == q) issue_one(min(kt + 2, nk - 1), cur, t);     // tile kt+2 into the stage this tile has finished reading
+                        }
+                        if (s32 == 0 && q == NM16 - 1) {
+                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // set 1 arrived (issued >= NM16 / 4 MFMAs ago); own pieces of tile kt+1 landed
+                            __builtin_amdgcn_s_barrier();
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        } else if constexpr (M16) {
+            typedef __attribute__((ext_vector_type(8))) __bf16 bfv8;
+            const int l15 = lane & 15, kq = lane >> 4, sw16 = (l15 >> 1) & 7;
+            const char* A16 = smem + cur * STAGE + (wm * SUB_M + l15) * 128;
+            const char* B16 = smem + cur * STAGE + BM * 128 + (wn * SUB_N + l15) * 128;
+            // registers: a ring of RING A fragments (one feeds NJ16 MFMAs = 64 cycles, the read two ahead has 128 cycles to arrive) and the W
+            // fragments of both 32-deep k-steps (the second set is read during the first step)
+            auto rd_a = [&](int s32, int i) { a3[(s32 * MI16 + i) % RING] = *(const bf16x8_t*)(A16 + i * 16 * 128 + (((4 * s32 + kq) ^ sw16) * 16)); };   // ring slot = running fragment number % RING
+            auto rd_b = [&](int s32, int j) { bw[s32][j] = *(const bf16x8_t*)(B16 + j * 16 * 128 + (((4 * s32 + kq) ^ sw16) * 16)); };
+            // XB: the first fragments of the NEXT tile, out of the other stage, behind this tile's barrier
+            const char* A16n = smem + nxt * STAGE + (wm * SUB_M + l15) * 128;
+            const char* B16n = smem + nxt * STAGE + BM * 128 + (wn * SUB_N + l15) * 128;
+            auto rd_a_next = [&](int i) { a3[i % RING] = *(const bf16x8_t*)(A16n + i * 16 * 128 + ((kq ^ sw16) * 16)); };
+            auto rd_b_next = [&](int j) { bw[0][j] = *(const bf16x8_t*)(B16n + j * 16 * 128 + ((kq ^ sw16) * 16)); };
+            if constexpr (!XB) {
+#pragma unroll
+                for (int j = 0; j < NJ16; ++j) rd_b(0, j);
+                rd_a(0, 0); rd_a(0, 1);
+            }
+#pragma unroll
+            for (int s32 = 0; s32 < 2; ++s32) {
+#pragma unroll
+                for (int i = 0; i < MI16; ++i) {
+#pragma unroll
+                    for (int j = 0; j < NJ16; ++j) {
+                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfv8, bw[s32][j]), __builtin_bit_cast(bfv8, a3[(s32 * MI16 + i) % RING]), acc4[i][j], 0, 0, 0);
                         const int m = (s32 * MI16 + i) * NJ16 + j;          // MFMA index inside the K tile, 0 .. 2 NM16 - 1
                         if (j == 0) {                                        // A fragment two ahead (the slot freed by fragment i - 1)
                             const int in = i + 2;
                             if (in < MI16) rd_a(s32, in);
                             else if (s32 == 0) rd_a(1, in - MI16);
+                            else if (XB) rd_a_next(in - MI16);               // fragments 0, 1 of the next tile (m >= XB_PM: behind the barrier)
                         }
                         if (s32 == 0 && j == 2 && i >= MI16 - NJ16) rd_b(1, i - (MI16 - NJ16));     // next k-step's W fragments, one per A fragment
-                        // DMA pieces of the next tile behind every (NM16 / NL)-th MFMA of the first quarter (two waves per SIMD) / half of the tile
-                        {
+                        if constexpr (XB) {
+                            // W fragments of the next tile's first k-step: one per MFMA behind the barrier (bw[0] is dead since k-step 0 ended)
+                            if (m >= XB_PM && j != 0) {
+                                const int c = (m - XB_PM) - (m - XB_PM) / NJ16 - 1;          // running count over the j != 0 positions
+                                if (c < NJ16) rd_b_next(c);
+                            }
+#pragma unroll
+                            for (int t = 0; t < NL; ++t)
+                                if (xb_pos(t) == m) {
+                                    if (xb_same_iter(t)) issue_one(min(kt + 2, nk - 1), cur, t);     // tile kt+2 into the stage this tile releases
+                                    else issue_one(min(kt + 1, nk - 1), nxt, t);                      // the rest of the group started behind the previous barrier
+                                }
+                            if (m == XB_PM - 1) {
+                                // every LDS read of this tile has been issued: wait for them and for this wave's pieces of tile kt+1, then meet
+                                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                                __builtin_amdgcn_s_barrier();
+                            }
+                        } else {
+                            // DMA pieces of the next tile behind every (NM16 / NL)-th MFMA of the first quarter (two waves per SIMD) / half of the tile
                             constexpr int SPAN16 = NW >= 8 ? NM16 / 2 : NM16;
 #pragma unroll
                             for (int t = 0; t < NL; ++t)
@@ -540,11 +676,13 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                                               : __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (!XB && !XB2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // XB: the next tile's first fragments stay in flight over the loop edge
         cur = (cur + 1) % NSTAGE;
     }
+    if constexpr (XB || XB2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // dead pieces of the last tiles must not land in the epilogue's staging rows
 #ifdef CVAR_GEMM_TIMING
     const unsigned long long dbg_t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long dbg_rt_loop_end = __builtin_amdgcn_s_memrealtime();
 #endif
     __syncthreads();
 
@@ -864,6 +1002,14 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     }
     }   // generic epilogue
 #ifdef CVAR_GEMM_TIMING
+    if (lane == 0 && wave == 0 && blockIdx.x < CVAR_DBG_WG_MAX && blockIdx.y == 0 && blockIdx.z == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the stores of this wave have been acknowledged
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* o = cvar_gemm_dbg_wg + (size_t)blockIdx.x * 5;
+        o[0] = dbg_rt_entry; o[1] = dbg_rt_loop; o[2] = dbg_rt_loop_end; o[3] = __builtin_amdgcn_s_memrealtime(); o[4] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+    }
     if (lane == 0 && blockIdx.x < 64) {
         const unsigned long long dbg_t2 = __builtin_amdgcn_s_memtime();
         unsigned long long* o = cvar_gemm_dbg + (blockIdx.x * 8 + wave) * 8;

@@ -141,10 +141,11 @@ __global__ void red_finalize_kernel(const float* __restrict__ partial, float* __
 }
 
 // df = dx * gate * rowscale (dtype);  dgate[r, c] = rowscale[r] * sum_{m in r} dx[m,c] * f[m,c]
-// ws: RED_S * R * C floats
+// ws: cvar_train_ws_floats(R * l, R, C) floats; ws_floats = what the caller allocated (checked)
 extern "C" int cvar_gated_grad(const float* dx, const void* f, int dtype, const float* gate, int64_t ldg, const float* rowscale,
-                               void* df, float* dgate, int64_t ldo, int R, int l, int C, float* ws, void* stream) {
+                               void* df, float* dgate, int64_t ldo, int R, int l, int C, float* ws, int64_t ws_floats, void* stream) {
     if (!dx || !f || !gate || !df || !dgate || !ws || R <= 0 || l <= 0 || C <= 0) return CVAR_EINVAL;
+    if (ws_floats < cvar_train_ws_floats((int64_t)R * l, R, C)) return CVAR_EINVAL;       // ABI 16: the workspace size is part of the call
     dim3 grid(cdiv(C, 256), R, RED_S), block(256);
     const bool vec = dtype == CVAR_BF16 && C % 4 == 0 && ldg % 4 == 0 && ((((uintptr_t)dx | (uintptr_t)gate | (uintptr_t)ws) & 15) == 0) &&
                      ((((uintptr_t)f | (uintptr_t)df) & 7) == 0);
@@ -462,8 +463,9 @@ __global__ void ln_bwd_finalize_kernel(const float* __restrict__ partial, float*
 #endif
 extern "C" int cvar_ln_modulate_bwd(const float* x, const void* dy, int dtype, const float* scale, int64_t ld_ada, int rows_per,
                                     const float* dx_in, float* dx_out, float* dscale, float* dshift, int64_t ldo,
-                                    int M, int C, float eps, float* ws, void* stream) {
+                                    int M, int C, float eps, float* ws, int64_t ws_floats, void* stream) {
     if (!x || !dy || !scale || !dx_out || !dscale || !dshift || !ws || M <= 0 || C <= 0 || rows_per <= 0 || M % rows_per) return CVAR_EINVAL;
+    if (ws_floats < cvar_train_ws_floats(M, M / rows_per, C)) return CVAR_EINVAL;            // ABI 16
     const int R = M / rows_per;
     float* stats = ws;
     float* partial = ws + 2 * (size_t)M;

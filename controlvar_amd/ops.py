@@ -316,7 +316,7 @@ def train_ws_floats(M: int, R: int, Cdim: int) -> int:
 
 def gated_grad(dx, f, gate, gate_off, ldg, rowscale, df, dgate, dgate_off, ldo, R, l, Cdim, ws):
     check(_lib.load().cvar_gated_grad(_ptr(dx), _ptr(f), dt(f), _ptr(gate) + 4 * gate_off, ldg, _ptr(rowscale), _ptr(df), _ptr(dgate) + 4 * dgate_off, ldo,
-                                      R, l, Cdim, _ptr(ws), _stream()), 'cvar_gated_grad')
+                                      R, l, Cdim, _ptr(ws), ws.numel(), _stream()), 'cvar_gated_grad')
 
 
 def gelu(a, h):
@@ -331,7 +331,7 @@ def gelu_bwd(a, dh):
 
 def ln_modulate_bwd(x, dy, ada, scale_off, ld_ada, rows_per, dx_in, dx_out, dada, dscale_off, dshift_off, ldo, M, Cdim, eps, ws):
     check(_lib.load().cvar_ln_modulate_bwd(_ptr(x), _ptr(dy), dt(dy), _ptr(ada) + 4 * scale_off, ld_ada, rows_per, _ptr(dx_in), _ptr(dx_out),
-                                           _ptr(dada) + 4 * dscale_off, _ptr(dada) + 4 * dshift_off, ldo, M, Cdim, eps, _ptr(ws), _stream()), 'cvar_ln_modulate_bwd')
+                                           _ptr(dada) + 4 * dscale_off, _ptr(dada) + 4 * dshift_off, ldo, M, Cdim, eps, _ptr(ws), ws.numel(), _stream()), 'cvar_ln_modulate_bwd')
 
 
 def colsum(A, lda, out, M, N, ws, accumulate=False, a_off: int = 0, out_off: int = 0):

@@ -70,6 +70,11 @@ def _cast(t: Optional[torch.Tensor], dtype):
         return t
     if t.requires_grad and torch.is_grad_enabled():
         return t.to(dtype)
+    # memoise nn.Parameters only (tensors that outlive the call).  Activations are cast directly: a cached bf16 copy of
+    # every x / q / k / v would stay alive until its source dies, and an inference tensor (torch.inference_mode) has no version
+    # counter to key the cache on - reading ._version on one raises.
+    if t.is_inference() or not isinstance(t, torch.nn.Parameter):
+        return t.detach().to(dtype)
     return _cached(_CAST_CACHE, t, (dtype,), lambda: t.detach().to(dtype))
 
 

@@ -248,17 +248,18 @@ int cvar_gate_residual(float* x, const void* f, int dtype, const float* gate, in
 /* floats of workspace the two per-sequence reductions below may use for M = R * l rows (row statistics + one partial row per row
  * segment: the sequences are cut into enough segments that R * segments blocks fill the 256 CUs) */
 int64_t cvar_train_ws_floats(int64_t M, int R, int C);
-/* df = dx * gate * rowscale;  dgate[r,:] = rowscale[r] * sum_{m in r} dx[m,:] * f[m,:].  ws: cvar_train_ws_floats(R*l, R, C) floats. */
+/* df = dx * gate * rowscale;  dgate[r,:] = rowscale[r] * sum_{m in r} dx[m,:] * f[m,:].  ws: cvar_train_ws_floats(R*l, R, C) floats;
+ * ws_floats (ABI 16) = floats the caller allocated: smaller than that -> CVAR_EINVAL instead of an out-of-bounds device write. */
 int cvar_gated_grad(const float* dx, const void* f, int dtype, const float* gate, int64_t ldg, const float* rowscale,
-                    void* df, float* dgate, int64_t ldo, int R, int l, int C, float* ws, void* stream);
+                    void* df, float* dgate, int64_t ldo, int R, int l, int C, float* ws, int64_t ws_floats, void* stream);
 int cvar_gelu(const void* a, void* h, int dtype, int64_t n, void* stream);            /* h = gelu_tanh(a) */
 int cvar_gelu_bwd(const void* a, void* dh, int dtype, int64_t n, void* stream);       /* dh *= gelu_tanh'(a) */
 /* backward of cvar_ln_modulate: dx_out = dx_in + dLN(dy * (1+scale)); dscale[r,:] = sum dy*xhat; dshift[r,:] = sum dy.
  * bf16 dy: ONE pass over x, dy, dx_in (row in registers, column sums carried per wave, folded through LDS in a fixed order).
- * ws: cvar_train_ws_floats(M, M / rows_per, C) floats. */
+ * ws: cvar_train_ws_floats(M, M / rows_per, C) floats, ws_floats as above (ABI 16). */
 int cvar_ln_modulate_bwd(const float* x, const void* dy, int dtype, const float* scale, int64_t ld_ada, int rows_per,
                          const float* dx_in, float* dx_out, float* dscale, float* dshift, int64_t ldo,
-                         int M, int C, float eps, float* ws, void* stream);
+                         int M, int C, float eps, float* ws, int64_t ws_floats, void* stream);
 /* ABI 14.  Gradient of word_embed = nn.Linear(Cvae, C) (control_var.py:74; its input is the token tensor of idxBl_to_var_input) from the token-major
  * fp32 tensors in place: dW[c][j] = sum_t dx[row(t)][c] * tok[t][j], db[c] = sum_t dx[row(t)][c], t < B * n_per_sample, row(t) = (t / n) *
  * rows_per_sample + skip + t % n (the first `skip` positions of every sample are not word-embedded).  Cvae == 32, C % 64 == 0.

@@ -27,8 +27,13 @@ SD = Dict[str, torch.Tensor]
 class Prec:
     """Rounding model: ``act`` marks every tensor the HIP bf16 path stores in bf16."""
 
-    def __init__(self, bf16: bool = False):
-        self.bf16 = bf16
+    def __init__(self, bf16: bool = False, q_round: str = 'prescaled'):
+        # q_round (bf16 only): where the attention queries are rounded.  'prescaled' = bf16(q * scale * log2 e), the HIP path's storage
+        # point since round 3; 'plain' = bf16(q), then the scale in fp32 - the rounding point of the reference's autocast and of rounds 1-2.
+        # Both are the same function up to one bf16 rounding of q; tests hold the HIP logits against BOTH so that a wrong prescale constant
+        # cannot be absorbed by an oracle that mirrors it.
+        assert q_round in ('prescaled', 'plain')
+        self.bf16, self.q_round = bf16, q_round
 
     def act(self, x: torch.Tensor) -> torch.Tensor:
         return x.to(torch.bfloat16).to(torch.float32) if self.bf16 else x

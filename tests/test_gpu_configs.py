@@ -165,6 +165,18 @@ def test_forward_d12_bf16_among_the_references_bf16(gpu_device):
     assert r['hip_vs_ref_fp32'][0] <= 1.1 * r['ref_autocast_vs_ref_fp32'][0]
     assert r['hip_vs_ref_fp32'][1] <= 1.1 * r['ref_autocast_vs_ref_fp32'][1]
     assert r['hip_vs_emulation'][1] <= 1e-3
+    # second, independent emulation mode (queries rounded BEFORE the scale, as the reference's autocast does): the HIP logits must sit as
+    # close to it - a mistake in the prescale constant cannot hide in an oracle that mirrors the implementation
+    from oracle import var_ref
+    from oracle.vqvae_ref import Prec
+    from controlvar_amd.synth import synth_var_state
+    cfg = VarConfig(depth=12)
+    with torch.no_grad():
+        plain = var_ref.forward_logits(synth_var_state(cfg), cfg, t(g['labels']), x.cpu(), t(g['types']), prec=Prec(True, 'plain'))[:, ::9, ::31]
+    dmax, drms = [v / float(g['absmax']) for v in _d(hip, plain)]
+    print(f'[bf16] forward_d12 HIP vs the plain-rounding emulation: {dmax:.2e} / {drms:.2e}')
+    record('forward_d12 bf16 vs plain-rounding emulation', kind='bf16_logits', absmax=float(g['absmax']), hip_vs_emulation_plain=[dmax, drms])
+    assert drms <= 1.2e-3 and dmax <= 2 * max(r['hip_vs_emulation'][0], BF16_REL_MEASURED)
 
 
 def test_generate_d12_bf16_along_the_references_bf16_trace(gpu_device):

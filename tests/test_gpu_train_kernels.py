@@ -49,6 +49,13 @@ def test_gate_residual_and_gated_grad(gpu_device, dtype):
     assert close(df, dx * g, dtype)
     ref = (dx * ff).view(R, l, C).sum(1) * rs[:, None]
     assert close(dgate[:, 2 * C:], ref, F32, 1e-4) and dgate[:, :2 * C].abs().max() == 0
+    # ABI 16: an undersized workspace is refused instead of being written past its end
+    from controlvar_amd._lib import CvarError
+    with pytest.raises(CvarError):
+        ops.gated_grad(dx.to(gpu_device), fd, ada.to(gpu_device), C, 4 * C, rs.to(gpu_device), df, dgate, 2 * C, 3 * C, R, l, C, ws[:ws.numel() - 1])
+    x0 = x.to(gpu_device)
+    with pytest.raises(CvarError):
+        ops.ln_modulate_bwd(x0, fd, ada.to(gpu_device), 0, 4 * C, l, None, torch.empty_like(x0), dgate, 0, C, 3 * C, R * l, C, 1e-6, ws[:ws.numel() - 1])
 
 
 @pytest.mark.parametrize('dtype', [F32, BF16])

@@ -277,6 +277,25 @@ def test_generate_d12_config1():
     _gen_check('gen_d12_b2', VarConfig(depth=12), 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]), vae_ch=160)
 
 
+def test_bf16_emulation_modes_agree():
+    """The two query-rounding modes of the bf16 emulation (Prec.q_round: 'prescaled' = the HIP storage point bf16(q * scale * log2 e),
+    'plain' = bf16(q) with the scale in fp32) are the same function up to one bf16 rounding of q: their teacher-forced logits differ by
+    bf16 noise only, and both differ from the fp32 oracle by the same order.  A wrong constant in either would show as an O(1) gap."""
+    from oracle.vqvae_ref import Prec
+    cfg = VarConfig(depth=2)
+    sd = synth_var_state(cfg)
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(2, cfg.pyramid.L - cfg.pyramid.first_l, 32, generator=gen)
+    labels, types = torch.tensor([3, 900]), torch.tensor([1, 2])
+    with torch.no_grad():
+        l32 = var_ref.forward_logits(sd, cfg, labels, x, types)
+        la = var_ref.forward_logits(sd, cfg, labels, x, types, prec=Prec(True))
+        lb = var_ref.forward_logits(sd, cfg, labels, x, types, prec=Prec(True, 'plain'))
+    amax = float(l32.abs().max())
+    rms = lambda a, b: float((a - b).pow(2).mean().sqrt()) / amax
+    assert 0 < rms(la, lb) < 2e-3 and rms(la, l32) < 5e-3 and rms(lb, l32) < 5e-3, (rms(la, lb), rms(la, l32), rms(lb, l32))
+
+
 @pytest.mark.slow
 def test_generate_d24_headline_model():
     """The model the BASELINE metric is quoted on, full width (d24 + ch160 VQVAE), B=2 greedy: the oracle (what bench.py's cpu_baseline

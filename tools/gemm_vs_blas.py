@@ -18,9 +18,12 @@ def bench(fn, flops, iters=20):
     return ms, flops / ms / 1e9
 
 C = 1536
-for M in (16384, 65536, 131072):
+DATA = os.environ.get('ISO_DATA', 'randn')          # zeros: same instruction streams without operand toggling -> what each kernel does when power does not limit the clock
+print(f'data {DATA}')
+for M in ((131072,) if DATA != 'randn' else (16384, 65536, 131072)):
     for name, N, K in (('qkv', 3 * C, C), ('proj', C, C), ('fc1', 4 * C, C), ('fc2', C, 4 * C)):
         A = torch.randn(M, K, device=dev).to(T); W = (torch.randn(N, K, device=dev) / K ** 0.5).to(T)
+        if DATA == 'zeros': A.zero_(); W.zero_()
         out = torch.empty(M, N, device=dev, dtype=T)
         ms0, tf0 = bench(lambda: ops.gemm(A, W, out, M=M, N=N, K=K), 2.0 * M * N * K)
         ms1, tf1 = bench(lambda: torch.matmul(A, W.t(), out=out), 2.0 * M * N * K)
