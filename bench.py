@@ -240,6 +240,14 @@ def _finish(world):
             dist.destroy_process_group()
 
 
+def _rank_evidence(units_per_step, steps, device):
+    """keys that let the one JSON line prove the N-rank run by itself: rccl_ranks (from a real all_reduce), rccl_version, per-rank rates"""
+    from controlvar_amd.launcher import LAST_RUN, collective_evidence
+    ev = collective_evidence(device)
+    ev['per_rank_value'] = [round(units_per_step * steps / s, 3) for s in LAST_RUN['rank_seconds']]
+    return ev
+
+
 def main_stub(a):
     """the launch / barrier / max-over-ranks clock / one-JSON-line logic with a sleeping step on CPU ranks (gloo): what
     tests/test_bench_launch.py runs with --gpus 2 to check that `python bench.py --gpus N` really becomes N ranks"""
@@ -248,8 +256,9 @@ def main_stub(a):
     init_dist('gloo')
     B = a.batch or 4
     _, dt = sharded_timed_run(lambda i: time.sleep(a.stub_step_ms * 1e-3 * (1 + rank)), a.steps, a.warmup, B)
+    ev = _rank_evidence(B, a.steps, None)
     if rank == 0:
-        print(json.dumps({'metric': 'stub', 'value': round(world * B * a.steps / dt, 3), 'unit': 'units/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+        print(json.dumps({**ev, 'metric': 'stub', 'value': round(world * B * a.steps / dt, 3), 'unit': 'units/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
                           'ms_per_step': round(1e3 * dt / a.steps, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'none',
                           'data': 'stub', 'config': {'workload': 'sleeping step (launch-logic test)', 'batch_per_gpu': B, 'global_batch': B * world,
                                                      'parallelism': f'dp{world}'}}), flush=True)
@@ -281,12 +290,24 @@ def main_train(a):
         last['out'] = tr.step(images, masks, cls, types, drop_seed=1000 * rank + i)
 
     _, dt = sharded_timed_run(step, a.steps, a.warmup, B, sync=torch.cuda.synchronize)
-    exposed = None
+    ev = _rank_evidence(B, a.steps, dev)
+    exposed, allreduce_ms = None, None
     if world > 1:
         tr.comm = False
         _, dt_nocomm = sharded_timed_run(step, a.steps, 1, B, sync=torch.cuda.synchronize)
         tr.comm = True
         exposed = max(0.0, (dt - dt_nocomm) / dt)
+        # the exchange alone, un-overlapped: every gradient slab of one step all-reduced back to back (what the overlap has to hide)
+        import torch.distributed as dist
+        slabs = [torch.zeros_like(b) for b in tr.engine.buckets]
+        for rep in range(2):
+            torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            for s_ in slabs:
+                dist.all_reduce(s_, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+            allreduce_ms = 1e3 * (time.perf_counter() - t0)
+        del slabs
     if rank == 0:
         fl = algorithmic_gflop_per_row(VarConfig(depth=a.depth), n_ada=1)
         per_sample_tf = (3 * fl['total'] + 2 * 215.4) / 1e3                   # fwd + 2x bwd + two frozen tokenizer encodes
@@ -298,6 +319,7 @@ def main_train(a):
                           'parallelism': f'dp{world} (per-layer gradient slabs, RCCL all-reduce on a side stream)'},
                'algorithmic_tflop_per_sample': round(per_sample_tf, 3), 'end_to_end_tflops_per_gpu': round(per_sample_tf * B * a.steps / dt, 1),
                'loss': round(float(last['out']['loss']), 4), 'exposed_comm_frac': None if exposed is None else round(exposed, 4),
+               'allreduce_ms_per_step': None if allreduce_ms is None else round(allreduce_ms, 2), **ev,
                'allreduce_bytes_per_step': sum(b.numel() * 4 for b in tr.engine.buckets)}
         print(json.dumps(out), flush=True)
     _finish(world)
@@ -341,6 +363,7 @@ def main_infer(a):
 
     _, dt = sharded_timed_run(timed_step, a.steps, a.warmup, B, sync=torch.cuda.synchronize)
     ops.GEMM_PROFILE = None
+    ev = _rank_evidence(B, a.steps, dev)
     img = last.pop('img')
     assert img.shape == (B, 3, 512, 256)
     del img
@@ -359,7 +382,7 @@ def main_infer(a):
                        'batch_per_gpu': B, 'global_batch': B * world, 'seq_len': cfg.pyramid.L, 'parallelism': f'dp{world} (sample-sharded, no collective)'},
             'algorithmic_tflop_per_image': round(per_sample_tf, 3),
             'end_to_end_tflops_per_gpu': round(per_sample_tf * B * a.steps / dt, 1),
-            'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+            'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), **ev,
         }
         if prof:
             ms = sum(r[0].elapsed_time(r[1]) for r in prof)

@@ -72,6 +72,7 @@ struct GemmParams {
     int group_m;              // row tiles per scheduling group (see launch_cfg)
     int stagger;              // > 0: the first wave of workgroups (one per CU) starts spread over this many shader cycles (see cvar_gemm_kernel)
     int tile_cfg;             // cvar_gemm_desc::tile_cfg (0 = automatic)
+    unsigned* pers_ctr;       // persistent kernels: this launch's 8 tile counters (one per XCD) + 1 exit counter, all zero at launch (self-resetting)
 };
 
 
@@ -92,9 +93,15 @@ static void make_fast_div(long d, unsigned* magic, int* shift) {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2, bool FAST = false, bool CUP = false>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2, bool FAST = false, bool CUP = false, bool PERS = false>
 __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParams p) {
     static_assert(!CUP || (CONV && FAST), "CUP (nearest x2 upsample folded into the conv) is a conv FAST variant");
+    // PERS (round 4): one workgroup per CU stays resident and walks over output tiles.  The workgroup timeline of the one-tile-per-workgroup
+    // kernel (profiles/r04_gemm_wg_timeline.txt, K = 1536: 41 us per tile) shows 1.7 us of dispatch gap + 2.3 us from entry to the first MFMA +
+    // an epilogue that ends in the drain of its own stores - a fifth of a CU's time outside the K loop, which is what hipBLASLt's persistent
+    // kernel does not pay.  Here the DMA stream simply runs on across the tile boundary: the last two K iterations of a tile fetch the first
+    // K tile of the NEXT output tile, the epilogue's stores drain under the next tile's first K iterations, nothing is dispatched in between.
+    static_assert(!PERS || (FAST && !CONV && sizeof(T) == 2 && NSTAGE == 2), "PERS is the plain bf16 FAST kernel");
     constexpr int NW = WM * WN;
     constexpr bool FRAG_PIPE = (BM == 256) && (!CONV || FAST);
 #ifndef CVAR_DMA_EARLY
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     constexpr bool TRANS = NW * 32 * (SUB_N + 4) * 4 <= NSTAGE * STAGE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef CVAR_GEMM_TIMING
-    const unsigned long long dbg_rt_entry = __builtin_amdgcn_s_memrealtime();
+    unsigned long long dbg_rt_entry = __builtin_amdgcn_s_memrealtime();
 #endif
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -152,19 +159,42 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
         }
     }
 
-    // ---- tile coordinates: bijective XCD remap, then grouped-M ordering
-    int bid = blockIdx.x;
-    {
-        const int nblk = gridDim.x, xcd = bid & 7, q = nblk >> 3, r = nblk & 7, local = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-    }
-    const int GM = p.group_m;             // row tiles per group: the tiles of GM consecutive rows share each W tile out of L2
-    const int group_sz = GM * p.tiles_n;
-    const int grp = bid / group_sz, first_m = grp * GM;
-    const int gm = min(p.tiles_m - first_m, GM);
-    const int tm = first_m + (bid % group_sz) % gm;
-    const int tn = (bid % group_sz) / gm;
-    const int m0 = tm * BM, n0 = tn * BN;
+    // ---- tile coordinates: bijective XCD remap, then grouped-M ordering.  v = virtual block id: the block index of the one-tile kernel; the
+    // persistent kernel walks v = blockIdx.x, blockIdx.x + gridDim.x (two static rounds), then local indices handed out by its XCD's counter
+    // (gridDim.x is a multiple of 8, so v & 7 - the XCD whose L2 holds this part of the tile space - never changes for a workgroup)
+    const int nblk_all = p.tiles_m * p.tiles_n;
+    auto tile_origin = [&](int v, int& m0_, int& n0_) {
+        const int xcd = v & 7, q = nblk_all >> 3, r = nblk_all & 7, local = v >> 3;
+        const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        const int GM = p.group_m;             // row tiles per group: the tiles of GM consecutive rows share each W tile out of L2
+        const int group_sz = GM * p.tiles_n;
+        const int grp = bid / group_sz, first_m = grp * GM;
+        const int gm = min(p.tiles_m - first_m, GM);
+        m0_ = (first_m + (bid % group_sz) % gm) * BM;
+        n0_ = ((bid % group_sz) / gm) * BN;
+    };
+    // persistent tile ids: this tile, the next one (needed two K tiles before this one ends) and - through pers_slot - the one after
+    __shared__ int pers_slot;
+    int vtile = (int)blockIdx.x;
+    int vnext = (PERS && (int)(blockIdx.x + gridDim.x) < nblk_all) ? (int)(blockIdx.x + gridDim.x) : -1;
+    // wave 0, lane 0: the RAW counter value fetched one epilogue ago (>= 0), turned into a tile id only when it is published at the next
+    // epilogue - touching the returned value any earlier puts an s_waitcnt vmcnt(0) for the atomic's round trip (1-2 us) into the epilogue
+    int pend = -1;
+    auto fetch_raw = [&]() { return (int)__hip_atomic_fetch_add(p.pers_ctr + ((int)blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto tile_of_raw = [&](int raw) {    // local index 2 G + raw of this workgroup's XCD; -1 when its part of the tile space is used up
+        const int x = (int)blockIdx.x & 7, G = (int)gridDim.x >> 3;
+        const int v = (2 * G + raw) * 8 + x;
+        return (raw >= 0 && v < nblk_all) ? v : -1;
+    };
+    bool pers_more = PERS && vnext >= 0;      // wave 0, lane 0: keep fetching (cleared once a published id came out as -1)
+    if (PERS && wave == 0 && lane == 0 && pers_more) pend = fetch_raw();
+    int cur = 0;                         // LDS stage of the K tile being computed; carried from tile to tile by the persistent kernel
+    bool pers_first = true;
+    for (;;) {                           // ---- one pass per output tile (a single pass unless PERS)
+    int m0, n0;
+    tile_origin(vtile, m0, n0);
+    int m0n = m0, n0n = n0;              // PERS: origin of the next tile (this tile again when there is none: its prefetch is then a harmless re-read)
+    if (PERS && vnext >= 0) tile_origin(vnext, m0n, n0n);
     const long zb = blockIdx.z;
 
     const char* const zero = (const char*)cvar_zero_chunk;
@@ -206,11 +236,17 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     unsigned a_off[A_PER_W], w_off[B_PER_W];
     const char* const a_tile = CONV ? Abase : Abase + (long)m0 * p.lda * ES;
     const char* const w_tile = Wbase + (long)n0 * p.ldw * ES;
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_tile, 0, CONV ? (int)p.conv_bytes : 0x7fffffff, 0x00020000);
+    // PERS: row offsets are NOT clamped (they then do not depend on the tile); rows past M fall outside the resource's range and read zeros
+    const long a_bytes = ((long)(p.M - m0 - 1) * p.lda + p.K) * ES;
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_tile, 0, CONV ? (int)p.conv_bytes : PERS ? (int)min(a_bytes, (long)0x7fffffff) : 0x7fffffff, 0x00020000);
     // W's range ends with the last row of the matrix: when K is not a multiple of the K tile (conv: K = 9 Cin) the last row's
     // tail would otherwise read whatever follows the weights - the A side is zero there, but 0 x Inf/NaN garbage is NaN
     const long w_bytes = ((long)(p.N - n0 - 1) * p.ldw + p.K) * ES;
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_tile, 0, (int)min(w_bytes, (long)0x7fffffff), 0x00020000);
+    // PERS: the same two resources for the next output tile
+    const long a_bytes_n = ((long)(p.M - m0n - 1) * p.lda + p.K) * ES, w_bytes_n = ((long)(p.N - n0n - 1) * p.ldw + p.K) * ES;
+    const __amdgpu_buffer_rsrc_t a_rsrc_n = __builtin_amdgcn_make_buffer_rsrc((void*)(Abase + (long)m0n * p.lda * ES), 0, (int)min(a_bytes_n, (long)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc_n = __builtin_amdgcn_make_buffer_rsrc((void*)(Wbase + (long)n0n * p.ldw * ES), 0, (int)min(w_bytes_n, (long)0x7fffffff), 0x00020000);
     // conv FAST (stride 1, no upsample, Cin % 32 == 0, input < 2 GiB): each 32-element half of a K tile lies inside ONE tap, so
     // (tap, channel) of the two halves are wave-uniform scalars advanced per K tile; a lane keeps its pixel's byte offset and a
     // 9-bit mask of in-range taps per piece, and because the swizzled chunk of a lane is the same for all its pieces
@@ -224,7 +260,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #pragma unroll
         for (int jj = 0; jj < A_PER_W; ++jj) {
             const int row = (wave + jj * NW) * 8 + lr;
-            a_off[jj] = (unsigned)min(row, p.M - 1 - m0) * (unsigned)(p.lda * ES) + (unsigned)((slot ^ ((row >> 1) & 7)) * 16);
+            a_off[jj] = (unsigned)(PERS ? row : min(row, p.M - 1 - m0)) * (unsigned)(p.lda * ES) + (unsigned)((slot ^ ((row >> 1) & 7)) * 16);
         }
     }
     if (FAST && CONV) {
@@ -263,7 +299,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #pragma unroll
         for (int jj = 0; jj < B_PER_W; ++jj) {
             const int row = w_piece(jj) * 8 + lr;
-            w_off[jj] = (unsigned)min(row, p.N - 1 - n0) * (unsigned)(p.ldw * ES) + (unsigned)((slot ^ ((row >> 1) & 7)) * 16);
+            w_off[jj] = (unsigned)(PERS ? row : min(row, p.N - 1 - n0)) * (unsigned)(p.ldw * ES) + (unsigned)((slot ^ ((row >> 1) & 7)) * 16);
         }
     }
     // conv FAST: lane offset / tap of the NEXT tile to issue, then advance the scalar (tap, channel) state by one K tile
@@ -304,8 +340,22 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     // one 1-KiB DMA piece of tile kt: idx < A_PER_W -> A operand, else W operand
     // the K loop issues pieces unconditionally (past the last tile it re-fetches the last one into a stage nobody reads), so
     // that its body is one basic block and the scheduler can place DMA issue and address math between MFMAs
+    const int nk_pers = p.K / KT;          // PERS: K tiles per output tile (K % KT == 0 on the FAST path)
     auto issue_one = [&](int kt, int stage, int idx) {
         char* sbase = smem + stage * STAGE;
+        if constexpr (PERS) {
+            // K tile index kt >= nk_pers addresses K tile kt - nk_pers of the NEXT output tile (wave-uniform selects of two SGPR quads)
+            const bool nx = kt >= nk_pers;
+            const int koff = (nx ? kt - nk_pers : kt) * 128;
+            if (idx < A_PER_W) {
+                if (nx) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc_n, (lptr_t)(sbase + (wave + idx * NW) * 1024), 16, (int)a_off[idx], koff, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(sbase + (wave + idx * NW) * 1024), 16, (int)a_off[idx], koff, 0, 0);
+            } else {
+                if (nx) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc_n, (lptr_t)(sbase + BM * 128 + w_piece(idx - A_PER_W) * 1024), 16, (int)w_off[idx - A_PER_W], koff, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(sbase + BM * 128 + w_piece(idx - A_PER_W) * 1024), 16, (int)w_off[idx - A_PER_W], koff, 0, 0);
+            }
+            return;
+        }
         if (FAST) {
             // buffer_load_dwordx4 v_off, s[rsrc], s_koff offen lds: resource and K offset are scalar, the lane offset is fixed
             if (idx < A_PER_W) {
@@ -423,7 +473,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     constexpr int XB_N2 = NL < NJ16 ? NL : NJ16;                  // pieces with xb_same_iter: 2 NM16 - XB_PM = 2 NJ16 MFMAs lie behind the barrier
     bf16x8_t a3[RING], bw[2][M16 ? NJ16 : 1];
     bf16x8_t fa[2][XB2 ? MI16 : 1], fb[2][XB2 ? NJ16 : 1];      // XB2: complete fragment sets of both k-steps
-    int cur = 0;
+    static_assert(!PERS || XB, "the persistent kernel runs the XB loop");
+    if constexpr (!PERS) cur = 0;
     if constexpr (XB2) {
         // tiles kt_lo and kt_lo + 1 in flight; the first tile's k-step-0 fragments are read before the loop
 #pragma unroll
@@ -440,18 +491,25 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #pragma unroll
         for (int i = 0; i < MI16; ++i) fa[0][i] = *(const bf16x8_t*)(A16 + i * 16 * 128 + ((kq ^ sw16) * 16));
     } else if constexpr (XB) {
+        // PERS, every tile but the first: K tile 0 already lies in stage `cur` (fetched by the previous tile's last two iterations, landed and
+        // met before its epilogue); the first half of K tile 1 goes into the other stage, which held the epilogue's staging rows until the
+        // barrier just passed.  Nothing to wait for.
+        if (!PERS || pers_first) {
 #pragma unroll
-        for (int idx = 0; idx < NL; ++idx) issue_one(kt_lo, 0, idx);
+            for (int idx = 0; idx < NL; ++idx) issue_one(kt_lo, cur, idx);
+        }
 #pragma unroll
         for (int t = 0; t < NL; ++t)
-            if (xb_same_iter(t)) issue_one(min(kt_lo + 1, nk - 1), 1, t);
-        // the pieces of the first tile have landed when at most the XB_N2 later ones are outstanding (vmcnt retires in order)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XB_N2) : "memory");
-        __builtin_amdgcn_s_barrier();
+            if (xb_same_iter(t)) issue_one(PERS ? kt_lo + 1 : min(kt_lo + 1, nk - 1), cur ^ 1, t);
+        if (!PERS || pers_first) {
+            // the pieces of the first tile have landed when at most the XB_N2 later ones are outstanding (vmcnt retires in order)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XB_N2) : "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         {
             const int l15 = lane & 15, kq = lane >> 4, sw16 = (l15 >> 1) & 7;
-            const char* A16 = smem + (wm * SUB_M + l15) * 128;
-            const char* B16 = smem + BM * 128 + (wn * SUB_N + l15) * 128;
+            const char* A16 = smem + cur * STAGE + (wm * SUB_M + l15) * 128;
+            const char* B16 = smem + cur * STAGE + BM * 128 + (wn * SUB_N + l15) * 128;
 #pragma unroll
             for (int j = 0; j < NJ16; ++j) bw[0][j] = *(const bf16x8_t*)(B16 + j * 16 * 128 + ((kq ^ sw16) * 16));
             a3[0] = *(const bf16x8_t*)(A16 + ((kq ^ sw16) * 16));
@@ -579,8 +637,9 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
 #pragma unroll
                             for (int t = 0; t < NL; ++t)
                                 if (xb_pos(t) == m) {
-                                    if (xb_same_iter(t)) issue_one(min(kt + 2, nk - 1), cur, t);     // tile kt+2 into the stage this tile releases
-                                    else issue_one(min(kt + 1, nk - 1), nxt, t);                      // the rest of the group started behind the previous barrier
+                                    // PERS: indices >= nk run on into the next output tile (issue_one); else dead re-reads of the last tile
+                                    if (xb_same_iter(t)) issue_one(PERS ? kt + 2 : min(kt + 2, nk - 1), cur, t);     // tile kt+2 into the stage this tile releases
+                                    else issue_one(PERS ? kt + 1 : min(kt + 1, nk - 1), nxt, t);                      // the rest of the group started behind the previous barrier
                                 }
                             if (m == XB_PM - 1) {
                                 // every LDS read of this tile has been issued: wait for them and for this wave's pieces of tile kt+1, then meet
@@ -685,6 +744,16 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     const unsigned long long dbg_rt_loop_end = __builtin_amdgcn_s_memrealtime();
 #endif
     __syncthreads();
+    if constexpr (PERS) {
+        // every wave has passed the barrier: nobody reads pers_slot any more (it is read right behind the barrier that follows the epilogue).
+        // Publish the id fetched one epilogue ago (the tile after next) and fetch another one; its value is not needed for a whole tile.
+        if (wave == 0 && lane == 0) {
+            const int v = pers_more ? tile_of_raw(pend) : -1;
+            pers_slot = v;
+            pers_more = v >= 0;
+            if (pers_more) pend = fetch_raw();
+        }
+    }
 
     // ---- epilogue: accumulators -> LDS (per-wave region, 32 rows at a time) -> row-major 8-wide vectors, so that
     // bias / gate / residual loads and the C stores are 16-byte and coalesced (128-B rows per 8 lanes).
@@ -697,20 +766,19 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     // is the output row, register r the column (r&3) + 8*(r>>2) + 4*(lane>>5) - four consecutive columns per register quad.
     // Staging a block is then 4 ds_write_b128 per 32 columns instead of 16 ds_write_b32 (LDS stores are the narrow port:
     // 64-85 B/clk); rows of EROW = SUB_N + 4 floats keep the 8-lane store groups on distinct banks.
-    constexpr bool FULL32 = TRANS;
+    constexpr bool FULL32 = TRANS && !M16;                // 16x16 blocks (M16) are staged one block row = 16 output rows at a time
     constexpr int SROWS = FULL32 ? 32 : 16;
-    static_assert(NW * SROWS * EROW * 4 <= NSTAGE * STAGE, "epilogue staging must fit the pipeline LDS");
-    float* stg = (float*)smem + wave * (SROWS * EROW);
+    static_assert(NW * SROWS * EROW * 4 <= (PERS ? 1 : NSTAGE) * STAGE, "epilogue staging must fit the pipeline LDS");
+    // PERS: stage `cur` already holds the first K tile of the next output tile; the staging rows live in the other one (whose last reader
+    // finished before the barrier above)
+    float* stg = (float*)(smem + (PERS ? (cur ^ 1) * STAGE : 0)) + wave * (SROWS * EROW);
     // rows of block i land in the staging region: the whole transposed block at once (4 x b128 per 32 columns), or - tiles whose
     // pipeline LDS is too small for 32 staged rows per wave keep the plain MFMA layout (lane = column) - 16 rows as b32 stores
     auto stage_block = [&](int i, int half) {
         if constexpr (M16) {                  // 16x16 blocks: lane & 15 = row inside the block, lane >> 4 selects 4 of its 16 columns
-            if (half != 0) return;
             const int l15 = lane & 15, cq = lane >> 4;
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int j = 0; j < NJ16; ++j) *(f32x4_t*)(stg + (16 * t + l15) * EROW + j * 16 + 4 * cq) = acc4[2 * i + t][j];
+            for (int j = 0; j < NJ16; ++j) *(f32x4_t*)(stg + l15 * EROW + j * 16 + 4 * cq) = acc4[2 * i + half][j];
         } else if (FULL32) {
             if (half != 0) return;
 #pragma unroll
@@ -1002,12 +1070,12 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     }
     }   // generic epilogue
 #ifdef CVAR_GEMM_TIMING
-    if (lane == 0 && wave == 0 && blockIdx.x < CVAR_DBG_WG_MAX && blockIdx.y == 0 && blockIdx.z == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the stores of this wave have been acknowledged
+    if (lane == 0 && wave == 0 && (PERS ? vtile : (int)blockIdx.x) < CVAR_DBG_WG_MAX && blockIdx.y == 0 && blockIdx.z == 0) {
+        if (!PERS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the stores of this wave have been acknowledged (the persistent kernel lets them drain under the next tile)
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long* o = cvar_gemm_dbg_wg + (size_t)blockIdx.x * 5;
+        unsigned long long* o = cvar_gemm_dbg_wg + (size_t)(PERS ? vtile : (int)blockIdx.x) * 5;
         o[0] = dbg_rt_entry; o[1] = dbg_rt_loop; o[2] = dbg_rt_loop_end; o[3] = __builtin_amdgcn_s_memrealtime(); o[4] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
     }
     if (lane == 0 && blockIdx.x < 64) {
@@ -1021,6 +1089,27 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
         atomicAdd(&cvar_gemm_dbg_tot[6], dbg_ew); atomicAdd(&cvar_gemm_dbg_tot[3], dbg_vm); atomicAdd(&cvar_gemm_dbg_tot[4], dbg_bar); atomicAdd(&cvar_gemm_dbg_tot[5], dbg_comp);
     }
 #endif
+    if constexpr (!PERS) break;
+    if (vnext < 0) break;                 // wave-uniform: this workgroup's part of the tile space is used up
+    __syncthreads();                      // all staging rows have been read (the next tile's K tile 1 is about to land on them); pers_slot is published
+    vtile = vnext;
+    vnext = __builtin_amdgcn_readfirstlane(pers_slot);
+    pers_first = false;
+#ifdef CVAR_GEMM_TIMING
+    dbg_rt_entry = __builtin_amdgcn_s_memrealtime();
+#endif
+    }   // tile loop
+    if constexpr (PERS) {
+        // exit protocol: the last workgroup out clears the launch's counters for the slot's next user
+        if (wave == 0 && lane == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the pending tile fetch has been performed
+            const unsigned old = __hip_atomic_fetch_add(p.pers_ctr + 8, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == gridDim.x - 1) {
+#pragma unroll
+                for (int x = 0; x < 9; ++x) __hip_atomic_store(p.pers_ctr + x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is sticky per (function, device): set it the first time a kernel is launched on a
@@ -1034,6 +1123,38 @@ static void set_max_lds_once(K kfn, size_t lds) {
         (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (dev >= 0 && dev < 64) done[dev] = 1;
     }
+}
+
+// ---- persistent kernels: per-launch tile counters.  A ring of self-resetting slots in device memory (9 words used per slot: one counter per
+// XCD + the exit counter whose last incrementer zeroes the slot).  A launch takes the next slot; by the time the ring comes round
+// (CVAR_PERS_SLOTS launches later) the slot's previous user has long finished.  A captured HIP graph replays the slot baked into its node,
+// which is fine for the same reason as long as the graph does not run concurrently with itself.
+// Built, bit-identical to the one-tile kernels (tests/test_gpu_kernels.py::test_persistent_gemm_...), measured NEUTRAL on every d24 shape
+// (profiles/r04_gemm_persistent_rejected.txt: what it saves in dispatch gap and prologue it pays in a longer epilogue and its own per-tile
+// setup; the epilogue - 4.7 us of a 41 us tile at K = 1536 - is what neither form overlaps).  Compiled only with -DCVAR_GEMM_PERS=1.
+#ifndef CVAR_GEMM_PERS
+#define CVAR_GEMM_PERS 0
+#endif
+#define CVAR_PERS_SLOTS 4096
+__device__ unsigned cvar_pers_counters[CVAR_PERS_SLOTS * 16];
+static unsigned* pers_counters(int* ncu) {
+    static unsigned* base[64] = {nullptr};
+    static int cus[64] = {0};
+    static unsigned next = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) return nullptr;
+    if (!base[dev]) {
+        void* ptr = nullptr;
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(cvar_pers_counters)) != hipSuccess) return nullptr;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
+        cus[dev] = prop.multiProcessorCount;
+        base[dev] = (unsigned*)ptr;
+    }
+    *ncu = cus[dev];
+    const unsigned slot = __atomic_fetch_add(&next, 1u, __ATOMIC_RELAXED) % CVAR_PERS_SLOTS;
+    return base[dev] + (size_t)slot * 16;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE = 2, bool CONVFAST = false, bool CUP = false>
@@ -1073,6 +1194,23 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
         return CVAR_EUNSUPPORTED;
     } else if (p.K % (128 / (int)sizeof(T)) == 0 && (long)(BM - 1) * p.lda * (long)sizeof(T) + (long)p.K * (long)sizeof(T) < (1L << 31) &&
                (long)(BN - 1) * p.ldw * (long)sizeof(T) + (long)p.K * (long)sizeof(T) < (1L << 31)) {
+        // persistent form of the 256x256 bf16 tiles: at least two rounds of tiles, no split-K / batch dimension, tile_cfg 7 / 8 select the one-tile-per-workgroup kernels (8 / 4 waves) for A/B runs
+        if constexpr (CVAR_GEMM_PERS != 0 && sizeof(T) == 2 && BM == 256 && BN == 256 && NSTAGE == 2) {
+            int ncu = 0;
+            const int ntiles = p.tiles_m * p.tiles_n;
+            if (splits == 1 && batch == 1 && p.stagger == 0 && p.tile_cfg != 7 && p.tile_cfg != 8 && nk_all >= 4) {
+                unsigned* ctr = pers_counters(&ncu);
+                const int gx = (ncu / 8) * 8;
+                if (ctr && gx >= 8 && ntiles >= 2 * gx) {
+                    p.pers_ctr = ctr;
+                    auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, false, NSTAGE, true, false, true>;
+                    set_max_lds_once(kfn, lds);
+                    hipLaunchKernelGGL(kfn, dim3((unsigned)gx), block, lds, st, p);
+                    CVAR_CHECK_LAUNCH();
+                    return CVAR_OK;
+                }
+            }
+        }
         auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, false, NSTAGE, true>;
         set_max_lds_once(kfn, lds);
         hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
@@ -1088,7 +1226,7 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
 // cvar_gemm_desc::tile_cfg -> the A/B selector of launch_typed: -1 automatic, 0 128x128 tiles only, 1 the 8-wave 256x256 tile, 3 the
 // 4-wave 256x256 tile (part of the call, not of the process environment)
 static int gemm_cfg_override(const GemmParams& p) {
-    return p.tile_cfg == 1 ? 0 : p.tile_cfg == 2 ? 1 : p.tile_cfg == 3 ? 3 : p.tile_cfg == 4 ? 4 : -1;
+    return p.tile_cfg == 1 ? 0 : (p.tile_cfg == 2 || p.tile_cfg == 7) ? 1 : (p.tile_cfg == 3 || p.tile_cfg == 8) ? 3 : p.tile_cfg == 4 ? 4 : -1;
 }
 
 template <typename T>

@@ -58,15 +58,43 @@ def sharded_timed_run(step: Callable[[int], object], steps: int, warmup: int, un
     t0 = time.perf_counter()
     for i in range(steps):
         step(warmup + i)
-    sync(); barrier()
+    sync()
+    own = time.perf_counter() - t0                         # this rank's own K steps, before it waits for the others
+    barrier()
     dt = time.perf_counter() - t0
+    LAST_RUN['rank_seconds'] = [own]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64)
+        o = torch.tensor([own], dtype=torch.float64)
         if dist.get_backend() == 'nccl':
-            t = t.cuda()
+            t, o = t.cuda(), o.cuda()
+        every = [torch.zeros_like(o) for _ in range(world)]
+        dist.all_gather(every, o)                          # every rank's own clock (reported per rank, see collective_evidence)
+        LAST_RUN['rank_seconds'] = [float(x.item()) for x in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return world * units_per_step * steps / dt, dt
+
+
+LAST_RUN: dict = {'rank_seconds': []}                       # per-rank seconds of the last sharded_timed_run (rank order)
+
+
+def collective_evidence(device: Optional[torch.device] = None) -> dict:
+    """What proves "the collective library saw N ranks" from inside the job: a REAL all_reduce of one element of ones over the
+    default group (SUM == number of ranks that took part), the backend and its library version.  World 1 without a group: one rank, no call."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return {'collective_backend': None, 'rccl_ranks': 1, 'rccl_version': None}
+    backend = dist.get_backend()
+    one = torch.ones(1, dtype=torch.float32, device=device if (backend == 'nccl' and device is not None) else 'cpu')
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    ver = None
+    if backend == 'nccl':
+        try:
+            ver = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                                   # never lose the bench line over a version string
+            ver = 'unknown'
+    return {'collective_backend': 'rccl' if backend == 'nccl' else backend, 'rccl_ranks': int(round(float(one.item()))), 'rccl_version': ver}
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------

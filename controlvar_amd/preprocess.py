@@ -15,7 +15,8 @@ Here JPEG decoding stays on the host; everything after it runs on the GPU from t
 * ``cvar_crop_flip_normalize`` / ``cvar_ignore_mask`` finish the sample.
 
 Random choices (crop offset, flip) are inputs: the caller owns the RNG, as with the reference's ``random`` module.
-Not yet on the device: COCO-RLE decoding and the colour map of segmentation conditions (imagenetC.py:15-37; pycocotools).
+Segmentation conditions (imagenetC.py:15-37): uncompressed COCO run lengths or decoded masks -> colour map on the device (cvar_rle_paint);
+the compressed RLE *string* of pycocotools is not decoded here (see _runs_of).
 """
 from __future__ import annotations
 
@@ -172,52 +173,34 @@ def create_color_map() -> np.ndarray:
     return np.array([[r, g, b] for r in lv for g in lv for b in lv])[1:]
 
 
-def rle_from_string(s) -> list:
-    """COCO compressed RLE string -> run lengths.  pycocotools (common/maskApi.c, rleFrString; the dependency is not vendored
-    in the reference and not installed here, so this codec is restated from the published algorithm - parity UNPINNED):
-    6-bit characters offset by 48, 5 payload bits + continuation bit 0x20, sign-extended by bit 0x10 of the last group,
-    and every value after the third is a delta against the value two places back."""
-    if isinstance(s, str):
-        s = s.encode('ascii')
-    cnts, p = [], 0
-    while p < len(s):
-        x, k, more = 0, 0, 1
-        while more:
-            c = s[p] - 48
-            x |= (c & 0x1f) << (5 * k)
-            more = c & 0x20
-            p += 1
-            k += 1
-            if not more and (c & 0x10):
-                x |= -1 << (5 * k)
-        if len(cnts) > 2:
-            x += cnts[-2]
-        cnts.append(x)
-    return cnts
-
-
-def rle_to_string(cnts: Sequence[int]) -> str:
-    """inverse of rle_from_string (rleToString); used by the tests"""
-    out = bytearray()
-    for i, x in enumerate(cnts):
-        x = int(x)
-        if i > 2:
-            x -= int(cnts[i - 2])
-        more = True
-        while more:
-            c = x & 0x1f
-            x >>= 5
-            more = (x != -1) if (c & 0x10) else (x != 0)
-            if more:
-                c |= 0x20
-            out.append(c + 48)
-    return out.decode('ascii')
+def runs_from_mask(mask) -> list:
+    """binary (h, w) mask -> uncompressed COCO run lengths: column-major, first run counts zeros (possibly 0 long).  What a caller
+    holding a decoded mask (pycocotools ``mask.decode``, the reference's own step at imagenetC.py:21) passes on."""
+    m = np.asarray(mask)
+    if m.ndim != 2:
+        raise ValueError(f'mask must be (h, w), got {m.shape}')
+    flat = (m != 0).T.reshape(-1)
+    change = np.flatnonzero(flat[1:] != flat[:-1]) + 1
+    edges = np.concatenate([[0], change, [flat.size]])
+    runs = np.diff(edges).tolist()
+    return ([0] + runs) if flat.size and flat[0] else runs
 
 
 def _runs_of(segmentation) -> Tuple[list, int, int]:
+    """a segmentation is a decoded (h, w) mask, or a COCO RLE dict with UNCOMPRESSED counts (a list of run lengths, column-major,
+    zeros first - the form SAM-style annotation writers emit before string compression).  The compressed counts STRING is pycocotools'
+    own wire format (maskApi.c rleFrString); that dependency is absent here and its codec could not be pinned against it, so the
+    product does not decode it (round 4): decode with pycocotools where the annotations are prepared - the reference needs it
+    installed anyway - or convert once with tools/coco_rle_string.py, which is an unpinned convenience and says so."""
+    if isinstance(segmentation, np.ndarray) or (hasattr(segmentation, 'shape') and not isinstance(segmentation, dict)):
+        m = np.asarray(segmentation)
+        return runs_from_mask(m), int(m.shape[0]), int(m.shape[1])
     h, w = segmentation['size']
     counts = segmentation['counts']
-    runs = rle_from_string(counts) if isinstance(counts, (str, bytes)) else [int(c) for c in counts]
+    if isinstance(counts, (str, bytes)):
+        raise TypeError('compressed COCO RLE strings are not decoded by controlvar_amd (parity with pycocotools cannot be pinned here): '
+                        'pass pycocotools.mask.decode(segmentation) or uncompressed counts (tools/coco_rle_string.py converts)')
+    runs = [int(c) for c in counts]
     if sum(runs) != h * w:
         raise ValueError(f'RLE covers {sum(runs)} pixels, size says {h}x{w}')
     return runs, h, w

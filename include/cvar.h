@@ -77,7 +77,8 @@ typedef struct {
      *   tile_cfg      0 automatic; 1 only 128x128 tiles; 2 the 8-wave 256x256 tile wherever it applies; 3 the 4-wave 256x256
      *                 tile (A/B measurements - results are bit-identical across tile choices of one split-K decision); 5: 3x3 convs
      *                 stay on the implicit-GEMM tiles, 6: eligible 3x3 convs take the LDS-halo kernel at any size (conv_halo.hip sums
-     *                 K chunk-major instead of tap-major: same math, different fp32 rounding);
+     *                 K chunk-major instead of tap-major: same math, different fp32 rounding); 7 / 8: the 8- / 4-wave 256x256 tile as ONE tile per
+     *                 workgroup instead of the persistent kernel that large launches take since round 4 (same sums, bit-identical);
      *   stagger       > 0: the first workgroup of every CU starts delayed by up to this many shader cycles (by its index), which
      *                 de-phases the output bursts of equally long tiles; 0: off.  Never changes results. */
     void* ws; int64_t ws_bytes;

@@ -81,24 +81,25 @@ def ignore_masks(cond: np.ndarray, patch_nums, first_masked_scale=5):
 
 
 def process_anns(anns, image_size, colormap):
-    """datasets/imagenetC.py:15-29 with the RLE decoded by explicit run expansion (column-major), numpy only.
-    The RLE *string* codec is controlvar_amd.preprocess.rle_from_string - restated from pycocotools' published maskApi.c,
-    parity unpinned (pycocotools is neither vendored in the reference nor installed in this image)."""
-    from controlvar_amd.preprocess import rle_from_string
+    """datasets/imagenetC.py:15-29 with UNCOMPRESSED run lengths (or decoded masks) expanded explicitly, column-major, numpy only.
+    pycocotools' compressed string codec is outside the product and outside this oracle (absent dependency, parity unpinned -
+    tools/coco_rle_string.py)."""
     mask = np.zeros((image_size, image_size, 3))
     for ann in anns:
         if ann['area'] < 5000:
             continue
         seg = ann['segmentation']
-        h, w = seg['size']
-        runs = rle_from_string(seg['counts']) if isinstance(seg['counts'], (str, bytes)) else list(seg['counts'])
-        flat = np.zeros(h * w, np.uint8)
-        pos, val = 0, 0
-        for r in runs:
-            flat[pos:pos + r] = val
-            pos += r
-            val ^= 1
-        m = flat.reshape(w, h).T                       # column-major
+        if isinstance(seg, np.ndarray):
+            m = (seg != 0).astype(np.uint8)
+        else:
+            h, w = seg['size']
+            flat = np.zeros(h * w, np.uint8)
+            pos, val = 0, 0
+            for r in list(seg['counts']):
+                flat[pos:pos + r] = val
+                pos += r
+                val ^= 1
+            m = flat.reshape(w, h).T                       # column-major
         X, Y = m.shape[1], m.shape[0]
         index = np.where(m == 1)
         x = int(np.mean(index[1]) // (X / 11))

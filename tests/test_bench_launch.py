@@ -25,6 +25,9 @@ def test_bench_gpus2_spawns_two_ranks_without_torchrun():
     assert out['config']['global_batch'] == 2 * out['config']['batch_per_gpu'] and out['config']['parallelism'] == 'dp2'
     assert out['ms_per_step'] >= 78, out                           # the slow rank (2 x 40 ms) sets the clock
     assert abs(out['value'] - 2 * out['config']['batch_per_gpu'] * 3 / (out['ms_per_step'] * 3e-3)) / out['value'] < 0.01
+    # self-evidencing keys: the collective really saw two ranks, and each rank's own rate is on the line
+    assert out['rccl_ranks'] == 2 and out['collective_backend'] == 'gloo' and 'rccl_version' in out
+    assert len(out['per_rank_value']) == 2 and out['per_rank_value'][0] > 1.5 * out['per_rank_value'][1]      # rank 1 sleeps twice as long
 
 
 def test_bench_under_torchrun_env_is_one_rank_of_the_world():
@@ -32,7 +35,7 @@ def test_bench_under_torchrun_env_is_one_rank_of_the_world():
     p = _run(['--gpus', '1', '--steps', '2', '--warmup', '0', '--stub-step-ms', '10'], dict(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1'))
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
-    assert out['n_gpus'] == 1
+    assert out['n_gpus'] == 1 and out['rccl_ranks'] == 1 and len(out['per_rank_value']) == 1
 
 
 def test_bench_refuses_more_gpus_than_visible():

@@ -138,20 +138,46 @@ def _random_anns(seed, n=6, size=512):
         runs = np.diff(edges).tolist()
         if flat[0] == 1:
             runs = [0] + runs
-        anns.append({'area': int(m.sum()), 'segmentation': {'size': [size, size], 'counts': P.rle_to_string(runs)}, '_runs': runs})
+        anns.append({'area': int(m.sum()), 'segmentation': {'size': [size, size], 'counts': runs}, '_runs': runs, '_mask': m})
     return anns
 
 
-def test_rle_string_codec_round_trip_and_small_cases():
-    assert P.rle_to_string([0, 4]) == '04' and P.rle_from_string('04') == [0, 4]
-    assert P.rle_from_string(P.rle_to_string([5, 3, 40, 2, 1000, 7])) == [5, 3, 40, 2, 1000, 7]
+def test_uncompressed_rle_semantics_against_an_independent_implementation():
+    """runs_from_mask / the run expansion of the oracle against transformers' SAM post-processing (_mask_to_rle / _rle_to_mask:
+    "the format expected by pycoco tools", written independently of this repo): same counts for the same mask, same mask back."""
+    sam = pytest.importorskip('transformers.models.sam.image_processing_sam')
+    anns = _random_anns(1)
+    masks = torch.from_numpy(np.stack([a['_mask'] for a in anns]).astype(bool))
+    theirs = sam._mask_to_rle(masks)
+    for a, t_ in zip(anns, theirs):
+        assert t_['size'] == [512, 512] and [int(c) for c in t_['counts']] == a['_runs'] == P.runs_from_mask(a['_mask'])
+        back = sam._rle_to_mask({'size': [512, 512], 'counts': a['_runs']}).numpy()
+        assert np.array_equal(back, a['_mask'].astype(bool))
+    full, empty = np.ones((4, 3), np.uint8), np.zeros((4, 3), np.uint8)
+    assert P.runs_from_mask(full) == [0, 12] and P.runs_from_mask(empty) == [12]
+    assert P.create_color_map().shape == (124, 3) and tuple(P.create_color_map()[0]) == (0, 0, 64)
+
+
+def test_compressed_rle_strings_are_refused_by_the_product_and_the_tool_matches_hand_derived_answers():
+    """The product does not decode pycocotools' compressed strings (unpinnable here).  tools/coco_rle_string.py is a labelled convenience;
+    its known answers below were worked out BY HAND from the published format (6-bit groups + 48, low 5 bits payload, 0x20 = more,
+    sign = bit 0x10 of the last group, deltas against the value two back from the fourth value on):
+      [0, 4]          -> '0' '4'
+      [5, 3, 40, 2]   -> '5' '3', then 40 as itself (third value, no delta): 40 = 0b01000 + 32 * 1 -> groups 8|0x20 = 40 -> 'X', then 1 -> '1';
+                         then 2 - 3 = -1 -> one group 0b11111 (sign bit set, rest all ones) = 31 -> 'O'
+      [0, 0, 0, 35]   -> '0' '0' '0', then 35 - 0 = 35 = 3 + 32 * 1 -> 3|0x20 = 35 -> 'S', then 1 -> '1'"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('coco_rle_string', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'coco_rle_string.py'))
+    C = importlib.util.module_from_spec(spec); spec.loader.exec_module(C)
+    for runs, text in (([0, 4], '04'), ([5, 3, 40, 2], '53X1O'), ([0, 0, 0, 35], '000S1')):
+        assert C.rle_to_string(runs) == text and C.rle_from_string(text) == runs
     rng = np.random.default_rng(0)
     for _ in range(20):
         runs = rng.integers(0, 70000, rng.integers(1, 60)).tolist()
-        assert P.rle_from_string(P.rle_to_string(runs)) == runs       # deltas (negative values) and multi-character groups
-    for ann in _random_anns(1):
-        assert P.rle_from_string(ann['segmentation']['counts']) == ann['_runs']
-    assert P.create_color_map().shape == (124, 3) and tuple(P.create_color_map()[0]) == (0, 0, 64)
+        assert C.rle_from_string(C.rle_to_string(runs)) == runs       # deltas (negative values) and multi-character groups
+    with pytest.raises(TypeError):
+        P.annotation_colours([{'area': 9999, 'segmentation': {'size': [512, 512], 'counts': C.rle_to_string([512 * 512])}}], 512)
 
 
 def test_annotation_colours_follow_the_centroid_rule():
@@ -164,7 +190,12 @@ def test_annotation_colours_follow_the_centroid_rule():
         assert tuple(col) in {tuple(c) for c in P.create_color_map()}
     assert want.shape == (512, 512, 3) and want.max() > 0
     with pytest.raises(ValueError):
-        P.annotation_colours([{'area': 9999, 'segmentation': {'size': [256, 256], 'counts': P.rle_to_string([256 * 256])}}], 512)
+        P.annotation_colours([{'area': 9999, 'segmentation': {'size': [256, 256], 'counts': [256 * 256]}}], 512)
+    # decoded masks (what pycocotools.mask.decode hands the reference, imagenetC.py:21) give the same runs / colours as the run lists
+    as_masks = [{'area': a_['area'], 'segmentation': a_['_mask']} for a_ in anns]
+    e2, o2, c2 = P.annotation_colours(as_masks, 512)
+    assert np.array_equal(e2, run_ends) and np.array_equal(o2, offsets) and np.array_equal(c2, colours)
+    assert np.array_equal(R.process_anns(as_masks, 512, P.create_color_map()), want)
 
 
 @pytest.mark.gpu

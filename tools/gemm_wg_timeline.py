@@ -45,6 +45,6 @@ for k, idx in per_cu.items():
 gaps = np.array(gaps)
 print(f'{len(per_cu)} distinct CUs, {np.mean([len(v) for v in per_cu.values()]):.1f} workgroups per CU; dispatch gap (exit -> next entry on the same CU): mean {gaps.mean():.2f} us, p10 {np.percentile(gaps, 10):.2f}, p50 {np.percentile(gaps, 50):.2f}, p90 {np.percentile(gaps, 90):.2f}, negative (overlap) {np.mean(gaps < 0) * 100:.0f} %')
 tot = pro.mean() + loop.mean() + epi.mean() + max(gaps.mean(), 0)
-print(f'share of a CU\\'s time: gap {max(gaps.mean(), 0) / tot * 100:.1f} %  prologue {pro.mean() / tot * 100:.1f} %  K loop {loop.mean() / tot * 100:.1f} %  epilogue {epi.mean() / tot * 100:.1f} %')
+print(f'share of the time of a CU: gap {max(gaps.mean(), 0) / tot * 100:.1f} %  prologue {pro.mean() / tot * 100:.1f} %  K loop {loop.mean() / tot * 100:.1f} %  epilogue {epi.mean() / tot * 100:.1f} %')
 first = np.array([t[v[0], 0] for v in per_cu.values()]); last = np.array([t[v[-1], 3] for v in per_cu.values()])
 print(f'ramp: first entries spread over {first.max():.1f} us; last exits between {last.min():.1f} and {last.max():.1f} us (tail {last.max() - last.min():.1f} us)')
