@@ -153,9 +153,13 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p) {
 // (a template takes its launch bounds from the FIRST declaration: without them here the kernels are compiled for 1024-thread groups, 128 VGPRs)
 template <bool HOLES, bool QPRE> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_mfma_bf16_kernel(const AttnParams p);
 template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_mfma_bf16_v1_kernel(const AttnParams p);
-template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma_bf16_pipe_kernel(const AttnParams p);
+// round 4: wave-internally pipelined form of the prescaled kernel - built, correct (35 tests, fuzz 600 / 600), 16 % SLOWER at the last scale
+// (profiles/r04_attn_pipe_rejected.txt); compiled only with -DCVAR_ATTN_PIPE=1
 #ifndef CVAR_ATTN_PIPE
-#define CVAR_ATTN_PIPE 1
+#define CVAR_ATTN_PIPE 0
+#endif
+#if CVAR_ATTN_PIPE
+template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma_bf16_pipe_kernel(const AttnParams p);
 #endif
 
 // impl: 0 = auto (MFMA flash kernel for bf16, row-wise exact kernel for fp32), 1 = row-wise
@@ -208,12 +212,14 @@ static int cvar_attention_impl(const void* qkv, const void* q, int dtype, int R,
         const long nblk = (long)cdiv(l, 128) * H * R;
         if (nblk > 0x7fffffffL) return CVAR_EUNSUPPORTED;
         const dim3 grid((unsigned)nblk), block(256);
-        if (qpre && CVAR_ATTN_PIPE && impl != 3) {             // round 4: the wave-internally pipelined kernel (impl 3 = the round-3 kernel, A/B and tests)
+#if CVAR_ATTN_PIPE
+        if (qpre) {
             if (holes) hipLaunchKernelGGL((attn_mfma_bf16_pipe_kernel<true>), grid, block, 0, as_stream(stream), p);
             else hipLaunchKernelGGL((attn_mfma_bf16_pipe_kernel<false>), grid, block, 0, as_stream(stream), p);
             CVAR_CHECK_LAUNCH();
             return CVAR_OK;
         }
+#endif
         if (holes) { if (qpre) hipLaunchKernelGGL((attn_mfma_bf16_kernel<true, true>), grid, block, 0, as_stream(stream), p);
                      else hipLaunchKernelGGL((attn_mfma_bf16_kernel<true, false>), grid, block, 0, as_stream(stream), p); }
         else { if (qpre) hipLaunchKernelGGL((attn_mfma_bf16_kernel<false, true>), grid, block, 0, as_stream(stream), p);
@@ -722,9 +728,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 //             region 2   QK^T(t+1), key block 1 + PV(t)                                       ||  exp / row sum / pack of tile t
 //             barrier - K(t+2), V(t+1) registers -> LDS - barrier - global loads of K(t+3), V(t+2)
 // ================================================================================================
-#ifndef CVAR_ATTN_PIPE
-#define CVAR_ATTN_PIPE 1
-#endif
+#if CVAR_ATTN_PIPE
 template <bool HOLES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma_bf16_pipe_kernel(const AttnParams p) {
     constexpr int D = 64, KT = 64;
@@ -811,8 +815,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int kt0 = 0;
 
     // one step: softmax + PV of the tile at kt0 (scores in `cur`), S^T of the tile behind it into `nxt`
-    auto step = [&](f32x16_t (&cur)[2], f32x16_t (&nxt)[2], auto MASK, auto HAVE_NEXT) {
-        constexpr bool have_next = decltype(HAVE_NEXT)::value;
+    // (One body for every tile: MASK / last-tile variants as template flags made the compiler copy both score blocks at the joins of the
+    // variants - 70 v_mov per step and 60 spilled registers.  The mask is a wave-uniform branch around an in-place pass instead, and the
+    // last tile computes the scores of a tile that does not exist - zeros out of the range-checked loads, never used, 10 idle MFMAs.)
+    auto step = [&](f32x16_t (&cur)[2], f32x16_t (&nxt)[2]) {
+        constexpr bool have_next = true;
+        const bool masked = kt0 + KT > wg_min_kv;
         if (active) {
             // ---- region 1: next tile's key block 0 on the matrix pipe; mask + row maximum of this tile on the vector pipe
             if constexpr (have_next) {
@@ -823,7 +831,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) nxt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], nxt[0], 0, 0, 0);
             }
-            if constexpr (decltype(MASK)::value) {
+            if (masked) {
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -943,15 +951,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     load_v(KT);
     // ---- tiles: the two score blocks swap roles every step.  MASK is compile-time (tiles every query of the workgroup sees completely
     // run without per-score compares); the last tile has no successor to compute.
-    auto dispatch = [&](f32x16_t (&cur)[2], f32x16_t (&nxt)[2]) {
-        const bool last = kt0 + KT >= kv_end, masked = kt0 + KT > wg_min_kv;
-        if (last) { if (masked) step(cur, nxt, Yes{}, No{}); else step(cur, nxt, No{}, No{}); }
-        else { if (masked) step(cur, nxt, Yes{}, Yes{}); else step(cur, nxt, No{}, Yes{}); }
-        return !last;
-    };
     for (;;) {
-        if (!dispatch(sA, sB)) break;
-        if (!dispatch(sB, sA)) break;
+        step(sA, sB);
+        if (kt0 >= kv_end) break;
+        step(sB, sA);
+        if (kt0 >= kv_end) break;
     }
     lsum += __shfl_xor(lsum, 32, 64);
     if (qi < p.l) {
@@ -969,6 +973,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
     }
 }
+
+#endif   // CVAR_ATTN_PIPE
 
 extern "C" int cvar_attention_rowwise(const void* qkv, const void* q, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
                                       const int* lvl_end_host, int n_lvl, const int* hole_host, void* out, float* lse, void* stream) {

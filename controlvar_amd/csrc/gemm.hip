@@ -73,6 +73,8 @@ struct GemmParams {
     int stagger;              // > 0: the first wave of workgroups (one per CU) starts spread over this many shader cycles (see cvar_gemm_kernel)
     int tile_cfg;             // cvar_gemm_desc::tile_cfg (0 = automatic)
     unsigned* pers_ctr;       // persistent kernels: this launch's 8 tile counters (one per XCD) + 1 exit counter, all zero at launch (self-resetting)
+    // fused split-K (host side of launch_cfg only): the call's own parameters, the launch's per-tile arrival counters, the slice count
+    const GemmParams* sk_final; unsigned* sk_ctr; int sk_nsplit;
 };
 
 
@@ -93,8 +95,42 @@ static void make_fast_div(long d, unsigned* magic, int* shift) {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2, bool FAST = false, bool CUP = false, bool PERS = false>
-__global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParams p) {
+// tile origin of virtual block id v: bijective XCD remap, then grouped-M ordering (shared by the kernel body and the fused split-K tail)
+__device__ __forceinline__ void gemm_tile_origin(const GemmParams& p, int v, int BM, int BN, int& m0_, int& n0_) {
+    const int nblk_all = p.tiles_m * p.tiles_n;
+    const int xcd = v & 7, q = nblk_all >> 3, r = nblk_all & 7, local = v >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    const int GM = p.group_m;             // row tiles per group: the tiles of GM consecutive rows share each W tile out of L2
+    const int group_sz = GM * p.tiles_n;
+    const int grp = bid / group_sz, first_m = grp * GM;
+    const int gm = min(p.tiles_m - first_m, GM);
+    m0_ = (first_m + (bid % group_sz) % gm) * BM;
+    n0_ = ((bid % group_sz) / gm) * BN;
+}
+
+// 16-byte fp32 store / load at DEVICE scope (sc1): written through to / fetched from the point all eight XCD L2s agree on.  The fused split-K
+// hand-over uses these per access instead of a release / acquire fence pair - on this part a fence is `buffer_wbl2 sc1` + `buffer_inv sc1`, a
+// write-back and an invalidate of the whole 4 MB L2 by every slice (measured: 63 us per small GEMM, B = 1 generation 36 -> 90 ms).
+__device__ __forceinline__ void store_f32x4_sc1(float* ptr, f32x4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory"); }
+// eight loads and the wait for them in ONE asm statement: the compiler does not know that a load issued by inline asm arrives later, so the
+// destination registers must not be visible to it before the s_waitcnt
+__device__ __forceinline__ void load8_f32x4_sc1(f32x4_t (&w)[8], const float* const (&ptr)[8]) {
+    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
+                 "global_load_dwordx4 %1, %9, off sc1\n\t"
+                 "global_load_dwordx4 %2, %10, off sc1\n\t"
+                 "global_load_dwordx4 %3, %11, off sc1\n\t"
+                 "global_load_dwordx4 %4, %12, off sc1\n\t"
+                 "global_load_dwordx4 %5, %13, off sc1\n\t"
+                 "global_load_dwordx4 %6, %14, off sc1\n\t"
+                 "global_load_dwordx4 %7, %15, off sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
+                 : "v"(ptr[0]), "v"(ptr[1]), "v"(ptr[2]), "v"(ptr[3]), "v"(ptr[4]), "v"(ptr[5]), "v"(ptr[6]), "v"(ptr[7])
+                 : "memory");
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2, bool FAST = false, bool CUP = false, bool PERS = false, bool SC1 = false>
+__device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
     static_assert(!CUP || (CONV && FAST), "CUP (nearest x2 upsample folded into the conv) is a conv FAST variant");
     // PERS (round 4): one workgroup per CU stays resident and walks over output tiles.  The workgroup timeline of the one-tile-per-workgroup
     // kernel (profiles/r04_gemm_wg_timeline.txt, K = 1536: 41 us per tile) shows 1.7 us of dispatch gap + 2.3 us from entry to the first MFMA +
@@ -163,16 +199,7 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     // persistent kernel walks v = blockIdx.x, blockIdx.x + gridDim.x (two static rounds), then local indices handed out by its XCD's counter
     // (gridDim.x is a multiple of 8, so v & 7 - the XCD whose L2 holds this part of the tile space - never changes for a workgroup)
     const int nblk_all = p.tiles_m * p.tiles_n;
-    auto tile_origin = [&](int v, int& m0_, int& n0_) {
-        const int xcd = v & 7, q = nblk_all >> 3, r = nblk_all & 7, local = v >> 3;
-        const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-        const int GM = p.group_m;             // row tiles per group: the tiles of GM consecutive rows share each W tile out of L2
-        const int group_sz = GM * p.tiles_n;
-        const int grp = bid / group_sz, first_m = grp * GM;
-        const int gm = min(p.tiles_m - first_m, GM);
-        m0_ = (first_m + (bid % group_sz) % gm) * BM;
-        n0_ = ((bid % group_sz) / gm) * BN;
-    };
+    auto tile_origin = [&](int v, int& m0_, int& n0_) { gemm_tile_origin(p, v, BM, BN, m0_, n0_); };
     // persistent tile ids: this tile, the next one (needed two K tiles before this one ends) and - through pers_slot - the one after
     __shared__ int pers_slot;
     int vtile = (int)blockIdx.x;
@@ -934,8 +961,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                             *(bf16x8_t*)cp = pack_bf16x8(v);
                         } else {
                             const f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                            *(f32x4_t*)cp = o0;
-                            *(f32x4_t*)(cp + 16) = o1;
+                            if constexpr (SC1) { store_f32x4_sc1((float*)cp, o0); store_f32x4_sc1((float*)(cp + 16), o1); }
+                            else { *(f32x4_t*)cp = o0; *(f32x4_t*)(cp + 16) = o1; }
                         }
                     }
                 }
@@ -1050,8 +1077,8 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
                 } else {
                     float* cp = (float*)Cdst + cbase;
                     const f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                    *(f32x4_t*)cp = o0;
-                    *(f32x4_t*)(cp + 4) = o1;
+                    if constexpr (SC1) { store_f32x4_sc1(cp, o0); store_f32x4_sc1(cp + 4, o1); }
+                    else { *(f32x4_t*)cp = o0; *(f32x4_t*)(cp + 4) = o1; }
                 }
             } else {
                 for (int e = 0; e < 8; ++e) {
@@ -1112,6 +1139,108 @@ __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParam
     }
 }
 
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2, bool FAST = false, bool CUP = false, bool PERS = false>
+__global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParams p) {
+    cvar_gemm_tile<T, BM, BN, WM, WN, CONV, NSTAGE, FAST, CUP, PERS>(p);
+}
+
+// One output quad of a split-K GEMM: the slices' fp32 partials summed in slice order (bit-reproducible), then the complete epilogue of `p`.
+template <bool SC1 = false>
+__device__ __forceinline__ void splitk_finish_quad(const GemmParams& p, const float* __restrict__ part, int nsplit, int m, int n) {
+    f32x4_t v;
+    const float* const q0 = part + (long)m * p.N + n;
+    const long sstride = (long)p.M * p.N;
+    if constexpr (SC1) {
+        // slices 0 .. 7 in one batch (slots past the last slice re-read the last one and are ignored), then further batches of eight
+        f32x4_t w[8];
+        const float* ptr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ptr[u] = q0 + (long)min(u, nsplit - 1) * sstride;
+        load8_f32x4_sc1(w, ptr);
+        v = w[0];
+#pragma unroll
+        for (int u = 1; u < 8; ++u)
+            if (u < nsplit) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += w[u][e];
+            }
+        for (int s0 = 8; s0 < nsplit; s0 += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ptr[u] = q0 + (long)min(s0 + u, nsplit - 1) * sstride;
+            load8_f32x4_sc1(w, ptr);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < nsplit) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += w[u][e];
+                }
+        }
+    } else {
+        v = *(const f32x4_t*)q0;
+        // the loads of the slices are independent: eight in flight at a time (a one-load-one-add loop is a chain of up to 15 memory latencies)
+        for (int s0 = 1; s0 < nsplit; s0 += 8) {
+            f32x4_t w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < nsplit) w[u] = *(const f32x4_t*)(q0 + (long)(s0 + u) * sstride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < nsplit) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += w[u][e];
+                }
+        }
+    }
+    long orow = m;
+    if (p.remap_l > 0) {
+        const int sq = fast_div(m, p.remap_magic, p.remap_shift);
+        orow = (long)sq * p.remap_L + p.remap_off + (m - sq * p.remap_l);
+    }
+    const float* grow = p.gate ? p.gate + (long)fast_div(m, p.gate_magic, p.gate_shift) * p.ldg : nullptr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = v[e] * p.alpha;
+        if (p.bias) x += p.bias[n + e];
+        if (p.C2) st_any(p.C2, p.in_dtype, (long)m * p.ldc + n + e, x);
+        if (p.act == CVAR_ACT_GELU_TANH) x = gelu_tanh_f(x);
+        else if (p.act == CVAR_ACT_GELU_GRAD) x *= gelu_tanh_grad(ld_any(p.aux, p.out_dtype, (long)m * p.ldc + n + e));
+        if (grow) x *= grow[n + e] * (p.gate_scale ? p.gate_scale[fast_div(m, p.gate_magic, p.gate_shift)] : 1.0f);
+        if (p.residual) x += ld_any(p.residual, p.res_dtype, (long)m * p.ldr + n + e);
+        if (p.split_n > 0) {
+            if (n < p.split_n) st_any(p.Cs, p.out_dtype, (long)m * p.ld_split + n + e, x * p.split_alpha);
+            else st_any(p.C, p.out_dtype, orow * p.ldc + (n - p.split_n) + e, x);
+        } else st_any(p.C, p.out_dtype, orow * p.ldc + n + e, x);
+    }
+}
+
+// Split-K with the reduction folded into the GEMM launch (round 4): every slice stores its fp32 partial tile as before, then signs a per-tile
+// counter; the slice that signs LAST sums the tile's partials in slice order - the same order, hence the same bits, as cvar_splitk_epilogue_kernel -
+// and applies the epilogue.  One launch instead of two for every small-M GEMM: 859 epilogue launches of 6.5 us in a B = 1 generation
+// (profiles/r04_b1_kernel_stats.txt).  ps = the slice view (C = workspace, plain fp32 stores), pf = the call's own parameters.
+template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool FAST>
+__global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_splitk_fused_kernel(const GemmParams ps, const GemmParams pf, unsigned* __restrict__ ctr, int nsplit) {
+    cvar_gemm_tile<T, BM, BN, WM, WN, false, NSTAGE, FAST, false, false, true>(ps);       // partial tile stored with sc1 (write-through)
+    __shared__ int sk_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's partial stores are acknowledged at device scope ...
+    __syncthreads();                                       // ... every wave's are
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(ctr + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sk_last = old == (unsigned)nsplit - 1u;
+        if (old == (unsigned)nsplit - 1u) __hip_atomic_store(ctr + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the slot's next user
+    }
+    __syncthreads();
+    if (!sk_last) return;
+    int m0, n0;
+    gemm_tile_origin(ps, (int)blockIdx.x, BM, BN, m0, n0);
+    const int rows = min(BM, pf.M - m0), cols4 = min(BN, pf.N - n0) / 4;
+    const float* part = (const float*)ps.C;
+    for (int i = threadIdx.x; i < rows * cols4; i += WM * WN * 64) {
+        const int m = m0 + i / cols4, n = n0 + (i % cols4) * 4;
+        splitk_finish_quad<true>(pf, part, nsplit, m, n);       // sc1 loads: the other slices' partials as the device sees them
+    }
+}
+
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is sticky per (function, device): set it the first time a kernel is launched on a
 // device instead of on every launch (~1200 launches per generation)
 template <typename K>
@@ -1157,9 +1286,38 @@ static unsigned* pers_counters(int* ncu) {
     return base[dev] + (size_t)slot * 16;
 }
 
+// ---- fused split-K: per-tile arrival counters.  Same ring-of-self-resetting-slots scheme as the persistent kernels' counters: a launch takes the
+// next slot of CVAR_SK_TILES words (all zero: the last slice to sign a tile's counter clears it), the ring comes round after CVAR_SK_SLOTS launches.
+// Built, bit-identical to the two-kernel form (tests/test_gpu_kernels.py::test_fused_split_k_...), SLOWER (profiles/r04_small_batch.txt): a device-scope
+// fence per slice (buffer_wbl2 + buffer_inv of the whole L2) costs 63 us per GEMM, per-access sc1 stores / loads still 30 us - the one workgroup that
+// reduces a tile reads all its slices at memory latency, where the separate epilogue kernel spreads the same bytes over the chip.  Compiled only
+// with -DCVAR_GEMM_FUSED_SPLITK=1.
+#ifndef CVAR_GEMM_FUSED_SPLITK
+#define CVAR_GEMM_FUSED_SPLITK 0
+#endif
+#define CVAR_SK_SLOTS 2048
+#define CVAR_SK_TILES 256
+__device__ unsigned cvar_splitk_counters[CVAR_SK_SLOTS * CVAR_SK_TILES];
+static unsigned* splitk_counters() {
+    static unsigned* base[64] = {nullptr};
+    static unsigned next = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) return nullptr;
+    if (!base[dev]) {
+        void* ptr = nullptr;
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(cvar_splitk_counters)) != hipSuccess) return nullptr;
+        base[dev] = (unsigned*)ptr;
+    }
+    const unsigned slot = __atomic_fetch_add(&next, 1u, __ATOMIC_RELAXED) % CVAR_SK_SLOTS;
+    return base[dev] + (size_t)slot * CVAR_SK_TILES;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE = 2, bool CONVFAST = false, bool CUP = false>
 static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     GemmParams p = gp;
+    // tiles a split-K launch can land on (launch_typed): 64x128, 128x128, the 4-wave 256x256 - only these carry a fused-reduction instance
+    constexpr bool SK_TILE = (BM == 64 && BN == 128) || (BM == 128 && BN == 128) || (BM == 256 && BN == 256 && WN == 2);
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     // Group height.  Within a group the A row blocks (GM x BM x K) are re-read once per column tile and the W tile once per group;
@@ -1168,6 +1326,7 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     // neutral or -1 % for the K = 1536 bf16-output GEMMs; 16 loses everywhere.
     if (p.group_m <= 0) p.group_m = (!p.conv && ((long)p.K * (long)sizeof(T) >= 8192 || p.out_dtype == CVAR_F32)) ? 4 : 8;
     if (p.conv) { const int kt_e = 128 / (int)sizeof(T); p.cv_adv = kt_e / p.Cin; p.cv_rem = kt_e % p.Cin; }
+    if (p.sk_final && !(SK_TILE && sizeof(T) == 2 && !p.conv)) return CVAR_EUNSUPPORTED;        // a fused split-K launch must reach a kernel that reduces
     const size_t lds = NSTAGE * (BM + BN) * 128;
     const int nk_all = (p.K + (128 / (int)sizeof(T)) - 1) / (128 / (int)sizeof(T));
     const int splits = p.split_tiles > 0 ? (nk_all + p.split_tiles - 1) / p.split_tiles : 1;
@@ -1211,10 +1370,28 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
                 }
             }
         }
+        if constexpr (sizeof(T) == 2 && CVAR_GEMM_FUSED_SPLITK != 0 && CVAR_TU_PLAIN && !CVAR_TU_CONV && SK_TILE) {
+            if (p.sk_final) {
+                auto kfn = cvar_gemm_splitk_fused_kernel<T, BM, BN, WM, WN, NSTAGE, true>;
+                set_max_lds_once(kfn, lds);
+                hipLaunchKernelGGL(kfn, grid, block, lds, st, p, *p.sk_final, p.sk_ctr, p.sk_nsplit);
+                CVAR_CHECK_LAUNCH();
+                return CVAR_OK;
+            }
+        }
         auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, false, NSTAGE, true>;
         set_max_lds_once(kfn, lds);
         hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
     } else {
+        if constexpr (sizeof(T) == 2 && CVAR_GEMM_FUSED_SPLITK != 0 && CVAR_TU_PLAIN && !CVAR_TU_CONV && SK_TILE) {
+            if (p.sk_final) {
+                auto kfn = cvar_gemm_splitk_fused_kernel<T, BM, BN, WM, WN, NSTAGE, false>;
+                set_max_lds_once(kfn, lds);
+                hipLaunchKernelGGL(kfn, grid, block, lds, st, p, *p.sk_final, p.sk_ctr, p.sk_nsplit);
+                CVAR_CHECK_LAUNCH();
+                return CVAR_OK;
+            }
+        }
         auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, false, NSTAGE>;
         set_max_lds_once(kfn, lds);
         hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
@@ -1309,45 +1486,8 @@ int cvar_gemm_launch_conv_bf16(const GemmParams& p, int batch, hipStream_t st) {
 // partial tiles to a caller workspace; this kernel sums the slices in a fixed order and applies the full epilogue.
 __global__ __launch_bounds__(256) void cvar_splitk_epilogue_kernel(const float* __restrict__ part, int nsplit, const GemmParams p) {
     const long nvec = (long)p.M * (p.N / 4);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-        const int m = (int)(i / (p.N / 4));
-        const int n = (int)(i % (p.N / 4)) * 4;
-        f32x4_t v = *(const f32x4_t*)(part + (long)m * p.N + n);
-        // the slices are added in slice order (bit-reproducible), but their loads are independent: eight in flight at a time - the one-load-one-add loop was a
-        // chain of up to 15 memory latencies in a kernel with 3 workgroups (7.2 us per launch, 849 launches in a B = 1 generation)
-        for (int s0 = 1; s0 < nsplit; s0 += 8) {
-            f32x4_t w[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (s0 + u < nsplit) w[u] = *(const f32x4_t*)(part + (long)(s0 + u) * p.M * p.N + (long)m * p.N + n);
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (s0 + u < nsplit) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += w[u][e];
-                }
-        }
-        long orow = m;
-        if (p.remap_l > 0) {
-            const int sq = fast_div(m, p.remap_magic, p.remap_shift);
-            orow = (long)sq * p.remap_L + p.remap_off + (m - sq * p.remap_l);
-        }
-        const float* grow = p.gate ? p.gate + (long)fast_div(m, p.gate_magic, p.gate_shift) * p.ldg : nullptr;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = v[e] * p.alpha;
-            if (p.bias) x += p.bias[n + e];
-            if (p.C2) st_any(p.C2, p.in_dtype, (long)m * p.ldc + n + e, x);
-            if (p.act == CVAR_ACT_GELU_TANH) x = gelu_tanh_f(x);
-            else if (p.act == CVAR_ACT_GELU_GRAD) x *= gelu_tanh_grad(ld_any(p.aux, p.out_dtype, (long)m * p.ldc + n + e));
-            if (grow) x *= grow[n + e] * (p.gate_scale ? p.gate_scale[fast_div(m, p.gate_magic, p.gate_shift)] : 1.0f);
-            if (p.residual) x += ld_any(p.residual, p.res_dtype, (long)m * p.ldr + n + e);
-            if (p.split_n > 0) {
-                if (n < p.split_n) st_any(p.Cs, p.out_dtype, (long)m * p.ld_split + n + e, x * p.split_alpha);
-                else st_any(p.C, p.out_dtype, orow * p.ldc + (n - p.split_n) + e, x);
-            } else st_any(p.C, p.out_dtype, orow * p.ldc + n + e, x);
-        }
-    }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256)
+        splitk_finish_quad<false>(p, part, nsplit, (int)(i / (p.N / 4)), (int)(i % (p.N / 4)) * 4);
 }
 
 
@@ -1399,6 +1539,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     make_fast_div(p.remap_l, &p.remap_magic, &p.remap_shift);
     make_fast_div(p.gate ? p.gate_rows : 1, &p.gate_magic, &p.gate_shift);
     p.split_tiles = 0; p.split_stride = 0;
+    p.pers_ctr = nullptr; p.sk_final = nullptr; p.sk_ctr = nullptr; p.sk_nsplit = 0;
     p.tile_cfg = d->tile_cfg; p.stagger = d->stagger > 0 ? d->stagger : 0; p.group_m = d->group_m > 0 ? d->group_m : 0;
     // split-K workspace: part of the call (caller-owned, any stream / device), nothing process-wide
     float* const g_splitk_ws = (d->ws && d->ws_bytes > 0 && (((uintptr_t)d->ws & 15) == 0)) ? (float*)d->ws : nullptr;
@@ -1436,6 +1577,20 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
             ps.alpha = 1.0f; ps.bias = nullptr; ps.act = CVAR_ACT_NONE; ps.gate = nullptr; ps.residual = nullptr; ps.C2 = nullptr; ps.aux = nullptr; ps.gate_scale = nullptr;
             ps.C = g_splitk_ws; ps.out_dtype = CVAR_F32; ps.ldc = d->N; ps.remap_l = 0; ps.split_n = 0; ps.Cs = nullptr; ps.strideC = 0;
             ps.split_tiles = per; ps.split_stride = (long)d->M * d->N;
+            // one launch: the last slice of every tile reduces and finishes it (bf16 operands; tile_cfg 9 keeps the two-kernel form for A/B runs)
+            if (CVAR_GEMM_FUSED_SPLITK && d->dtype == CVAR_BF16 && d->tile_cfg != 9 && d->N % 8 == 0) {      // N % 8: the partial tiles go out as 16-byte sc1 stores
+                const int t_m = d->M <= 64 ? (d->M + 63) / 64 : long_k_splits ? (d->M + 255) / 256 : (d->M + 127) / 128;
+                const int t_n = long_k_splits ? (d->N + 255) / 256 : (d->N + 127) / 128;
+                unsigned* ctr = (long)t_m * t_n <= CVAR_SK_TILES ? splitk_counters() : nullptr;
+                if (ctr) {
+                    GemmParams pfin = p;
+                    pfin.tile_cfg = 0;
+                    ps.sk_final = &pfin; ps.sk_ctr = ctr; ps.sk_nsplit = splits;
+                    const int rc = launch_typed<bf16_t>(ps, 1, st);
+                    if (rc != CVAR_OK) return rc;
+                    return CVAR_OK;
+                }
+            }
             const int rc = d->dtype == CVAR_BF16 ? launch_typed<bf16_t>(ps, 1, st) : cvar_gemm_launch_f32(ps, 1, st);
             if (rc != CVAR_OK) return rc;
             const long nvec = (long)d->M * (d->N / 4);
@@ -1446,7 +1601,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     }
     // stride-1 3x3 convs (plain or behind the nearest x2 upsample) over 32-channel multiples with 160-multiple outputs on 16-multiple images (every ResnetBlock conv of the VQVAE
     // decoder from 16x16 up): the LDS-halo kernel (conv_halo.hip).  tile_cfg 5 keeps them on the implicit-GEMM tiles, 6 forces the halo kernel at any grid size (A/B runs, tests).
-    if (d->conv && d->dtype == CVAR_BF16 && d->stride == 1 && d->batch == 1 && (d->tile_cfg == 0 || d->tile_cfg == 6) &&
+    if (d->conv && d->dtype == CVAR_BF16 && d->stride == 1 && d->batch == 1 && (d->tile_cfg == 0 || d->tile_cfg == 6 || d->tile_cfg == 9) &&
         d->Cin % 32 == 0 && d->Hout % 16 == 0 && d->Wout % 16 == 0 && d->act == CVAR_ACT_NONE && !d->gate && d->alpha == 1.0f &&
         !d->pre_act && !d->aux && !d->gate_scale && d->remap_l == 0 && d->split_n == 0 && d->strideC == 0 && d->ldc == d->N &&
         d->ldw == d->K &&      // the halo kernel addresses packed [Cout][9 Cin] weights: padded weight rows stay on the implicit-GEMM path
@@ -1455,7 +1610,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
         // wide form: Cout a multiple of 160, bf16 output, optional bf16 residual; two workgroups per CU or the implicit-GEMM tiles win (640->640 at 16x16)
         const bool wide = d->N % 160 == 0 && d->out_dtype == CVAR_BF16 && (((uintptr_t)d->C & 7) == 0) &&
                           (!d->residual || (d->res_dtype == CVAR_BF16 && d->ldr == d->N && (((uintptr_t)d->residual & 7) == 0))) &&
-                          (tiles * (d->N / 160) >= 512 || d->tile_cfg == 6);
+                          true;       // round 4: at any grid size - small batches (B = 1: 36.5 -> 34.9 ms, B = 8: 71.0 -> 69.8 ms per generation, profiles/r04_small_batch.txt) gain too
         // narrow form: Cout <= 32 (conv_out, 160 -> 3), bf16 or fp32 output, no residual - the implicit-GEMM tile spends its time re-fetching the input
         const bool narrow = d->N <= 32 && !d->residual && (d->out_dtype == CVAR_BF16 || d->out_dtype == CVAR_F32) && (tiles >= 512 || d->tile_cfg == 6);
         if (wide || narrow)

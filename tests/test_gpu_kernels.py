@@ -712,3 +712,46 @@ def test_persistent_gemm_equals_the_one_tile_per_workgroup_kernel(gpu_device, M,
             want = A.float() @ W.float().t() + bias
             assert not torch.isnan(ref.float()).any()
             assert (ref.float() - want).abs().max() < 0.06 * max(1.0, float(want.abs().max()) / 8)
+
+
+@pytest.mark.parametrize('M,N,K', [(4, 4608, 1536), (36, 1536, 6144), (100, 6144, 1536), (256, 1536, 1536), (676, 1536, 6144), (1024, 4608, 1536)])
+def test_fused_split_k_is_bit_identical_to_the_two_kernel_form(gpu_device, M, N, K):
+    """Small-M GEMMs are split along K.  With -DCVAR_GEMM_FUSED_SPLITK=1 (not the default build: measured slower, profiles/r04_small_batch.txt)
+    the slice that signs a tile's arrival counter last sums the tile's fp32 partials in slice order and applies the epilogue inside the same
+    launch (cvar_gemm_splitk_fused_kernel) - same order, same bits as the second launch (cvar_splitk_epilogue_kernel, tile_cfg 9).  In the
+    default build both settings are the two-kernel form and this checks its run-to-run determinism over every epilogue of the transformer."""
+    from controlvar_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(gpu_device)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(gpu_device)
+    bias = torch.randn(N, generator=g).to(gpu_device)
+    l = max(M // 2, 1)
+    R = (M + l - 1) // l
+    ada = (torch.randn(R, 2 * N, generator=g) * 0.3).to(gpu_device)
+    res0 = (torch.randn(M, N, generator=g) * 0.5).to(gpu_device)
+
+    def run(cfg, kind):
+        ops.GEMM_TILE_CFG = cfg
+        try:
+            if kind == 'plain':
+                out = torch.full((M, N), float('nan'), device=gpu_device, dtype=torch.bfloat16)
+                ops.gemm(A, W, out, M=M, N=N, K=K, bias=bias)
+            elif kind == 'gelu':
+                out = torch.full((M, N), float('nan'), device=gpu_device, dtype=torch.bfloat16)
+                ops.gemm(A, W, out, M=M, N=N, K=K, bias=bias, act=ops.ACT_GELU_TANH)
+            elif kind == 'gate_res':
+                out = res0.clone()
+                ops.gemm(A, W, out, M=M, N=N, K=K, bias=bias, gate=ada, gate_off=N, ldg=2 * N, gate_rows=l, residual=out)
+            else:
+                out = torch.full((M, N), float('nan'), device=gpu_device, dtype=torch.float32)
+                ops.gemm(A, W, out, M=M, N=N, K=K)
+            return out
+        finally:
+            ops.GEMM_TILE_CFG = 0
+    for kind in ('plain', 'gelu', 'gate_res', 'f32out'):
+        ref = run(9, kind)
+        assert not torch.isnan(ref.float()).any(), kind
+        for rep in range(3):
+            assert torch.equal(run(0, kind), ref), (kind, rep)
+    want = A.float() @ W.float().t() + bias
+    assert (run(0, 'plain').float() - want).abs().max() < 0.06 * max(1.0, float(want.abs().max()) / 8)

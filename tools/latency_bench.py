@@ -3,13 +3,14 @@
 import sys, os, time, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from controlvar_amd import models
+from controlvar_amd import models, ops
+ops.GEMM_TILE_CFG = int(os.environ.get('ISO_CFG', '0'))      # 6: every eligible 3x3 conv on the LDS-halo kernel whatever the grid size
 dev = torch.device('cuda:0')
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 vae = models.build_vae(ch=160).to(dev)
 var = models.build_control_var(vae, depth=depth, mask_type='interleave_append', multi_cond=True).to(dev).eval()
 res = {}
-for B in (1, 4, 8, 16):
+for B in [int(b) for b in os.environ.get('LAT_B', '1,4,8,16').split(',')]:
     labels = torch.arange(B) % 1000; types = torch.arange(B) % 4
     var.autoregressive_infer_cfg(B, labels, g_seed=0, cfg=4.0, top_k=900, top_p=0.96, cond_type=types); torch.cuda.synchronize()
     t0 = time.perf_counter()
