@@ -795,17 +795,26 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
     // 64-85 B/clk); rows of EROW = SUB_N + 4 floats keep the 8-lane store groups on distinct banks.
     constexpr bool FULL32 = TRANS && !M16;                // 16x16 blocks (M16) are staged one block row = 16 output rows at a time
     constexpr int SROWS = FULL32 ? 32 : 16;
-    static_assert(NW * SROWS * EROW * 4 <= (PERS ? 1 : NSTAGE) * STAGE, "epilogue staging must fit the pipeline LDS");
+#ifndef CVAR_GEMM_EPI_PIPE
+#define CVAR_GEMM_EPI_PIPE 0
+#endif
+    // EPI_PIPE (round 4, 16x16-block kernels; built, bit-identical, measured: plain bf16 epilogue neutral, GELU / gate + residual epilogues 3-7 %
+    // SLOWER - 256 VGPRs + 52 B of scratch in the 8-wave kernel, profiles/r04_gemm_epilogue_pipe_rejected.txt; -DCVAR_GEMM_EPI_PIPE=1 to build it):
+    // two staging regions per wave and the row-major reads of block row ih + 1 issued BEFORE the arithmetic and the stores of block row ih -
+    // the LDS write -> read round trip (~250 cycles, once per 16 output rows, eight times per wave) sits in front of every pass
+    constexpr bool EPI_PIPE = (CVAR_GEMM_EPI_PIPE != 0) && M16 && !PERS;
+    constexpr int NSTG = EPI_PIPE ? 2 : 1;
+    static_assert(NW * SROWS * EROW * 4 * NSTG <= (PERS ? 1 : NSTAGE) * STAGE, "epilogue staging must fit the pipeline LDS");
     // PERS: stage `cur` already holds the first K tile of the next output tile; the staging rows live in the other one (whose last reader
     // finished before the barrier above)
-    float* stg = (float*)(smem + (PERS ? (cur ^ 1) * STAGE : 0)) + wave * (SROWS * EROW);
+    float* stg = (float*)(smem + (PERS ? (cur ^ 1) * STAGE : 0)) + wave * (SROWS * EROW * NSTG);
     // rows of block i land in the staging region: the whole transposed block at once (4 x b128 per 32 columns), or - tiles whose
     // pipeline LDS is too small for 32 staged rows per wave keep the plain MFMA layout (lane = column) - 16 rows as b32 stores
     auto stage_block = [&](int i, int half) {
         if constexpr (M16) {                  // 16x16 blocks: lane & 15 = row inside the block, lane >> 4 selects 4 of its 16 columns
             const int l15 = lane & 15, cq = lane >> 4;
 #pragma unroll
-            for (int j = 0; j < NJ16; ++j) *(f32x4_t*)(stg + l15 * EROW + j * 16 + 4 * cq) = acc4[2 * i + half][j];
+            for (int j = 0; j < NJ16; ++j) *(f32x4_t*)(stg + (EPI_PIPE ? half * (SROWS * EROW) : 0) + l15 * EROW + j * 16 + 4 * cq) = acc4[2 * i + half][j];
         } else if (FULL32) {
             if (half != 0) return;
 #pragma unroll
@@ -853,7 +862,7 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
     constexpr bool SPEC = (BM * BN >= 128 * 160) && ES == 2;      // bf16 kernels only: the fp32 parity mode is not a throughput path, and every variant costs compile time
     bool done = false;
     if constexpr (SPEC) {
-        auto run = [&](auto OUTBF, auto ACT, auto GATE, auto RES, auto REMAP) {
+        auto run = [&](auto OUTBF, auto ACT, auto GATE, auto RES, auto REMAP) __attribute__((always_inline)) {
             constexpr bool out_bf = decltype(OUTBF)::value, gate = decltype(GATE)::value, remap = decltype(REMAP)::value;
             constexpr int act = decltype(ACT)::value, res = decltype(RES)::value;          // res: 0 none, 1 fp32, 2 bf16
             constexpr int OES = out_bf ? 2 : 4, RES_ES = res == 2 ? 2 : 4;
@@ -902,18 +911,35 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
                 }
             };
             if constexpr (gate || res != 0 || act == CVAR_ACT_GELU_GRAD) fetch_operands(0);
+            // EPI_PIPE: the staged values of a block row, read one block row ahead (unconditionally: the staging rows always exist)
+            f32x4_t pa[2][EPI_PIPE ? NPASS : 1][2];
+            auto read_rows = [&](int ihh) {
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const float* sp = stg_r + (ihh & 1) * (SROWS * EROW) + (ps * RPP) * EROW;
+                    pa[ihh & 1][ps][0] = *(const f32x4_t*)sp;
+                    pa[ihh & 1][ps][1] = *(const f32x4_t*)(sp + 4);
+                }
+            };
+            if constexpr (EPI_PIPE) { stage_block(0, 0); read_rows(0); }
 #pragma clang loop unroll(full)
             for (int ih = 0; ih < 2 * MI; ++ih) {
                 const int i = ih >> 1, half = ih & 1, bsel = ih & 1;
                 if constexpr (gate || res != 0 || act == CVAR_ACT_GELU_GRAD) { if (ih + 1 < 2 * MI) fetch_operands(ih + 1); }
-                stage_block(i, half);
+                if constexpr (EPI_PIPE) {
+                    if (ih + 1 < 2 * MI) { stage_block((ih + 1) >> 1, (ih + 1) & 1); read_rows(ih + 1); }
+                } else stage_block(i, half);
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) {
                     const int roff = i * 32 + 16 * half + ps * RPP;          // wave-uniform, known at compile time
                     const int m = mrow + roff;
                     if (lane_on && m < p.M && ((16 % RPP == 0) || ps * RPP + erow < 16)) {
-                        const f32x4_t a0 = *(const f32x4_t*)(stg_r + (ps * RPP + srow_half * half) * EROW);
-                        const f32x4_t a1 = *(const f32x4_t*)(stg_r + (ps * RPP + srow_half * half) * EROW + 4);
+                        f32x4_t a0, a1;
+                        if constexpr (EPI_PIPE) { a0 = pa[ih & 1][ps][0]; a1 = pa[ih & 1][ps][1]; }
+                        else {
+                            a0 = *(const f32x4_t*)(stg_r + (ps * RPP + srow_half * half) * EROW);
+                            a1 = *(const f32x4_t*)(stg_r + (ps * RPP + srow_half * half) * EROW + 4);
+                        }
                         float v[8];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[e] = a0[e] * p.alpha + bias8[e]; v[4 + e] = a1[e] * p.alpha + bias8[4 + e]; }
@@ -1015,8 +1041,9 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
             if (!lane_on || rr >= 16 || m >= p.M) continue;
             float v[8];
             {
-                const f32x4_t a0 = *(const f32x4_t*)(stg + (rr + srow_half * half) * EROW + ecol);
-                const f32x4_t a1 = *(const f32x4_t*)(stg + (rr + srow_half * half) * EROW + ecol + 4);
+                const float* sg = stg + (EPI_PIPE ? half * (SROWS * EROW) : 0);             // EPI_PIPE: block row ih lies in staging region ih & 1
+                const f32x4_t a0 = *(const f32x4_t*)(sg + (rr + srow_half * half) * EROW + ecol);
+                const f32x4_t a1 = *(const f32x4_t*)(sg + (rr + srow_half * half) * EROW + ecol + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = a0[e] * p.alpha; v[4 + e] = a1[e] * p.alpha; }
             }
