@@ -40,8 +40,8 @@ def parse(argv=None):
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--depth', type=int, default=24)
-    ap.add_argument('--batch', type=int, default=0, help='samples per GPU per step; 0 = 384 up to d24, 128 above (K/V arena: 0.4 GB per sample at d24 bf16 '
-                                                          '-> 154 GB at 384, peak allocation 172 GB of the 288 GB; larger batches fill the partial tile rounds of the '
+    ap.add_argument('--batch', type=int, default=0, help='samples per GPU per step; 0 = 512 up to d24, 128 above (K/V arena: 0.4 GB per sample at d24 bf16 '
+                                                          '-> 205 GB at 512, peak allocation 226 GB of the 288 GB; larger batches fill the partial tile rounds of the '
                                                           'mid scales: 128 -> 256 +2.5 %%, 256 -> 384 +0.8 %%, 384 -> 512 +0.7 %% at 226 GB)')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--cfg', type=float, default=4.0)
@@ -201,12 +201,12 @@ def side_configs(a, dev, box):
     del tr, var
     torch.cuda.empty_cache()
 
-    # BASELINE config 5: VQVAE encode -> multi-scale quantise -> decode, 128 images per pass (two chunks of 64)
+    # BASELINE config 5: VQVAE encode -> multi-scale quantise -> decode, 128 images per pass.  Round 4: ONE encode + quantise over the 128 images (the
+    # ten-scale quantiser is a latency-bound 2.7 ms launch at any batch <= 256 - two chunks of 64 paid it twice); the decoder chunks by itself (decode_chunk)
     img = synth_images(128, 256, seed=3).to(dev)
 
     def roundtrip(i):
-        for s0 in range(0, 128, 64):
-            vae.idxBl_to_img(vae.img_to_idxBl(img[s0:s0 + 64]), same_shape=True, last_one=True)
+        vae.idxBl_to_img(vae.img_to_idxBl(img), same_shape=True, last_one=True)
 
     dt = _timeit(roundtrip, 3, 1)
     out['vqvae_roundtrip_b128'] = {'value': round(128 / dt, 1), 'unit': 'images/s', 'steps': 3, 'ms_per_step': round(dt * 1e3, 2),
@@ -341,7 +341,7 @@ def main_infer(a):
     t_build = time.time()
     vae = models.build_vae(ch=160, compute_dtype=T).to(dev)
     var = models.build_control_var(vae, depth=a.depth, mask_type='interleave_append', multi_cond=True, compute_dtype=T).to(dev).eval()
-    B = a.batch or (384 if a.depth <= 24 else 128)
+    B = a.batch or (512 if a.depth <= 24 else 128)       # round 4: 384 -> 512 (+1.0 % on one box: 195.4 -> 197.3 images/s; 576: 198.1 at 254 GB - not taken)
     g = torch.Generator().manual_seed(1234 + rank)
     labels = torch.randint(0, 1000, (B,), generator=g).to(dev)
     types = (torch.arange(B) % 4).to(dev)

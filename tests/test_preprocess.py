@@ -2,6 +2,7 @@
 CPU: host tables + numpy oracle against the Pillow-recorded fixture (and the installed Pillow, when there is one).
 GPU: the HIP kernels against the oracle, bit for bit."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -145,7 +146,21 @@ def _random_anns(seed, n=6, size=512):
 def test_uncompressed_rle_semantics_against_an_independent_implementation():
     """runs_from_mask / the run expansion of the oracle against transformers' SAM post-processing (_mask_to_rle / _rle_to_mask:
     "the format expected by pycoco tools", written independently of this repo): same counts for the same mask, same mask back."""
-    sam = pytest.importorskip('transformers.models.sam.image_processing_sam')
+    # the module itself imports torchvision (absent in this image): take the two pure-torch functions out of the installed file by AST
+    import ast
+    import importlib.util
+    import types
+    from typing import Any
+    spec = importlib.util.find_spec('transformers')
+    if spec is None:
+        pytest.skip('transformers not installed')
+    path = os.path.join(os.path.dirname(spec.origin), 'models', 'sam', 'image_processing_sam.py')
+    tree = ast.parse(open(path).read())
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ('_mask_to_rle', '_rle_to_mask')]
+    assert len(fns) == 2, 'transformers SAM post-processing helpers not found'
+    ns = {'torch': torch, 'Any': Any}
+    exec(compile(ast.Module(body=fns, type_ignores=[]), path, 'exec'), ns)
+    sam = types.SimpleNamespace(_mask_to_rle=ns['_mask_to_rle'], _rle_to_mask=ns['_rle_to_mask'])
     anns = _random_anns(1)
     masks = torch.from_numpy(np.stack([a['_mask'] for a in anns]).astype(bool))
     theirs = sam._mask_to_rle(masks)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Integer / bf16 parity report (VERDICT r2, next #1c).
 
-    python tools/parity_report.py [--run] [--out profiles/r03_parity_report.json]
+    python tools/parity_report.py [--run] [--out profiles/r04_parity_report.json]
 
 --run   runs `pytest tests -m gpu` on this box with a fresh JSON-lines record file (tests/conftest.py: `record`, `ids_parity`), then
         summarises; without it the existing gpurun_out/parity_report.jsonl is summarised.
@@ -21,7 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--run', action='store_true')
     ap.add_argument('--jsonl', default=os.path.join(ROOT, 'gpurun_out', 'parity_report.jsonl'))
-    ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'r03_parity_report.json'))
+    ap.add_argument('--out', default=os.path.join(ROOT, 'gpurun_out', 'r04_parity_report.json'))
     a = ap.parse_args()
     rc = None
     if a.run:

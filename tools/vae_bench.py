@@ -10,9 +10,10 @@ dev = torch.device('cuda:0')
 vae = models.build_vae(ch=160, decode_chunk=64).to(dev)
 img = synth_images(B, 256, seed=3).to(dev)
 def step():
+    CH = int(os.environ.get('VAE_CHUNK', '128'))          # images per encode + quantise call (round 4: 128, was 64; the decoder chunks by itself)
     outs = []
-    for s in range(0, B, 64):
-        ids = vae.img_to_idxBl(img[s:s + 64])
+    for s in range(0, B, CH):
+        ids = vae.img_to_idxBl(img[s:s + CH])
         outs.append(vae.idxBl_to_img(ids, same_shape=True, last_one=True))
     return outs
 step(); torch.cuda.synchronize()
