@@ -1291,6 +1291,7 @@ static void set_max_lds_once(K kfn, size_t lds) {
 #ifndef CVAR_GEMM_PERS
 #define CVAR_GEMM_PERS 0
 #endif
+#if CVAR_GEMM_PERS
 #define CVAR_PERS_SLOTS 4096
 __device__ unsigned cvar_pers_counters[CVAR_PERS_SLOTS * 16];
 static unsigned* pers_counters(int* ncu) {
@@ -1312,6 +1313,9 @@ static unsigned* pers_counters(int* ncu) {
     const unsigned slot = __atomic_fetch_add(&next, 1u, __ATOMIC_RELAXED) % CVAR_PERS_SLOTS;
     return base[dev] + (size_t)slot * 16;
 }
+#else
+static unsigned* pers_counters(int*) { return nullptr; }
+#endif   // CVAR_GEMM_PERS
 
 // ---- fused split-K: per-tile arrival counters.  Same ring-of-self-resetting-slots scheme as the persistent kernels' counters: a launch takes the
 // next slot of CVAR_SK_TILES words (all zero: the last slice to sign a tile's counter clears it), the ring comes round after CVAR_SK_SLOTS launches.
@@ -1322,8 +1326,9 @@ static unsigned* pers_counters(int* ncu) {
 #ifndef CVAR_GEMM_FUSED_SPLITK
 #define CVAR_GEMM_FUSED_SPLITK 0
 #endif
-#define CVAR_SK_SLOTS 2048
 #define CVAR_SK_TILES 256
+#if CVAR_GEMM_FUSED_SPLITK
+#define CVAR_SK_SLOTS 2048
 __device__ unsigned cvar_splitk_counters[CVAR_SK_SLOTS * CVAR_SK_TILES];
 static unsigned* splitk_counters() {
     static unsigned* base[64] = {nullptr};
@@ -1339,6 +1344,9 @@ static unsigned* splitk_counters() {
     const unsigned slot = __atomic_fetch_add(&next, 1u, __ATOMIC_RELAXED) % CVAR_SK_SLOTS;
     return base[dev] + (size_t)slot * CVAR_SK_TILES;
 }
+#else
+static unsigned* splitk_counters() { return nullptr; }
+#endif   // CVAR_GEMM_FUSED_SPLITK
 
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE = 2, bool CONVFAST = false, bool CUP = false>
 static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
