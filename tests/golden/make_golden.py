@@ -696,6 +696,15 @@ def case_generate_d24():
     r = _run_generate(m, ref_cv, 2, torch.tensor([3, 7]), 4.0, cond_type=torch.tensor([0, 1]))
     print(f'  d24 B=2 reference generate {time.time() - t0:.1f}s')
     save('gen_d24_b2', **r)
+    # the same model through conditional_infer_cfg (control_var.py:223-354): 4-branch CFG with cfg = (4, 4, 4) - the script default,
+    # train_control_var_hpu.py:77 - and the control tokens teacher-forced from synthetic control images
+    ctrl = synth_images(2, 256, seed=4)
+    with torch.no_grad():
+        c_ids = vae.img_to_idxBl(ctrl, v_patch_nums=PN)
+    t0 = time.time()
+    r = _run_generate(m, ref_cv, 2, torch.tensor([5, 6]), (4.0, 4.0, 4.0), cond_type=torch.tensor([2, 3]), four=True, c_mask=c_ids)
+    print(f'  d24 B=2 reference conditional_infer_cfg {time.time() - t0:.1f}s')
+    save('gen_d24_cmask', c_ids=torch.cat(c_ids, dim=1).to(torch.int16), **r)
 
 
 def case_train_step_d24():

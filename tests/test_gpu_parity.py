@@ -191,6 +191,25 @@ def test_tokenizer_fp32_against_reference(gpu_device, tag, ch):
     assert (rec.mean(dim=(2, 3)) - t(g['rec_mean'])).abs().max() < 2e-4
 
 
+def test_tokenizer_fp32_rows_inside_a_large_batch_equal_the_fixture(gpu_device):
+    """BASELINE config 5 runs the tokenizer on 128 images per GPU; the fixture (tokenizer_ch160.npz) holds 2.  The fixture's images ride as rows 37 and
+    90 of a batch of 96 (other tile counts, other split-K partitions of the small GEMMs, the quantiser's map-per-workgroup grid at a size the small
+    tests never reach): their ids must still be the reference's, strictly, and the decode of the whole batch must reproduce the fixture's crops."""
+    g = golden('tokenizer_ch160')
+    vae = make_vae(160, F32, gpu_device)
+    own = synth_images(int(g['nimg']), 256, seed=1)
+    filler = synth_images(96, 256, seed=77)
+    rows = (37, 90)
+    for r_, img in zip(rows, own):
+        filler[r_] = img
+    ids = vae.img_to_idxBl(filler.to(gpu_device))
+    got = torch.cat(ids, dim=1)[list(rows)].cpu()
+    nm, ok = assert_ids(got, g['ids'], np.zeros(tuple(got.shape), np.float32), 0.0, 'img_to_idxBl ch160, fixture rows inside a batch of 96', strict=True)
+    rec = vae.idxBl_to_img(ids, same_shape=True, last_one=True)[list(rows)].cpu()
+    assert maxabs_on(rec[:, :, 100:116, 60:76] - t(g['rec_crop']), ok) < 2e-3
+    assert maxabs_on(rec.mean(dim=(2, 3)) - t(g['rec_mean']), ok) < 2e-4
+
+
 def test_tokenizer_bf16_encoder_ids_against_reference(gpu_device):
     """Throughput mode of A11 (vqvae.py:73-75 behind train_control_var_hpu.py:159-167): the ENCODER runs in bf16, the quantiser in
     fp32.  (i) the quantiser is exact on whatever features it gets: ids == the oracle quantiser applied to the HIP bf16 features,
