@@ -75,7 +75,6 @@ struct GemmParams {
     unsigned* pers_ctr;       // persistent kernels: this launch's 8 tile counters (one per XCD) + 1 exit counter, all zero at launch (self-resetting)
     // fused split-K (host side of launch_cfg only): the call's own parameters, the launch's per-tile arrival counters, the slice count
     const GemmParams* sk_final; unsigned* sk_ctr; int sk_nsplit;
-    int rows64;               // host side: take the 64x128 tile although M > 64 (cvar_gemm: small-M GEMMs that 64-row tiles fill the chip with, unsplit)
 };
 
 
@@ -1445,7 +1444,7 @@ static int gemm_cfg_override(const GemmParams& p) {
 template <typename T>
 static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     // small-M problems (early scales, ada_lin) use a 64-row tile to put more blocks on the chip
-    if (p.M <= 64 || p.rows64) return launch_cfg<T, 64, 128, 1, 4>(p, batch, st);
+    if (p.M <= 64) return launch_cfg<T, 64, 128, 1, 4>(p, batch, st);
     // channel counts of the VQVAE (160, 320) are multiples of 160 but not of 128: a 160-wide tile wastes no MFMA work
     // few output channels (the decoder's conv_out: 160 -> 3): a 256x32 tile wastes 10x instead of 42x of the MFMA work of a
     // 128-wide tile; the kernel is then bound by streaming the activations, as it should be
@@ -1527,12 +1526,6 @@ __global__ __launch_bounds__(256) void cvar_splitk_epilogue_kernel(const float* 
 }
 
 
-#ifndef CVAR_ROWS64_MIN_TILES
-#define CVAR_ROWS64_MIN_TILES 128
-#endif
-#ifndef CVAR_ROWS64_MAX_KTILES
-#define CVAR_ROWS64_MAX_KTILES 32
-#endif
 extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->W || !d->C) return CVAR_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch < 1) return CVAR_EINVAL;
@@ -1581,7 +1574,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     make_fast_div(p.remap_l, &p.remap_magic, &p.remap_shift);
     make_fast_div(p.gate ? p.gate_rows : 1, &p.gate_magic, &p.gate_shift);
     p.split_tiles = 0; p.split_stride = 0;
-    p.pers_ctr = nullptr; p.sk_final = nullptr; p.sk_ctr = nullptr; p.sk_nsplit = 0; p.rows64 = 0;
+    p.pers_ctr = nullptr; p.sk_final = nullptr; p.sk_ctr = nullptr; p.sk_nsplit = 0;
     p.tile_cfg = d->tile_cfg; p.stagger = d->stagger > 0 ? d->stagger : 0; p.group_m = d->group_m > 0 ? d->group_m : 0;
     // split-K workspace: part of the call (caller-owned, any stream / device), nothing process-wide
     float* const g_splitk_ws = (d->ws && d->ws_bytes > 0 && (((uintptr_t)d->ws & 15) == 0)) ? (float*)d->ws : nullptr;
@@ -1608,15 +1601,9 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
             if (long_k_splits < 2) long_k_splits = 0;
         }
     }
-    // Round 4: before splitting a small-M GEMM along K (two launches: slices + the reduction, 6.5 us for the second), see whether 64-row tiles alone
-    // put >= 128 workgroups on the chip: M = 256 x N = 4608 is 72 tiles of 128x128 (split 4 ways + epilogue, ~17 us) or 144 tiles of 64x128 in
-    // ONE launch.  Short K only (the unsplit K loop is the latency of the launch); tile_cfg 10 switches the rule off (A/B runs).
-    const int tm64 = (d->M + 63) / 64;
-    if (!long_k_splits && !d->conv && d->batch == 1 && d->dtype == CVAR_BF16 && d->M > 64 && d->M <= 1024 && tm * tn < 128 && tm64 * tn >= CVAR_ROWS64_MIN_TILES &&
-        nk_all <= CVAR_ROWS64_MAX_KTILES && d->tile_cfg != 10 && d->tile_cfg != 1) {
-        p.rows64 = 1;
-        return launch_typed<bf16_t>(p, 1, st);
-    }
+    // (Round 4, measured and removed: 64-row tiles UNSPLIT wherever they alone put >= 96 / 128 / 192 workgroups on the chip - e.g. M = 256 x N = 4608 as 144 tiles
+    //  of 64x128 in one launch instead of 72 tiles of 128x128 split four ways + the reduction launch - is exactly neutral at B = 1 ... 16:
+    //  profiles/r04_small_batch.txt.  The launches of this regime sit on their latency floor either way.)
     if (long_k_splits || (!d->conv && d->batch == 1 && d->M <= 1024 && (d->N % 4) == 0 && tm * tn < 128 && nk_all >= 8 && g_splitk_ws)) {
         int splits = long_k_splits ? long_k_splits : min(16, max(2, 320 / (tm * tn)));
         int per = (nk_all + splits - 1) / splits;
@@ -1652,7 +1639,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     }
     // stride-1 3x3 convs (plain or behind the nearest x2 upsample) over 32-channel multiples with 160-multiple outputs on 16-multiple images (every ResnetBlock conv of the VQVAE
     // decoder from 16x16 up): the LDS-halo kernel (conv_halo.hip).  tile_cfg 5 keeps them on the implicit-GEMM tiles, 6 forces the halo kernel at any grid size (A/B runs, tests).
-    if (d->conv && d->dtype == CVAR_BF16 && d->stride == 1 && d->batch == 1 && (d->tile_cfg == 0 || d->tile_cfg == 6 || d->tile_cfg == 9) &&
+    if (d->conv && d->dtype == CVAR_BF16 && d->stride == 1 && d->batch == 1 && (d->tile_cfg == 0 || d->tile_cfg == 6 || d->tile_cfg == 9 || d->tile_cfg == 10) &&
         d->Cin % 32 == 0 && d->Hout % 16 == 0 && d->Wout % 16 == 0 && d->act == CVAR_ACT_NONE && !d->gate && d->alpha == 1.0f &&
         !d->pre_act && !d->aux && !d->gate_scale && d->remap_l == 0 && d->split_n == 0 && d->strideC == 0 && d->ldc == d->N &&
         d->ldw == d->K &&      // the halo kernel addresses packed [Cout][9 Cin] weights: padded weight rows stay on the implicit-GEMM path
