@@ -11,7 +11,7 @@ import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CVAR_LIB') or os.path.join(HERE, 'libcvar_hip.so')      # CVAR_LIB: A/B runs against another build
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 CVAR_F32, CVAR_BF16 = 0, 1
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_GRAD = 0, 1, 2
@@ -38,6 +38,7 @@ class GemmDesc(C.Structure):
         ('pre_act', c_p), ('aux', c_p), ('gate_scale', c_p),
         ('ws', c_p), ('ws_bytes', c_l), ('tile_cfg', c_i), ('stagger', c_i), ('group_m', c_i),
         ('C_split', c_p), ('split_n', c_i), ('ld_split', c_l), ('split_alpha', c_f),
+        ('ln_out', c_p), ('ln_out_dtype', c_i), ('ln_scale', c_p), ('ln_shift', c_p), ('ld_ln', c_l), ('ln_rows', c_i), ('ln_eps', c_f),
     ]
 
 

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'csrc', 'build')
 LIB = os.path.join(HERE, 'libcvar_hip.so')
-SOURCES = ['gemm.hip', 'gemm_conv.hip', 'gemm_f32.hip', 'conv_halo.hip', 'gemm_tn.hip', 'ops.hip', 'attn.hip', 'sample.hip', 'msq.hip', 'train.hip', 'preproc.hip']
+SOURCES = ['gemm.hip', 'gemm_conv.hip', 'gemm_f32.hip', 'gemm_skinny.hip', 'conv_halo.hip', 'gemm_tn.hip', 'ops.hip', 'attn.hip', 'sample.hip', 'msq.hip', 'train.hip', 'preproc.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wno-unused-result']
 # per-source extras.  attn.hip: keep MFMA results in VGPRs - the softmax consumes every score with vector ALU ops, and the AGPR form
 # costs one v_accvgpr_read per score and tile (plus writes for the rescale)
@@ -47,7 +47,7 @@ def _compile(src: str) -> str:
 
 def build_lib(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'cvar_common.h'),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, 'cvar_common.h'), os.path.join(CSRC, 'gemm_params.h'),
                                                          os.path.join(os.path.dirname(HERE), 'include', 'cvar.h')]
     stamp = os.path.join(OBJ, 'digest.txt')
     dig = _digest(deps)

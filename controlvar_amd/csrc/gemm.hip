@@ -18,6 +18,7 @@
 // bf16 GEMM kernels, split-K; from gemm_conv.hip (CVAR_GEMM_CONV_TU) - the bf16 implicit-conv kernels; from gemm_f32.hip
 // (CVAR_GEMM_F32_TU) - everything fp32 (parity mode).
 #include "cvar_common.h"
+#include "gemm_params.h"
 #if defined(CVAR_GEMM_CONV_TU)
 #define CVAR_TU_CONV 1
 #define CVAR_TU_PLAIN 0
@@ -44,53 +45,6 @@ extern "C" int cvar_gemm_dbg_wg_read(unsigned long long* host, int n) { return (
 extern "C" int cvar_gemm_dbg_tot_read(unsigned long long* host, int reset) { int rc = (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cvar_gemm_dbg_tot), 64); if (reset) { unsigned long long z[8] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(cvar_gemm_dbg_tot), z, 64); } return rc; }
 extern "C" int cvar_gemm_dbg_read(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(cvar_gemm_dbg), sizeof(unsigned long long) * 64 * 8 * 8); }
 #endif
-
-struct GemmParams {
-    int M, N, K;
-    const char* A; long lda;
-    const char* W; long ldw;
-    long strideA, strideW, strideC, strideR;
-    int conv, Hin, Win, Cin, Hout, Wout, stride, up;
-    float alpha;
-    const float* bias;
-    int act;
-    const float* gate; long ldg; int gate_rows;
-    const void* residual; int res_dtype; long ldr;
-    void* C; int out_dtype; long ldc;
-    void* C2; const void* aux;     // optional: copy of alpha*acc+bias in the OPERAND dtype (before act / gate / residual) / gelu' operand (act GELU_GRAD); ld = ldc
-    const float* gate_scale;       // optional per-gate-row multiplier (DropPath keep-scale of training)
-    int in_dtype;                  // operand dtype (for the split-K epilogue kernel, which is not templated on it)
-    int remap_l, remap_L, remap_off;
-    float split_alpha;        // factor on the split columns [0, split_n) (1 = none)
-    void* Cs; int split_n; long ld_split;       // column split: columns [0, split_n) -> Cs[m][ld_split] (rows not remapped), the rest -> C at column n - split_n
-    int tiles_m, tiles_n;
-    int cv_adv, cv_rem;       // conv: a K tile advances (tap, ci) by (KT / Cin, KT % Cin) plus one carry
-    unsigned conv_bytes;      // conv FAST: bytes of the NHWC input of one batch slice (buffer range: out-of-range offsets read zeros)
-    unsigned remap_magic, gate_magic; int remap_shift, gate_shift;   // exact m / remap_l and m / gate_rows for 0 <= m < 2^31 (fast_div)
-    int split_tiles;          // split-K: K tiles per blockIdx.y slice (0 = no split); partials go to C + blockIdx.y * split_stride
-    long split_stride;
-    int group_m;              // row tiles per scheduling group (see launch_cfg)
-    int stagger;              // > 0: the first wave of workgroups (one per CU) starts spread over this many shader cycles (see cvar_gemm_kernel)
-    int tile_cfg;             // cvar_gemm_desc::tile_cfg (0 = automatic)
-    unsigned* pers_ctr;       // persistent kernels: this launch's 8 tile counters (one per XCD) + 1 exit counter, all zero at launch (self-resetting)
-    // fused split-K (host side of launch_cfg only): the call's own parameters, the launch's per-tile arrival counters, the slice count
-    const GemmParams* sk_final; unsigned* sk_ctr; int sk_nsplit;
-};
-
-
-// floor(m / d) for 0 <= m < 2^31 as mulhi + shift: magic = ceil(2^(31+s) / d), 2^(s-1) < d <= 2^s (shift < 0 encodes d == 1)
-__device__ __forceinline__ int fast_div(int m, unsigned magic, int shift) {
-    const unsigned q = __umulhi((unsigned)m, magic) >> (shift < 0 ? 0 : shift);
-    return shift < 0 ? m : (int)q;
-}
-static void make_fast_div(long d, unsigned* magic, int* shift) {
-    if (d <= 1) { *magic = 0; *shift = -1; return; }
-    int sft = 0;
-    while ((1L << sft) < d) ++sft;                        // 2^(s-1) < d <= 2^s, s >= 1
-    const unsigned long long num = 1ULL << (31 + sft);
-    *magic = (unsigned)((num + (unsigned long long)d - 1) / (unsigned long long)d);
-    *shift = sft - 1;                                      // mulhi drops 32 bits; 31 + s - 32 remain
-}
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -1218,26 +1172,7 @@ __device__ __forceinline__ void splitk_finish_quad(const GemmParams& p, const fl
                 }
         }
     }
-    long orow = m;
-    if (p.remap_l > 0) {
-        const int sq = fast_div(m, p.remap_magic, p.remap_shift);
-        orow = (long)sq * p.remap_L + p.remap_off + (m - sq * p.remap_l);
-    }
-    const float* grow = p.gate ? p.gate + (long)fast_div(m, p.gate_magic, p.gate_shift) * p.ldg : nullptr;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float x = v[e] * p.alpha;
-        if (p.bias) x += p.bias[n + e];
-        if (p.C2) st_any(p.C2, p.in_dtype, (long)m * p.ldc + n + e, x);
-        if (p.act == CVAR_ACT_GELU_TANH) x = gelu_tanh_f(x);
-        else if (p.act == CVAR_ACT_GELU_GRAD) x *= gelu_tanh_grad(ld_any(p.aux, p.out_dtype, (long)m * p.ldc + n + e));
-        if (grow) x *= grow[n + e] * (p.gate_scale ? p.gate_scale[fast_div(m, p.gate_magic, p.gate_shift)] : 1.0f);
-        if (p.residual) x += ld_any(p.residual, p.res_dtype, (long)m * p.ldr + n + e);
-        if (p.split_n > 0) {
-            if (n < p.split_n) st_any(p.Cs, p.out_dtype, (long)m * p.ld_split + n + e, x * p.split_alpha);
-            else st_any(p.C, p.out_dtype, orow * p.ldc + (n - p.split_n) + e, x);
-        } else st_any(p.C, p.out_dtype, orow * p.ldc + n + e, x);
-    }
+    gemm_epilogue_quad(p, m, n, v);
 }
 
 // Split-K with the reduction folded into the GEMM launch (round 4): every slice stores its fp32 partial tile as before, then signs a per-tile
@@ -1508,6 +1443,11 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
 }
 
+// gemm_skinny.hip: the weight-streaming small-M kernel and the row-finishing split-K reduction (+ adaLN of the next op)
+int cvar_gemm_skinny_plan(int M, int N, int K, long lda, long ldw, int want_rowfin, int have_ws, int* mt, int* nt, int* slices);
+int cvar_gemm_skinny_launch(const GemmParams& p, int mt, int nt, int slices, hipStream_t st);
+int cvar_splitk_rowfin_ok(const GemmParams& p, const cvar_gemm_desc* d);
+int cvar_splitk_rowfin_launch(const float* part, int nsplit, const GemmParams& p, const cvar_gemm_desc* d, hipStream_t st);
 int cvar_gemm_launch_f32(const GemmParams& p, int batch, hipStream_t st);            // defined in the CVAR_GEMM_F32_TU compilation
 int cvar_gemm_launch_conv_bf16(const GemmParams& p, int batch, hipStream_t st);      // defined in the CVAR_GEMM_CONV_TU compilation
 #if defined(CVAR_GEMM_F32_TU)
@@ -1580,6 +1520,42 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     float* const g_splitk_ws = (d->ws && d->ws_bytes > 0 && (((uintptr_t)d->ws & 15) == 0)) ? (float*)d->ws : nullptr;
     const size_t g_splitk_ws_bytes = g_splitk_ws ? (size_t)d->ws_bytes : 0;
     hipStream_t st = as_stream(stream);
+    // ABI 17: adaLN of the finished rows for the op that follows (cvar.h).  Row-wise fused with the split-K reduction where this call is sliced
+    // (cvar_splitk_rowfin_kernel), a cvar_ln_modulate launch behind the GEMM otherwise - same bits either way.
+    if (d->ln_out) {
+        if (!d->ln_scale || !d->ln_shift || d->ln_rows <= 0 || (d->N % 4) || d->N > 2048 || (d->ld_ln % 4) || d->out_dtype != CVAR_F32 || d->ldc != d->N ||
+            d->remap_l > 0 || d->split_n > 0 || d->conv || d->batch != 1 || (d->ln_out_dtype != CVAR_BF16 && d->ln_out_dtype != CVAR_F32)) return CVAR_EUNSUPPORTED;
+    }
+    auto ln_after = [&](int rc) -> int {
+        if (rc != CVAR_OK || !d->ln_out) return rc;
+        return cvar_ln_modulate((const float*)d->C, d->ln_scale, d->ln_shift, d->ld_ln, d->ln_rows, d->ln_out, d->ln_out_dtype, d->M, d->N, d->ln_eps, stream);
+    };
+    const bool rowfin = g_splitk_ws && cvar_splitk_rowfin_ok(p, d);
+    // sums the slices a producer left in the workspace and finishes the call: row-wise with the adaLN, or element-wise (+ the adaLN launch)
+    auto finish_slices = [&](int splits) -> int {
+        if (rowfin) return cvar_splitk_rowfin_launch(g_splitk_ws, splits, p, d, st);
+        const long nvec = (long)d->M * (d->N / 4);
+        hipLaunchKernelGGL(cvar_splitk_epilogue_kernel, dim3((unsigned)min((long)2048, (nvec + 255) / 256)), dim3(256), 0, st, g_splitk_ws, splits, p);
+        CVAR_CHECK_LAUNCH();
+        return ln_after(CVAR_OK);
+    };
+    // small-M bf16 GEMMs whose caller opted in (tile_cfg 12): the weight-streaming kernel (gemm_skinny.hip) - whole K per workgroup, epilogue in the launch;
+    // long K as a few slices + the row-finishing reduction.  Opt-in because the plan, hence the fp32 summation order of an output, depends on M: the
+    // transformer's small passes accept that (their split-K already does), the VQVAE's per-image bit-reproducibility across batch sizes must not.
+    if (!d->conv && d->batch == 1 && d->dtype == CVAR_BF16 && d->tile_cfg == 12 && !d->pre_act && !d->aux) {
+        int mt = 0, nt = 0, sl = 0;
+        if (cvar_gemm_skinny_plan(d->M, d->N, d->K, d->lda, d->ldw, rowfin ? 1 : 0, g_splitk_ws ? 1 : 0, &mt, &nt, &sl)) {
+            if (sl > 1 && (size_t)sl * d->M * d->N * sizeof(float) <= g_splitk_ws_bytes) {
+                GemmParams ps = p;
+                ps.C = g_splitk_ws; ps.out_dtype = CVAR_F32; ps.ldc = d->N;
+                ps.split_tiles = (d->K >> 5) / sl; ps.split_stride = (long)d->M * d->N;
+                const int rc = cvar_gemm_skinny_launch(ps, mt, nt, sl, st);
+                if (rc != CVAR_OK) return rc;
+                return finish_slices(sl);
+            }
+            if (sl == 1) return ln_after(cvar_gemm_skinny_launch(p, mt, nt, 1, st));
+        }
+    }
     // split-K decision: plain (non-conv, unbatched) GEMMs whose tile count leaves most CUs idle
     const int kt_elems = 128 / es;
     const int nk_all = (d->K + kt_elems - 1) / kt_elems;
@@ -1624,17 +1600,12 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
                     GemmParams pfin = p;
                     pfin.tile_cfg = 0;
                     ps.sk_final = &pfin; ps.sk_ctr = ctr; ps.sk_nsplit = splits;
-                    const int rc = launch_typed<bf16_t>(ps, 1, st);
-                    if (rc != CVAR_OK) return rc;
-                    return CVAR_OK;
+                    return ln_after(launch_typed<bf16_t>(ps, 1, st));
                 }
             }
             const int rc = d->dtype == CVAR_BF16 ? launch_typed<bf16_t>(ps, 1, st) : cvar_gemm_launch_f32(ps, 1, st);
             if (rc != CVAR_OK) return rc;
-            const long nvec = (long)d->M * (d->N / 4);
-            hipLaunchKernelGGL(cvar_splitk_epilogue_kernel, dim3((unsigned)min((long)2048, (nvec + 255) / 256)), dim3(256), 0, st, g_splitk_ws, splits, p);
-            CVAR_CHECK_LAUNCH();
-            return CVAR_OK;
+            return finish_slices(splits);
         }
     }
     // stride-1 3x3 convs (plain or behind the nearest x2 upsample) over 32-channel multiples with 160-multiple outputs on 16-multiple images (every ResnetBlock conv of the VQVAE
@@ -1655,7 +1626,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
             return cvar_conv3x3_halo_bf16(d->A, d->W, d->bias, d->residual, d->C, d->out_dtype == CVAR_F32, d->M / (d->Hout * d->Wout), d->Hout, d->Wout, d->Cin,
                                           d->N, d->up, st);
     }
-    if (d->dtype == CVAR_BF16) return d->conv ? cvar_gemm_launch_conv_bf16(p, d->batch, st) : launch_typed<bf16_t>(p, d->batch, st);
-    return cvar_gemm_launch_f32(p, d->batch, st);
+    if (d->dtype == CVAR_BF16) return d->conv ? cvar_gemm_launch_conv_bf16(p, d->batch, st) : ln_after(launch_typed<bf16_t>(p, d->batch, st));
+    return ln_after(cvar_gemm_launch_f32(p, d->batch, st));
 }
 #endif   // main translation unit

@@ -1,0 +1,311 @@
+// Small-M GEMMs of the early scales and of small batches (M = R * l <= a few hundred rows): weight-streaming kernel + row-finishing split-K reduction.
+//
+// Why a second GEMM kernel.  With M <= 144 rows the LDS-tiled kernels of gemm.hip have one or two row tiles; they fill the chip only by splitting K
+// (128x128 tiles x up to 16 slices) and pay a second launch that sums the slices: 9.5 + 5.2 us per GEMM at M <= 64 and 13-16 + 6.5-8 us at M = 100 ... 256
+// in a B = 1 generation (profiles/r04_small_batch_scales.txt), against 1-4 us of weight streaming.  Here the problem is cut along N instead:
+//   * a workgroup owns 16 NT output columns x 16 MT rows over the WHOLE K range: no partial sums leave the workgroup, the epilogue runs in the same launch;
+//   * its 8 waves interleave the 32-deep k-steps (wave w takes steps w, w + 8, ... of a per-workgroup rotation of K), so the workgroup streams 512 contiguous
+//     bytes of every weight row per round and different workgroups read different k-blocks of the shared activations at any moment;
+//   * operands go global -> registers (buffer_load_dwordx4, 16 B per lane = one MFMA fragment; rows past M / N are out-of-range offsets = zeros): every weight
+//     byte is used by exactly one wave, so LDS staging would only add a hop; the activations (M x K, <= 0.4 MB) are re-read by every workgroup out of L2;
+//   * v_mfma_f32_16x16x32_bf16 with the weight fragment as the row operand: a lane ends up with 4 consecutive output columns of one row (vector stores);
+//   * the 8 partial accumulators meet in LDS (fixed wave order -> bit-reproducible) and each thread finishes one quad through gemm_epilogue_quad.
+// Long-K calls (fc2: K = 4C) would make every workgroup read M x K activations; they keep a K split (blockIdx.z, fp32 partial tiles in the caller's workspace)
+// and are finished ROW-WISE by cvar_splitk_rowfin_kernel, which also runs the adaLN of the next op on the finished row (cvar_gemm_desc.ln_out): slices -> sum ->
+// bias / gate / residual -> x, LN(x) * (1 + scale) + shift -> bf16 in one launch instead of epilogue kernel + cvar_ln_modulate.
+// Math: basic_var.py:43-51,92,119,207-209 (same functions as gemm.hip / ops.hip; accumulation order differs from the tile kernels, fp32 sums).
+#include "gemm_params.h"
+
+typedef __attribute__((ext_vector_type(4))) int v4i_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bfv8_t;
+
+template <int MT, int NT, int PF, bool PARTIAL>
+__global__ __launch_bounds__(512) void cvar_gemm_skinny_kernel(const GemmParams p) {
+    constexpr int T = MT * NT;
+    static_assert(T <= 8, "one output quad per thread");
+    __shared__ f32x4_t sred[8 * T * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int n0 = blockIdx.x * (16 * NT), m0 = blockIdx.y * (16 * MT);
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((long)p.M * p.lda * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)((long)p.N * p.ldw * 2), 0x00020000);
+    unsigned offA[MT], offW[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m = m0 + 16 * i + l15;
+        offA[i] = m < p.M ? (unsigned)(((long)m * p.lda + kq * 8) * 2) : 0x80000000u;
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + 16 * j + l15;
+        offW[j] = n < p.N ? (unsigned)(((long)n * p.ldw + kq * 8) * 2) : 0x80000000u;
+    }
+    f32x4_t acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // k-steps of this workgroup: [ks_lo, ks_hi) in units of 32 k (a K slice when the call is split); wave w takes ks_lo + w + 8 t
+    const int nks_all = p.K >> 5;
+    const int ks_lo = p.split_tiles > 0 ? (int)blockIdx.z * p.split_tiles : 0;
+    const int ks_hi = p.split_tiles > 0 ? min(nks_all, ks_lo + p.split_tiles) : nks_all;
+    const int S = ks_hi - ks_lo;
+    const int nsteps = (S - wave + 7) >> 3;                      // <= 0: nothing for this wave
+    // Every workgroup reads the SAME activation rows, and rows of K = 1536 bf16 (3072 B) put one k-block of all rows on 4 of an L2's 16 channels: with all
+    // workgroups walking K in the same order those channels serve the whole chip (measured: 7.7 us at M = 4 -> 14.3 us at M = 64 per GEMM).  Each workgroup
+    // therefore starts its walk at its own k-step (a rotation of the step order: still every step exactly once, the sum order is fixed per output tile).
+    const int rot = (int)((blockIdx.x * 11u + blockIdx.y * 5u) % (unsigned)max(S, 1));
+    bf16x8_t af[PF][MT], wf[PF][NT];
+    auto issue = [&](int slot, int t) {
+        int j = wave + 8 * t + rot;
+        if (j >= S) j -= S;
+        const unsigned so = (unsigned)(ks_lo + j) * 64u;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[slot][j] = __builtin_bit_cast(bf16x8_t, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, offW[j], so, 0));
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[slot][i] = __builtin_bit_cast(bf16x8_t, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(a_rsrc, offA[i], so, 0));
+    };
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+        if (u < nsteps) issue(u, u);
+    for (int base = 0; base < nsteps; base += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int t = base + u;
+            if (t < nsteps) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfv8_t, wf[u][j]), __builtin_bit_cast(bfv8_t, af[u][i]), acc[i][j], 0, 0, 0);
+                if (t + PF < nsteps) issue(u, t + PF);
+            }
+        }
+    }
+    // the eight waves' partial tiles -> LDS -> one quad per thread, summed in wave order
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) sred[(wave * T + i * NT + j) * 64 + lane] = acc[i][j];
+    __syncthreads();
+    if (tid < T * 64) {
+        f32x4_t v = sred[tid];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) {
+            const f32x4_t o = sred[w * T * 64 + tid];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += o[e];
+        }
+        const int tile = tid >> 6, ln = tid & 63;
+        const int m = m0 + 16 * (tile / NT) + (ln & 15), n = n0 + 16 * (tile % NT) + 4 * (ln >> 4);
+        if (m < p.M && n < p.N) {
+            if constexpr (PARTIAL) *(f32x4_t*)((float*)p.C + (long)blockIdx.z * p.split_stride + (long)m * p.N + n) = v;      // K slice: raw fp32 sums
+            else gemm_epilogue_quad(p, m, n, v);
+        }
+    }
+}
+
+template <int MT, int NT, int PF>
+static int skinny_launch_cfg(const GemmParams& p, int slices, hipStream_t st) {
+    dim3 grid((unsigned)((p.N + 16 * NT - 1) / (16 * NT)), (unsigned)((p.M + 16 * MT - 1) / (16 * MT)), (unsigned)slices), block(512);
+    if (p.split_tiles > 0) hipLaunchKernelGGL((cvar_gemm_skinny_kernel<MT, NT, PF, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((cvar_gemm_skinny_kernel<MT, NT, PF, false>), grid, block, 0, st, p);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// plan: rows per workgroup 16 mt, columns 16 nt, K slices (1 = none).  Returns 0 when the call is not one for this kernel.
+// Cost model (bytes; the kernel is bound by what a CU can pull and by what the L2s serve, not by MFMA):
+//   per workgroup   (16 mt + 16 nt) * Kslice * 2        <= 320 KB   (a CU ingests ~100-130 GB/s: 2.5-3 us)
+//   all workgroups  A re-read once per column group + W re-read once per row group <= 160 MB (~20 TB/s of L2 -> 8 us: beyond that the tile kernels win)
+int cvar_gemm_skinny_plan(int M, int N, int K, long lda, long ldw, int want_rowfin, int have_ws, int* mt_, int* nt_, int* slices_) {
+    if (M <= 0 || M > 512 || (K & 31) || (N & 15) || (lda & 7) || (ldw & 7)) return 0;
+    if ((long)M * lda * 2 >= (1L << 31) || (long)N * ldw * 2 >= (1L << 31)) return 0;
+    const int mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+    const int gy = (M + 16 * mt - 1) / (16 * mt);
+    const int nks = K >> 5;
+    int best_nt = 0, best_sl = 0;
+    double best = 1e30;
+    for (int nt = 1; nt <= 2; ++nt) {
+        if (mt * nt > 8 || (nt == 2 && (N & 31))) continue;
+        const long gx = N / (16 * nt);
+        for (int sl = 1; sl <= 8; sl *= 2) {
+            if (sl > 1 && (!have_ws || nks % sl || nks / sl < 16)) continue;          // a K slice is at least 512 deep
+            const double wg = (double)(16 * mt + 16 * nt) * (K / sl) * 2.0;
+            const double total = (double)gx * M * K * 2.0 + (double)gy * N * K * 2.0;
+            if (wg > 320.0 * 1024 || total > 160e6) continue;
+            // time model (us): the slower of per-workgroup ingest (rounds of 256 CUs x 2 resident workgroups) and the L2 service; a sliced call pays its
+            // second launch unless that launch replaces the cvar_ln_modulate that would follow anyway; few workgroups stream badly
+            const long wgs = gx * gy * sl;
+            const double rounds = (double)((wgs + 511) / 512);
+            const double t = fmax(rounds * wg / 110e3, total / 18e6) + (sl > 1 ? (want_rowfin ? 1.0 : 5.0) : 0.0) + (wgs < 256 ? 1.5 * (double)(256 - wgs) / 256.0 : 0.0);
+            if (t < best) { best = t; best_nt = nt; best_sl = sl; }
+        }
+    }
+    if (!best_nt) return 0;
+    *mt_ = mt; *nt_ = best_nt; *slices_ = best_sl;
+    return 1;
+}
+
+int cvar_gemm_skinny_launch(const GemmParams& p, int mt, int nt, int slices, hipStream_t st) {
+    if (nt == 1) {
+        if (mt == 1) return skinny_launch_cfg<1, 1, 8>(p, slices, st);
+        if (mt == 2) return skinny_launch_cfg<2, 1, 6>(p, slices, st);
+        return skinny_launch_cfg<4, 1, 4>(p, slices, st);
+    }
+    if (mt == 1) return skinny_launch_cfg<1, 2, 8>(p, slices, st);
+    if (mt == 2) return skinny_launch_cfg<2, 2, 6>(p, slices, st);
+    return skinny_launch_cfg<4, 2, 4>(p, slices, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-finishing split-K reduction: one wave per output row.  part = nsplit fp32 slices [M][N]; the row is summed in slice order (the order of
+// cvar_splitk_epilogue_kernel -> same bits), finished with bias / gate / fp32 residual exactly as gemm_epilogue_quad does, stored, and - the point of
+// working row-wise - normalised and modulated for the next op while it is still in registers, with cvar_ln_modulate's lane <-> column map and
+// reduction order (ops.hip: bit-identical to running that kernel on the stored row).
+// ------------------------------------------------------------------------------------------------
+struct RowFinLn { void* out; const float* scale; const float* shift; long ld; int rows_per; float eps; };
+
+template <typename TO, int NV, bool TAIL>
+__global__ __launch_bounds__(256) void cvar_splitk_rowfin_kernel(const float* __restrict__ part, int nsplit, const GemmParams p, const RowFinLn ln) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const int N = p.N;
+    const long sstride = (long)p.M * N;
+    const float* q0 = part + (long)row * N;
+    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t v[NV];
+    bool ok[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        ok[i] = !(TAIL && i == NV - 1) || c < N;
+        v[i] = ok[i] ? *(const f32x4_t*)(q0 + c) : zero4;
+    }
+    // epilogue operands: issued before the slice sums so that their latency hides behind them
+    const int g = fast_div(row, p.gate_magic, p.gate_shift);
+    const float* grow = p.gate + (long)g * p.ldg;
+    const float* rrow = (const float*)p.residual + (long)row * p.ldr;
+    f32x4_t bq[NV], gq[NV], rq[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        bq[i] = (ok[i] && p.bias) ? *(const f32x4_t*)(p.bias + c) : zero4;
+        gq[i] = ok[i] ? *(const f32x4_t*)(grow + c) : zero4;
+        rq[i] = ok[i] ? *(const f32x4_t*)(rrow + c) : zero4;
+    }
+    for (int s0 = 1; s0 < nsplit; s0 += 4) {
+        f32x4_t w[4][NV];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                w[u][i] = (s0 + u < nsplit && ok[i]) ? *(const f32x4_t*)(q0 + (long)(s0 + u) * sstride + c) : zero4;
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (s0 + u < nsplit) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[i][e] += w[u][i][e];
+            }
+    }
+    const float gs = p.gate_scale ? p.gate_scale[g] : 1.0f;
+    float* crow = (float*)p.C + (long)row * p.ldc;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = v[i][e] * p.alpha;                 // same operation order as gemm_epilogue_quad
+            if (p.bias) x += bq[i][e];
+            x *= gq[i][e] * gs;
+            x += rq[i][e];
+            v[i][e] = x;
+        }
+        if (ok[i]) *(f32x4_t*)(crow + c) = v[i];
+        else v[i] = zero4;
+    }
+    // adaLN of the finished row: cvar_ln_modulate's arithmetic (ops.hip:ln_modulate_kernel)
+    const long lg = row / ln.rows_per;
+    const float* sc = ln.scale + lg * ln.ld;
+    const float* sh = ln.shift + lg * ln.ld;
+    f32x4_t a[NV], b[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        a[i] = ok[i] ? *(const f32x4_t*)(sc + c) : zero4;
+        b[i] = ok[i] ? *(const f32x4_t*)(sh + c) : zero4;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float)N;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[i][e] = ok[i] ? v[i][e] - mean : 0.f; q += v[i][e] * v[i][e]; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)N + ln.eps);
+    TO* orow = (TO*)ln.out + (long)row * N;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (!ok[i]) continue;
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = (v[i][e] * rstd) * (1.0f + a[i][e]) + b[i][e];
+        if constexpr (sizeof(TO) == 4) {
+            f32x4_t o = {y[0], y[1], y[2], y[3]};
+            *(f32x4_t*)(orow + c) = o;
+        } else {
+            *(bf16x4_t*)(orow + c) = pack_bf16x4(y);
+        }
+    }
+}
+
+template <typename TO, int NV>
+static void rowfin_launch(bool tail, dim3 grid, hipStream_t st, const float* part, int nsplit, const GemmParams& p, const RowFinLn& ln) {
+    if (tail) hipLaunchKernelGGL((cvar_splitk_rowfin_kernel<TO, NV, true>), grid, dim3(256), 0, st, part, nsplit, p, ln);
+    else hipLaunchKernelGGL((cvar_splitk_rowfin_kernel<TO, NV, false>), grid, dim3(256), 0, st, part, nsplit, p, ln);
+}
+
+template <typename TO>
+static int rowfin_dispatch(const float* part, int nsplit, const GemmParams& p, const RowFinLn& ln, hipStream_t st) {
+    const int nv = (p.N + 255) / 256;
+    const bool tail = (p.N % 256) != 0;
+    dim3 grid(cdiv(p.M, 4));
+    switch (nv) {
+        case 1: rowfin_launch<TO, 1>(tail, grid, st, part, nsplit, p, ln); break;
+        case 2: rowfin_launch<TO, 2>(tail, grid, st, part, nsplit, p, ln); break;
+        case 3: rowfin_launch<TO, 3>(tail, grid, st, part, nsplit, p, ln); break;
+        case 4: rowfin_launch<TO, 4>(tail, grid, st, part, nsplit, p, ln); break;
+        case 5: rowfin_launch<TO, 5>(tail, grid, st, part, nsplit, p, ln); break;
+        case 6: rowfin_launch<TO, 6>(tail, grid, st, part, nsplit, p, ln); break;
+        case 7: rowfin_launch<TO, 7>(tail, grid, st, part, nsplit, p, ln); break;
+        case 8: rowfin_launch<TO, 8>(tail, grid, st, part, nsplit, p, ln); break;
+        default: return CVAR_EUNSUPPORTED;
+    }
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// can this call's split-K reduction be finished row-wise with the adaLN behind it?  (the inference proj / fc2 calls: gate + fp32 residual in place, plain rows)
+int cvar_splitk_rowfin_ok(const GemmParams& p, const cvar_gemm_desc* d) {
+    return d->ln_out && d->ln_scale && d->ln_shift && d->ln_rows > 0 && p.gate && p.residual && p.res_dtype == CVAR_F32 && p.out_dtype == CVAR_F32 &&
+           p.act == CVAR_ACT_NONE && !p.C2 && !p.aux && p.remap_l == 0 && p.split_n == 0 && p.ldc == p.N && p.ldr == p.N && (p.N % 4) == 0 && p.N <= 2048 &&
+           (d->ld_ln % 4) == 0 && (p.ldg % 4) == 0 && (((uintptr_t)p.gate | (uintptr_t)p.residual | (uintptr_t)p.C | (uintptr_t)d->ln_scale | (uintptr_t)d->ln_shift |
+           (uintptr_t)d->ln_out | (uintptr_t)p.bias) & 15) == 0 && (d->ln_out_dtype == CVAR_BF16 || d->ln_out_dtype == CVAR_F32);
+}
+
+int cvar_splitk_rowfin_launch(const float* part, int nsplit, const GemmParams& p, const cvar_gemm_desc* d, hipStream_t st) {
+    RowFinLn ln;
+    ln.out = d->ln_out; ln.scale = d->ln_scale; ln.shift = d->ln_shift; ln.ld = d->ld_ln; ln.rows_per = d->ln_rows; ln.eps = d->ln_eps;
+    if (d->ln_out_dtype == CVAR_BF16) return rowfin_dispatch<bf16_t>(part, nsplit, p, ln, st);
+    return rowfin_dispatch<float>(part, nsplit, p, ln, st);
+}

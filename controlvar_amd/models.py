@@ -776,25 +776,35 @@ class ControlVAR(nn.Module):
         LOG2E = 1.4426950408889634
         pre = T == torch.bfloat16
         q_alpha = (float(cfg.attn_scale) * LOG2E) if (pre and not cfg.uses_cos_attn) else 1.0
+        # Small passes (early scales, small batches): proj / fc2 also produce the adaLN input of the op that follows (cvar_gemm_desc.ln_out) - their split-K
+        # reduction finishes rows, so LayerNorm + modulation ride in that launch instead of a cvar_ln_modulate of their own (same bits).  Large passes keep the
+        # separate launch: their GEMMs finish tiles, not rows.
+        fuse_ln = M <= 1024
+        ah = cfg.depth * 6 * C
+        ops.ln_modulate(x, ada, 2 * C, 4 * C, n_ada, l, u, M, C, cfg.norm_eps)
         for i in range(cfg.depth):
             a0 = i * 6 * C
-            ops.ln_modulate(x, ada, a0 + 2 * C, a0 + 4 * C, n_ada, l, u, M, C, cfg.norm_eps)
             # one GEMM for q | k | v: the q columns land in the scratch, k | v rows straight in their KV-arena slots (row remap)
             ops.gemm(u, P['w_qkv'], arena, M=M, N=3 * C, K=C, w_off=i * 3 * C * C, bias=P['b_qkv'][i], c_off=i * arena_stride,
-                     ldc=2 * C, remap=(l, Lmax, q_off), split=(qs, C, C), split_alpha=q_alpha)
+                     ldc=2 * C, remap=(l, Lmax, q_off), split=(qs, C, C), split_alpha=q_alpha, small_m=True)
             if cfg.uses_cos_attn:
                 ops.cos_qk_norm(arena, R, H, Lmax, q_off, l, P['scale_mul'], qkv_off=i * arena_stride, sm_off=i * H, q=qs, q_mul=LOG2E if pre else 1.0)
             ops.attention(arena, o, R, H, Lmax, q_off, l, float(cfg.attn_scale), lvl_end, qkv_off=i * arena_stride, holes=holes, q=qs, prescaled=pre)
+            ln2 = (u, ada, a0 + 3 * C, a0 + 5 * C, n_ada, l, cfg.norm_eps)
             ops.gemm(o, P['w_proj'], x, M=M, N=C, K=C, w_off=i * C * C, bias=P['b_proj'][i], gate=ada, gate_off=a0, ldg=n_ada, gate_rows=l,
-                     residual=x)
-            ops.ln_modulate(x, ada, a0 + 3 * C, a0 + 5 * C, n_ada, l, u, M, C, cfg.norm_eps)
-            ops.gemm(u, P['w_fc1'], hbuf, M=M, N=hid, K=C, w_off=i * hid * C, bias=P['b_fc1'][i], act=ACT_GELU_TANH)
+                     residual=x, ln=ln2 if fuse_ln else None, small_m=True)
+            if not fuse_ln:
+                ops.ln_modulate(x, *ln2[1:6], u, M, C, cfg.norm_eps)
+            ops.gemm(u, P['w_fc1'], hbuf, M=M, N=hid, K=C, w_off=i * hid * C, bias=P['b_fc1'][i], act=ACT_GELU_TANH, small_m=True)
+            # the row finished by fc2 is the input of the next block's first adaLN (or of the head's)
+            a1 = a0 + 6 * C
+            ln1 = (u, ada, a1 + 2 * C, a1 + 4 * C, n_ada, l, cfg.norm_eps) if i + 1 < cfg.depth else (u, ada, ah, ah + C, n_ada, l, cfg.norm_eps)
             ops.gemm(hbuf, P['w_fc2'], x, M=M, N=C, K=hid, w_off=i * C * hid, bias=P['b_fc2'][i], gate=ada, gate_off=a0 + C, ldg=n_ada,
-                     gate_rows=l, residual=x)
-        ah = cfg.depth * 6 * C
-        ops.ln_modulate(x, ada, ah, ah + C, n_ada, l, u, M, C, cfg.norm_eps)
+                     gate_rows=l, residual=x, ln=ln1 if fuse_ln else None, small_m=True)
+            if not fuse_ln:
+                ops.ln_modulate(x, *ln1[1:6], u, M, C, cfg.norm_eps)
         logits = torch.empty(M, cfg.head_ld, device=dev, dtype=torch.float32)
-        ops.gemm(u, P['w_head'], logits, M=M, N=cfg.head_ld, K=C, bias=P['b_head'])
+        ops.gemm(u, P['w_head'], logits, M=M, N=cfg.head_ld, K=C, bias=P['b_head'], small_m=True)
         return logits
 
     def _ada(self, cond: torch.Tensor, R: int):
@@ -802,7 +812,7 @@ class ControlVAR(nn.Module):
         cs = torch.empty(R, self.cfg.C, device=cond.device, dtype=self.compute_dtype)
         ops.silu_cast(cond, cs)
         ada = torch.empty(R, P['n_ada'], device=cond.device, dtype=torch.float32)
-        ops.gemm(cs, P['w_ada'], ada, M=R, N=P['n_ada'], K=self.cfg.C, bias=P['b_ada'])
+        ops.gemm(cs, P['w_ada'], ada, M=R, N=P['n_ada'], K=self.cfg.C, bias=P['b_ada'], small_m=True)
         return ada
 
     def _as_labels(self, B, label_B, seed):

@@ -44,6 +44,7 @@ _SPLITK_WS = {}
 GEMM_TILE_CFG = 0          # 0 automatic, 1 128x128 only, 2 8-wave 256x256, 3 4-wave 256x256
 GEMM_STAGGER = 0           # start-stagger window in shader cycles (0 = the library's default: off)
 GEMM_GROUP_M = 0           # row tiles per scheduling group (0 = automatic)
+SMALL_M_KERNEL = True      # False: small_m calls stay on the LDS-tiled kernels + split-K (A/B runs)
 
 
 def ensure_splitk_workspace(device, nbytes: int = 256 << 20) -> torch.Tensor:
@@ -93,8 +94,10 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
          remap: Optional[Sequence[int]] = None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0, strideR: int = 0,
          conv: Optional[dict] = None, a_off: int = 0, w_off: int = 0, c_off: int = 0,
          pre_act: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None, gate_scale: Optional[torch.Tensor] = None,
-         split: Optional[tuple] = None, split_alpha: float = 1.0):
+         split: Optional[tuple] = None, split_alpha: float = 1.0, ln: Optional[tuple] = None, small_m: bool = False):
     """C = epilogue(A @ W^T).  Offsets (*_off) are in elements of the respective tensor.
+    ln = (out, ada, scale_off, shift_off, ld_ada, rows_per, eps): also write cast(LN(C[m]) * (1 + scale) + shift) of the finished rows to ``out`` -
+    the ln_modulate of the op that follows (cvar_gemm_desc.ln_out, ABI 17; fused into the split-K reduction of small-M calls).
     split = (tensor, split_n, ld_split): result columns [0, split_n) go to ``tensor`` (rows not remapped), the rest to ``out`` at
     column n - split_n (cvar_gemm_desc.C_split; the qkv GEMM of inference: q beside a [R][Lmax][2C] K/V arena)."""
     d = GemmDesc()
@@ -128,11 +131,16 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
             raise TypeError('split target and out must share a dtype')
         d.C_split = _ptr(st)
         d.split_alpha = float(split_alpha)
+    if ln is not None:
+        lo, ada, sc_off, sh_off, ld_ada, rows_per, eps = ln
+        d.ln_out, d.ln_out_dtype = _ptr(lo), dt(lo)
+        d.ln_scale, d.ln_shift = _ptr(ada) + 4 * sc_off, _ptr(ada) + 4 * sh_off
+        d.ld_ln, d.ln_rows, d.ln_eps = ld_ada, rows_per, eps
     ws = _SPLITK_WS.get((A.device.index, _stream()))
     if ws is None:
         ws = ensure_splitk_workspace(A.device)
     d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
-    d.tile_cfg, d.stagger, d.group_m = GEMM_TILE_CFG, GEMM_STAGGER, GEMM_GROUP_M
+    d.tile_cfg, d.stagger, d.group_m = (12 if (small_m and GEMM_TILE_CFG == 0 and SMALL_M_KERNEL) else GEMM_TILE_CFG), GEMM_STAGGER, GEMM_GROUP_M
     if GEMM_PROFILE is None:
         check(_lib.load().cvar_gemm(C.byref(d), _stream()), 'cvar_gemm')
     else:

@@ -79,6 +79,9 @@ typedef struct {
      *                 stay on the implicit-GEMM tiles, 6: eligible 3x3 convs take the LDS-halo kernel at any size (conv_halo.hip sums
      *                 K chunk-major instead of tap-major: same math, different fp32 rounding); 7 / 8: the 8- / 4-wave 256x256 tile as ONE tile per
      *                 workgroup instead of the persistent kernel that large launches take since round 4 (same sums, bit-identical);
+     *                 12: as 0, and a small-M bf16 call (M <= 512) may take the weight-streaming kernel of gemm_skinny.hip - whole K per workgroup, no
+     *                 reduction launch (long K: a few K slices finished row-wise).  Same math; the fp32 summation order then depends on the plan chosen for
+     *                 (M, N, K), so callers that promise bit-identical rows across batch sizes (the VQVAE) stay on 0.  The transformer's passes use 12;
      *   stagger       > 0: the first workgroup of every CU starts delayed by up to this many shader cycles (by its index), which
      *                 de-phases the output bursts of equally long tiles; 0: off.  Never changes results. */
     void* ws; int64_t ws_bytes;
@@ -94,6 +97,14 @@ typedef struct {
      * softmax scale * log2(e) into the query rows here - ONE rounding of q * c instead of a multiply per score in the attention kernel
      * (cvar_attention_prescaled). */
     float split_alpha;
+    /* ABI 17: adaLN of the FINISHED rows in the same call (ln_out != NULL): after C[m,:] is complete,
+     *   ln_out[m,:] = cast( LN(C[m,:]) * (1 + ln_scale[(m / ln_rows) * ld_ln + :]) + ln_shift[(m / ln_rows) * ld_ln + :] )
+     * - exactly the cvar_ln_modulate the next op would run on this GEMM's output (basic_var.py:208-209: the x that proj / fc2 update is the input of the
+     * next ln_wo_grad).  Needs N = the row width (N % 4 == 0, N <= 2048), an fp32 C with ldc == N, no row remap / column split / conv / batch.  Calls that
+     * are sliced along K (small M) are finished row-wise - slices summed, bias / gate / residual, LayerNorm and modulation in one kernel instead of the
+     * reduction launch plus cvar_ln_modulate; every other call gets a cvar_ln_modulate launch behind it.  Same bits either way. */
+    void* ln_out; int ln_out_dtype;
+    const float* ln_scale; const float* ln_shift; int64_t ld_ln; int ln_rows; float ln_eps;
 } cvar_gemm_desc;
 int cvar_gemm(const cvar_gemm_desc* d, void* stream);
 

@@ -755,3 +755,121 @@ def test_fused_split_k_is_bit_identical_to_the_two_kernel_form(gpu_device, M, N,
             assert torch.equal(run(0, kind), ref), (kind, rep)
     want = A.float() @ W.float().t() + bias
     assert (run(0, 'plain').float() - want).abs().max() < 0.06 * max(1.0, float(want.abs().max()) / 8)
+
+
+# ---- round 4 (second half): the weight-streaming small-M kernel (gemm_skinny.hip) and the row-finishing split-K reduction with the adaLN behind it
+def _skinny_case(gpu_device, M, N, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(gpu_device)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(gpu_device)
+    bias = torch.randn(N, generator=g).to(gpu_device)
+    return A, W, bias, g
+
+
+@pytest.mark.parametrize('M,N,K', [(4, 4608, 1536), (16, 1536, 6144), (36, 1536, 1536), (64, 6144, 1536), (100, 4608, 1536), (144, 1536, 1536), (256, 1536, 1536),
+                                   (2, 1568, 96), (50, 48, 1536), (33, 4096, 1536), (400, 1536, 1536)])
+def test_skinny_gemm_every_epilogue_against_torch_and_the_tile_kernels(gpu_device, M, N, K):
+    """tile_cfg 12 sends these bf16 calls to cvar_gemm_skinny_kernel (whole K per workgroup, 8 waves interleaving the k-steps, epilogue in the launch);
+    tile_cfg 0 keeps them on the LDS-tiled kernels + split-K.  Same math, other fp32 summation order: both against torch on the bf16 operands, and the
+    two against each other inside the rounding of the output type.  Operands sit in NaN-filled arenas (a read outside a tensor cannot hide)."""
+    ops.ensure_splitk_workspace(gpu_device)
+    A0, W0, bias, g = _skinny_case(gpu_device, M, N, K, M * 13 + N + K)
+    # NaN arenas around both operands
+    Abuf = torch.full((M + 2, K), float('nan'), device=gpu_device, dtype=torch.bfloat16); Abuf[1:M + 1] = A0; A = Abuf[1:M + 1]
+    Wbuf = torch.full((N + 2, K), float('nan'), device=gpu_device, dtype=torch.bfloat16); Wbuf[1:N + 1] = W0; W = Wbuf[1:N + 1]
+    l = max(M // 2, 1)
+    R = (M + l - 1) // l
+    ada = (torch.randn(R, 2 * N, generator=g) * 0.3).to(gpu_device)
+    res0 = (torch.randn(M, N, generator=g) * 0.5).to(gpu_device)
+    want = A0.float() @ W0.float().t() + bias
+    tol = 0.02 * max(1.0, float(want.abs().max()) / 8)
+
+    def run(cfg, kind):
+        ops.GEMM_TILE_CFG = cfg
+        try:
+            if kind == 'gelu':
+                out = torch.full((M, N), float('nan'), device=gpu_device, dtype=torch.bfloat16)
+                ops.gemm(A, W, out, M=M, N=N, K=K, a_off=0, bias=bias, act=ACT_GELU_TANH)
+            elif kind == 'gate_res':
+                out = res0.clone()
+                ops.gemm(A, W, out, M=M, N=N, K=K, bias=bias, gate=ada, gate_off=N, ldg=2 * N, gate_rows=l, residual=out)
+            elif kind == 'f32':
+                out = torch.full((M, N), float('nan'), device=gpu_device, dtype=torch.float32)
+                ops.gemm(A, W, out, M=M, N=N, K=K, bias=bias)
+            else:               # K/V-arena remap + column split with the query factor (the qkv call of inference); N = 3 parts
+                Cq = N // 3
+                Lmax, off = l + 7, 3
+                arena = torch.full((R, Lmax, 2 * Cq), float('nan'), device=gpu_device, dtype=torch.bfloat16)
+                qs = torch.full((M, Cq), float('nan'), device=gpu_device, dtype=torch.bfloat16)
+                ops.gemm(A, W, arena, M=M, N=N, K=K, bias=bias, ldc=2 * Cq, remap=(l, Lmax, off), split=(qs, Cq, Cq), split_alpha=0.18)
+                out = (arena, qs)
+            return out
+        finally:
+            ops.GEMM_TILE_CFG = 0
+
+    kinds = ['gelu', 'gate_res', 'f32'] + (['qkv'] if N % 24 == 0 and M % l == 0 else [])
+    for kind in kinds:
+        a, b = run(12, kind), run(0, kind)
+        if kind == 'qkv':
+            Cq = N // 3
+            Lmax, off = l + 7, 3
+            for got in (a, b):
+                arena, qs = got
+                assert (qs.float().cpu() - (want[:, :Cq] * 0.18).cpu()).abs().max() < tol
+                kv = arena[:, off:off + l].reshape(M, 2 * Cq).float().cpu()
+                assert (kv - want[:, Cq:].cpu()).abs().max() < tol
+                rest = torch.cat([arena[:, :off].reshape(-1), arena[:, off + l:].reshape(-1)])
+                assert torch.isnan(rest.float()).all()                       # rows outside the scale's slots untouched
+            continue
+        ref = {'gelu': F.gelu(want, approximate='tanh'), 'f32': want,
+               'gate_res': res0 + want * ada[:, N:].repeat_interleave(l, 0)[:M]}[kind]
+        for got in (a, b):
+            assert not torch.isnan(got.float()).any(), kind
+            assert (got.float() - ref).abs().max() < tol, (kind, float((got.float() - ref).abs().max()))
+        assert (a.float() - b.float()).abs().max() < tol
+    # run-to-run determinism of the streaming kernel (fixed wave order in the LDS reduction)
+    r0 = run(12, 'f32')
+    for _ in range(3):
+        assert torch.equal(run(12, 'f32'), r0)
+
+
+@pytest.mark.parametrize('out_dtype', [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize('M,N,K,cfg', [(4, 1536, 6144, 12), (64, 1536, 6144, 12), (144, 1536, 6144, 12), (100, 1536, 1536, 12), (36, 1920, 1920, 12),
+                                       (64, 1536, 6144, 0), (256, 1536, 1536, 0), (676, 1536, 6144, 0), (1024, 1536, 1536, 0), (200, 1920, 7680, 0),
+                                       (2048, 1536, 1536, 12)])
+def test_gemm_with_the_adaln_of_the_next_op_is_bit_identical_to_two_calls(gpu_device, out_dtype, M, N, K, cfg):
+    """cvar_gemm_desc.ln_out (ABI 17): proj / fc2 of a small pass also write LN(x) * (1 + scale) + shift of the rows they finish.  Where the call is sliced
+    along K the rows are finished by cvar_splitk_rowfin_kernel (slices -> bias / gate / residual -> x -> adaLN in one launch); otherwise the library
+    launches cvar_ln_modulate behind the GEMM.  With the slice producer held fixed the result must equal GEMM + cvar_ln_modulate bit for bit: x AND the
+    modulated rows.  cfg 0 = LDS-tiled producers (split-K for M <= 1024), cfg 12 = the streaming kernel's K slices / unsliced form; M = 2048: no slices at all."""
+    ops.ensure_splitk_workspace(gpu_device)
+    A, W, bias, g = _skinny_case(gpu_device, M, N, K, M + 3 * N + K)
+    l = max(M // 2, 1)
+    R = (M + l - 1) // l
+    n_ada = 6 * N
+    ada = (torch.randn(R, n_ada, generator=g) * 0.3).to(gpu_device)
+    res0 = (torch.randn(M, N, generator=g) * 0.5).to(gpu_device)
+    eps = 1e-6
+    ops.GEMM_TILE_CFG = cfg
+    try:
+        x1 = res0.clone()
+        u1 = torch.full((M, N), float('nan'), device=gpu_device, dtype=out_dtype)
+        ops.gemm(A, W, x1, M=M, N=N, K=K, bias=bias, gate=ada, gate_off=N, ldg=n_ada, gate_rows=l, residual=x1, ln=(u1, ada, 3 * N, 5 * N, n_ada, l, eps))
+        # the same call without the request: the slice plan of the streaming kernel depends on whether a row-finishing launch follows, so the unfused
+        # reference of cfg 12 is only guaranteed to share the producer when the call is not sliced; compare bits where it does, numbers otherwise
+        x2 = res0.clone()
+        ops.gemm(A, W, x2, M=M, N=N, K=K, bias=bias, gate=ada, gate_off=N, ldg=n_ada, gate_rows=l, residual=x2)
+        u2 = torch.empty(M, N, device=gpu_device, dtype=out_dtype)
+        ops.ln_modulate(x1, ada, 3 * N, 5 * N, n_ada, l, u2, M, N, eps)
+    finally:
+        ops.GEMM_TILE_CFG = 0
+    assert not torch.isnan(u1.float()).any()
+    # (a) the modulated rows are exactly cvar_ln_modulate of the x this call wrote
+    assert torch.equal(u1, u2)
+    # (b) x itself: same bits as the unfused call when the producer is the same (always for the tile kernels), same numbers otherwise
+    want = res0 + (A.float() @ W.float().t() + bias) * ada[:, N:2 * N].repeat_interleave(l, 0)[:M]
+    assert (x1 - want).abs().max() < 0.02 * max(1.0, float(want.abs().max()) / 8)
+    if cfg == 0 or M > 1024:
+        assert torch.equal(x1, x2)
+    else:
+        assert (x1 - x2).abs().max() < 1e-3 * max(1.0, float(want.abs().max()))
