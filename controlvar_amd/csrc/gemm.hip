@@ -1440,6 +1440,13 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
         if (c128 < 0.97 * c256) return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
     }
     if (ov != 0 && (p.M >= 2048 || (p.split_tiles > 0 && p.M > 1024)) && n_ok) return launch_cfg<T, 256, 256, 2, 4>(p, batch, st);
+#if CVAR_TU_PLAIN && !CVAR_TU_CONV
+    // experiment (tile_cfg 13 / 14): the 128x128 tile with three / four LDS stages - two / three K tiles in flight per workgroup (one workgroup per CU)
+    if constexpr (sizeof(T) == 2) {
+        if (p.tile_cfg == 13 && !p.conv) return launch_cfg<T, 128, 128, 2, 2, 3>(p, batch, st);
+        if (p.tile_cfg == 14 && !p.conv) return launch_cfg<T, 128, 128, 2, 2, 4>(p, batch, st);
+    }
+#endif
     return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
 }
 
@@ -1580,8 +1587,22 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     // (Round 4, measured and removed: 64-row tiles UNSPLIT wherever they alone put >= 96 / 128 / 192 workgroups on the chip - e.g. M = 256 x N = 4608 as 144 tiles
     //  of 64x128 in one launch instead of 72 tiles of 128x128 split four ways + the reduction launch - is exactly neutral at B = 1 ... 16:
     //  profiles/r04_small_batch.txt.  The launches of this regime sit on their latency floor either way.)
-    if (long_k_splits || (!d->conv && d->batch == 1 && d->M <= 1024 && (d->N % 4) == 0 && tm * tn < 128 && nk_all >= 8 && g_splitk_ws)) {
-        int splits = long_k_splits ? long_k_splits : min(16, max(2, 320 / (tm * tn)));
+    // Mid-M passes of the transformer (64 < M <= 1024, tile_cfg 12): the 128x128 tile with THREE LDS stages wherever all its workgroups fit the chip
+    // at once (tiles x slices <= 256, one workgroup of 96 KB per CU).  A workgroup of this regime is bound by the latency of its own K loop - one K tile
+    // of DMA in flight behind the one being multiplied - not by the matrix pipe: two tiles in flight run M = 400 qkv / fc1 27.7 / 28.6 -> 18.5 / 19.6 us and
+    // M = 676 qkv 28.2 -> 19.4 us, while launches of more than 256 workgroups (a second round at one workgroup per CU) lose 15-20 % and keep two stages
+    // (tools/skinny_bench.py with ISO_CFG = 13, profiles/r04_small_batch.txt).  Slices are then chosen to fill 256 workgroups instead of 320.
+    const bool three = d->tile_cfg == 12 && !d->conv && d->batch == 1 && d->dtype == CVAR_BF16 && d->M > 64 && d->M <= 1024 && (d->N % 4) == 0 && tm * tn <= 256 &&
+                       nk_all >= 6 && !d->pre_act && !d->aux;
+    int three_splits = 1;
+    if (three && g_splitk_ws) {
+        three_splits = min(16, max(1, 256 / (tm * tn)));
+        while (three_splits > 1 && nk_all / three_splits < 4) --three_splits;           // at least 4 K tiles per slice: the pipeline needs a loop to fill
+    }
+    if (three) p.tile_cfg = 13;                                                         // launch_typed: three-stage instance of the 128x128 tile
+    if (long_k_splits || (three && three_splits > 1) ||
+        (!three && !d->conv && d->batch == 1 && d->M <= 1024 && (d->N % 4) == 0 && tm * tn < 128 && nk_all >= 8 && g_splitk_ws)) {
+        int splits = long_k_splits ? long_k_splits : three ? three_splits : min(16, max(2, 320 / (tm * tn)));
         int per = (nk_all + splits - 1) / splits;
         if (per < 2) per = 2;
         splits = (nk_all + per - 1) / per;
@@ -1615,13 +1636,13 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
         !d->pre_act && !d->aux && !d->gate_scale && d->remap_l == 0 && d->split_n == 0 && d->strideC == 0 && d->ldc == d->N &&
         d->ldw == d->K &&      // the halo kernel addresses packed [Cout][9 Cin] weights: padded weight rows stay on the implicit-GEMM path
         (!d->bias || (((uintptr_t)d->bias & 15) == 0)) && (long)d->Hin * d->Win * d->Cin * 2 < 0x7fffffffL) {
-        const long tiles = (long)(d->M / 256);
         // wide form: Cout a multiple of 160, bf16 output, optional bf16 residual; two workgroups per CU or the implicit-GEMM tiles win (640->640 at 16x16)
         const bool wide = d->N % 160 == 0 && d->out_dtype == CVAR_BF16 && (((uintptr_t)d->C & 7) == 0) &&
                           (!d->residual || (d->res_dtype == CVAR_BF16 && d->ldr == d->N && (((uintptr_t)d->residual & 7) == 0))) &&
                           true;       // round 4: at any grid size - small batches (B = 1: 36.5 -> 34.9 ms, B = 8: 71.0 -> 69.8 ms per generation, profiles/r04_small_batch.txt) gain too
         // narrow form: Cout <= 32 (conv_out, 160 -> 3), bf16 or fp32 output, no residual - the implicit-GEMM tile spends its time re-fetching the input
-        const bool narrow = d->N <= 32 && !d->residual && (d->out_dtype == CVAR_BF16 || d->out_dtype == CVAR_F32) && (tiles >= 512 || d->tile_cfg == 6);
+        // (decided by the IMAGE size, not by the batch: the two kernels sum K in different orders, and an image's pixels must not depend on the batch it rides in)
+        const bool narrow = d->N <= 32 && !d->residual && (d->out_dtype == CVAR_BF16 || d->out_dtype == CVAR_F32) && ((long)d->Hout * d->Wout >= 65536 || d->tile_cfg == 6);
         if (wide || narrow)
             return cvar_conv3x3_halo_bf16(d->A, d->W, d->bias, d->residual, d->C, d->out_dtype == CVAR_F32, d->M / (d->Hout * d->Wout), d->Hout, d->Wout, d->Cin,
                                           d->N, d->up, st);

@@ -6,8 +6,12 @@
 //   * a workgroup owns 16 NT output columns x 16 MT rows over the WHOLE K range: no partial sums leave the workgroup, the epilogue runs in the same launch;
 //   * its 8 waves interleave the 32-deep k-steps (wave w takes steps w, w + 8, ... of a per-workgroup rotation of K), so the workgroup streams 512 contiguous
 //     bytes of every weight row per round and different workgroups read different k-blocks of the shared activations at any moment;
-//   * operands go global -> registers (buffer_load_dwordx4, 16 B per lane = one MFMA fragment; rows past M / N are out-of-range offsets = zeros): every weight
-//     byte is used by exactly one wave, so LDS staging would only add a hop; the activations (M x K, <= 0.4 MB) are re-read by every workgroup out of L2;
+//   * weights go global -> registers (buffer_load_dwordx4, 16 B per lane = one MFMA fragment; rows past N are out-of-range offsets = zeros): every weight
+//     byte is used by exactly one wave, LDS staging would only add a hop;
+//   * the activations (16 MT rows x K, re-read by every workgroup out of L2) are the bulk of a workgroup's bytes.  Fetched as fragments - 16 rows x 16 B per
+//     quarter wave, 64 cache lines per instruction - the CU's texture path delivers a quarter of its rate (first version: 8.5 us at M = 4 -> 24.6 us at
+//     M = 144 for the qkv call, profiles/r04_small_batch.txt).  They are therefore fetched row-contiguously (half a wave per 512-byte row piece), parked in
+//     LDS (two 256-k blocks, XOR-swizzled 16-byte slots, two blocks ahead in registers) and read back as fragments with conflict-free ds_read_b128;
 //   * v_mfma_f32_16x16x32_bf16 with the weight fragment as the row operand: a lane ends up with 4 consecutive output columns of one row (vector stores);
 //   * the 8 partial accumulators meet in LDS (fixed wave order -> bit-reproducible) and each thread finishes one quad through gemm_epilogue_quad.
 // Long-K calls (fc2: K = 4C) would make every workgroup read M x K activations; they keep a K split (blockIdx.z, fp32 partial tiles in the caller's workspace)
@@ -19,72 +23,107 @@
 typedef __attribute__((ext_vector_type(4))) int v4i_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bfv8_t;
 
-template <int MT, int NT, int PF, bool PARTIAL>
+template <int MT, int NT, bool PARTIAL>
 __global__ __launch_bounds__(512) void cvar_gemm_skinny_kernel(const GemmParams p) {
-    constexpr int T = MT * NT;
+    constexpr int T = MT * NT, RM = 16 * MT;
     static_assert(T <= 8, "one output quad per thread");
-    __shared__ f32x4_t sred[8 * T * 64];
+    constexpr int STAGE = RM * 512;                              // one activation block: RM rows x 256 k (512 B per row)
+    constexpr int RED = 8 * T * 64 * 16;
+    constexpr int LDS_BYTES = 2 * STAGE > RED ? 2 * STAGE : RED;
+    constexpr int WPF = 8;                                       // weight fragments in flight per wave: 8 blocks ahead (K = 1536: all of them)
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
-    const int n0 = blockIdx.x * (16 * NT), m0 = blockIdx.y * (16 * MT);
+    const int n0 = blockIdx.x * (16 * NT), m0 = blockIdx.y * RM;
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((long)p.M * p.lda * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, (int)((long)p.N * p.ldw * 2), 0x00020000);
-    unsigned offA[MT], offW[NT];
+
+    // k range of this workgroup in steps of 32 (a K slice when the call is split) and in blocks of 8 steps; each workgroup starts its walk over the blocks at
+    // its own block (rot): every workgroup reads the SAME activation rows, and with one common order a k-block of all rows sits on a few L2 channels
+    const int nks_all = p.K >> 5;
+    const int ks_lo = p.split_tiles > 0 ? (int)blockIdx.z * p.split_tiles : 0;
+    const int ks_hi = p.split_tiles > 0 ? min(nks_all, ks_lo + p.split_tiles) : nks_all;
+    const int S = ks_hi - ks_lo, nb = (S + 7) >> 3;
+    const int rot = (int)((blockIdx.x * 11u + blockIdx.y * 5u) % (unsigned)max(nb, 1));
+    auto blk = [&](int b) { const int bb = b + rot; return bb >= nb ? bb - nb : bb; };
+
+    // staging: thread -> (row, 16-byte chunk) of the block, row-contiguous (half a wave covers a row's 512 B); LDS slot XOR-swizzled by the row
+    unsigned a_off[MT];
+    int lds_w[MT];
+    const int c = tid & 31;
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int m = m0 + 16 * i + l15;
-        offA[i] = m < p.M ? (unsigned)(((long)m * p.lda + kq * 8) * 2) : 0x80000000u;
+    for (int e = 0; e < MT; ++e) {
+        const int r = (tid >> 5) + 16 * e, m = m0 + r;
+        a_off[e] = m < p.M ? (unsigned)(((long)m * p.lda + c * 8) * 2) : 0x80000000u;
+        lds_w[e] = r * 512 + ((c ^ (r & 15)) << 4);
     }
+    bf16x8_t ar[2][MT];
+    auto issueA = [&](int slot, int b) {
+        const int k0 = (ks_lo + 8 * blk(b)) * 32, rem = ks_hi * 32 - k0;          // elements of the slice from this block on
+#pragma unroll
+        for (int e = 0; e < MT; ++e)
+            ar[slot][e] = __builtin_bit_cast(bf16x8_t, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(a_rsrc, c * 8 < rem ? a_off[e] : 0x80000000u, (unsigned)k0 * 2u, 0));
+    };
+    unsigned offW[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int n = n0 + 16 * j + l15;
         offW[j] = n < p.N ? (unsigned)(((long)n * p.ldw + kq * 8) * 2) : 0x80000000u;
     }
+    bf16x8_t wf[WPF][NT];
+    auto issueW = [&](int slot, int b) {
+        const int st = 8 * blk(b) + wave;                                          // this wave's step of the block
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            wf[slot][j] = __builtin_bit_cast(bf16x8_t, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, st < S ? offW[j] : 0x80000000u, (unsigned)(ks_lo + st) * 64u, 0));
+    };
     f32x4_t acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // k-steps of this workgroup: [ks_lo, ks_hi) in units of 32 k (a K slice when the call is split); wave w takes ks_lo + w + 8 t
-    const int nks_all = p.K >> 5;
-    const int ks_lo = p.split_tiles > 0 ? (int)blockIdx.z * p.split_tiles : 0;
-    const int ks_hi = p.split_tiles > 0 ? min(nks_all, ks_lo + p.split_tiles) : nks_all;
-    const int S = ks_hi - ks_lo;
-    const int nsteps = (S - wave + 7) >> 3;                      // <= 0: nothing for this wave
-    // Every workgroup reads the SAME activation rows, and rows of K = 1536 bf16 (3072 B) put one k-block of all rows on 4 of an L2's 16 channels: with all
-    // workgroups walking K in the same order those channels serve the whole chip (measured: 7.7 us at M = 4 -> 14.3 us at M = 64 per GEMM).  Each workgroup
-    // therefore starts its walk at its own k-step (a rotation of the step order: still every step exactly once, the sum order is fixed per output tile).
-    const int rot = (int)((blockIdx.x * 11u + blockIdx.y * 5u) % (unsigned)max(S, 1));
-    bf16x8_t af[PF][MT], wf[PF][NT];
-    auto issue = [&](int slot, int t) {
-        int j = wave + 8 * t + rot;
-        if (j >= S) j -= S;
-        const unsigned so = (unsigned)(ks_lo + j) * 64u;
+    // fragment of MFMA row block i: row 16 i + l15, chunk 4 wave + kq of the block (conflict-free with the swizzle: see the ds_read_b128 lane groups)
+    const int fr = l15 * 512 + (((4 * wave + kq) ^ l15) << 4);
+    if (nb > 0) {
+        issueA(0, 0);
+        if (nb > 1) issueA(1, 1);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) wf[slot][j] = __builtin_bit_cast(bf16x8_t, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, offW[j], so, 0));
+        for (int u = 0; u < WPF; ++u)
+            if (u < nb) issueW(u, u);
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[slot][i] = __builtin_bit_cast(bf16x8_t, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(a_rsrc, offA[i], so, 0));
-    };
+        for (int e = 0; e < MT; ++e) *(bf16x8_t*)(smem + lds_w[e]) = ar[0][e];
+        if (nb > 2) issueA(0, 2);
+    }
+    __syncthreads();
+    for (int base = 0; base < nb; base += WPF) {
 #pragma unroll
-    for (int u = 0; u < PF; ++u)
-        if (u < nsteps) issue(u, u);
-    for (int base = 0; base < nsteps; base += PF) {
+        for (int u = 0; u < WPF; ++u) {
+            const int b = base + u;
+            if (b < nb) {
+                bf16x8_t af[MT];
 #pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int t = base + u;
-            if (t < nsteps) {
+                for (int i = 0; i < MT; ++i) af[i] = *(const bf16x8_t*)(smem + (u & 1) * STAGE + fr + i * 8192);
+                if (b + 1 < nb) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
+                    for (int e = 0; e < MT; ++e) *(bf16x8_t*)(smem + ((u + 1) & 1) * STAGE + lds_w[e]) = ar[(u + 1) & 1][e];
+                }
+                if (b + 3 < nb) issueA((u + 1) & 1, b + 3);
+                if (8 * blk(b) + wave < S) {
 #pragma unroll
-                    for (int i = 0; i < MT; ++i)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfv8_t, wf[u][j]), __builtin_bit_cast(bfv8_t, af[u][i]), acc[i][j], 0, 0, 0);
-                if (t + PF < nsteps) issue(u, t + PF);
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfv8_t, wf[u][j]), __builtin_bit_cast(bfv8_t, af[i]), acc[i][j], 0, 0, 0);
+                }
+                if (b + WPF < nb) issueW(u, b + WPF);
+                __syncthreads();
             }
         }
     }
-    // the eight waves' partial tiles -> LDS -> one quad per thread, summed in wave order
+    // the eight waves' partial tiles -> LDS (over the staging buffers: everybody is past the last block's barrier) -> one quad per thread, summed in wave order
+    f32x4_t* sred = (f32x4_t*)smem;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -107,57 +146,47 @@ __global__ __launch_bounds__(512) void cvar_gemm_skinny_kernel(const GemmParams 
     }
 }
 
-template <int MT, int NT, int PF>
+template <int MT, int NT>
 static int skinny_launch_cfg(const GemmParams& p, int slices, hipStream_t st) {
     dim3 grid((unsigned)((p.N + 16 * NT - 1) / (16 * NT)), (unsigned)((p.M + 16 * MT - 1) / (16 * MT)), (unsigned)slices), block(512);
-    if (p.split_tiles > 0) hipLaunchKernelGGL((cvar_gemm_skinny_kernel<MT, NT, PF, true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((cvar_gemm_skinny_kernel<MT, NT, PF, false>), grid, block, 0, st, p);
+    if (p.split_tiles > 0) hipLaunchKernelGGL((cvar_gemm_skinny_kernel<MT, NT, true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((cvar_gemm_skinny_kernel<MT, NT, false>), grid, block, 0, st, p);
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;
 }
 
 // plan: rows per workgroup 16 mt, columns 16 nt, K slices (1 = none).  Returns 0 when the call is not one for this kernel.
-// Cost model (bytes; the kernel is bound by what a CU can pull and by what the L2s serve, not by MFMA):
-//   per workgroup   (16 mt + 16 nt) * Kslice * 2        <= 320 KB   (a CU ingests ~100-130 GB/s: 2.5-3 us)
-//   all workgroups  A re-read once per column group + W re-read once per row group <= 160 MB (~20 TB/s of L2 -> 8 us: beyond that the tile kernels win)
+// Rules from tools/skinny_bench.py on the d24 calls (profiles/r04_small_batch.txt; per call incl. the adaLN where requested, us, streaming / LDS-tiled + split-K):
+//   one row group (M <= 64):  qkv 8.9-12.4 / 11.6-16.9, fc1 9.4-12.9 / 13.2-18.8, proj 8.5-10.4 / 12.0-15.1, fc2 (K = 6144 as 4 slices + row finish) 14.8-21.0 / 18.8-21.7
+//   more row groups:          wins only for the small square call (proj, N K <= 4 M: 13.5-15.8 / 17.7-22.5 up to M = 256); qkv / fc1 / fc2 tie or lose from M = 100 on
+// - every extra row group re-reads the weights and multiplies the workgroups past what is resident (two per CU).  16 columns per workgroup always (nt = 2 halves
+// the activation re-reads but needs 161 registers: one workgroup per CU, two rounds).  Slices: the fewest that keep a workgroup's bytes under 320 KB.
 int cvar_gemm_skinny_plan(int M, int N, int K, long lda, long ldw, int want_rowfin, int have_ws, int* mt_, int* nt_, int* slices_) {
-    if (M <= 0 || M > 512 || (K & 31) || (N & 15) || (lda & 7) || (ldw & 7)) return 0;
+    (void)want_rowfin;
+    if (M <= 0 || M > 256 || (K & 31) || (N & 15) || (lda & 7) || (ldw & 7)) return 0;
     if ((long)M * lda * 2 >= (1L << 31) || (long)N * ldw * 2 >= (1L << 31)) return 0;
     const int mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
     const int gy = (M + 16 * mt - 1) / (16 * mt);
+    if (gy > 1 && (long)N * K > (4L << 20)) return 0;
     const int nks = K >> 5;
-    int best_nt = 0, best_sl = 0;
-    double best = 1e30;
-    for (int nt = 1; nt <= 2; ++nt) {
-        if (mt * nt > 8 || (nt == 2 && (N & 31))) continue;
-        const long gx = N / (16 * nt);
-        for (int sl = 1; sl <= 8; sl *= 2) {
-            if (sl > 1 && (!have_ws || nks % sl || nks / sl < 16)) continue;          // a K slice is at least 512 deep
-            const double wg = (double)(16 * mt + 16 * nt) * (K / sl) * 2.0;
-            const double total = (double)gx * M * K * 2.0 + (double)gy * N * K * 2.0;
-            if (wg > 320.0 * 1024 || total > 160e6) continue;
-            // time model (us): the slower of per-workgroup ingest (rounds of 256 CUs x 2 resident workgroups) and the L2 service; a sliced call pays its
-            // second launch unless that launch replaces the cvar_ln_modulate that would follow anyway; few workgroups stream badly
-            const long wgs = gx * gy * sl;
-            const double rounds = (double)((wgs + 511) / 512);
-            const double t = fmax(rounds * wg / 110e3, total / 18e6) + (sl > 1 ? (want_rowfin ? 1.0 : 5.0) : 0.0) + (wgs < 256 ? 1.5 * (double)(256 - wgs) / 256.0 : 0.0);
-            if (t < best) { best = t; best_nt = nt; best_sl = sl; }
-        }
+    for (int sl = 1; sl <= 8; sl *= 2) {
+        if (sl > 1 && (!have_ws || gy > 1 || nks % sl || (nks / sl) % 8 || nks / sl < 16)) continue;          // a K slice is whole 256-k blocks, at least 512 deep
+        if ((double)(16 * mt + 16) * (K / sl) * 2.0 > 320.0 * 1024) continue;
+        *mt_ = mt; *nt_ = 1; *slices_ = sl;
+        return 1;
     }
-    if (!best_nt) return 0;
-    *mt_ = mt; *nt_ = best_nt; *slices_ = best_sl;
-    return 1;
+    return 0;
 }
 
 int cvar_gemm_skinny_launch(const GemmParams& p, int mt, int nt, int slices, hipStream_t st) {
     if (nt == 1) {
-        if (mt == 1) return skinny_launch_cfg<1, 1, 8>(p, slices, st);
-        if (mt == 2) return skinny_launch_cfg<2, 1, 6>(p, slices, st);
-        return skinny_launch_cfg<4, 1, 4>(p, slices, st);
+        if (mt == 1) return skinny_launch_cfg<1, 1>(p, slices, st);
+        if (mt == 2) return skinny_launch_cfg<2, 1>(p, slices, st);
+        return skinny_launch_cfg<4, 1>(p, slices, st);
     }
-    if (mt == 1) return skinny_launch_cfg<1, 2, 8>(p, slices, st);
-    if (mt == 2) return skinny_launch_cfg<2, 2, 6>(p, slices, st);
-    return skinny_launch_cfg<4, 2, 4>(p, slices, st);
+    if (mt == 1) return skinny_launch_cfg<1, 2>(p, slices, st);
+    if (mt == 2) return skinny_launch_cfg<2, 2>(p, slices, st);
+    return skinny_launch_cfg<4, 2>(p, slices, st);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -207,11 +207,11 @@ constexpr int WE_TOK = 64;
 __global__ __launch_bounds__(256) void word_embed_kernel(const float* __restrict__ tok, const float* __restrict__ W,
                                                         const float* __restrict__ bias, const float* __restrict__ lvl_pos,
                                                         float* __restrict__ x, int nb, int nrep, int l, int Cvae, int C,
-                                                        int x_rows, int x_off) {
+                                                        int x_rows, int x_off, int tpb) {
     __shared__ __attribute__((aligned(16))) float tk[WE_TOK * 64];
     const long ntok = (long)nb * l;
-    const long bt0 = (long)blockIdx.x * WE_TOK;
-    const int nt = (int)min((long)WE_TOK, ntok - bt0);
+    const long bt0 = (long)blockIdx.x * tpb;            // tpb <= WE_TOK tokens per block
+    const int nt = (int)min((long)tpb, ntok - bt0);
     for (int i = threadIdx.x; i < nt * Cvae; i += 256) tk[i] = tok[bt0 * Cvae + i];
     __syncthreads();
     const int c = blockIdx.y * 256 + threadIdx.x;
@@ -248,8 +248,12 @@ extern "C" int cvar_word_embed(const float* tok, const float* W, const float* bi
     if (x_rows < x_off + l || x_off < 0) return CVAR_EINVAL;
     if (Cvae > 64 || Cvae % 4) return CVAR_EUNSUPPORTED;
     const long ntok = (long)nb * l;
-    hipLaunchKernelGGL(word_embed_kernel, dim3((unsigned)((ntok + WE_TOK - 1) / WE_TOK), (unsigned)cdiv(C, 256)), dim3(256), 0, as_stream(stream), tok, W,
-                       bias, lvl_pos, x, nb, nrep, l, Cvae, C, x_rows, x_off);
+    // tokens per block: 64 amortise the weight rows a thread keeps in registers; few tokens in all (small batches: a B = 1 generation spent 52 us per call in
+    // 8 x 6 blocks walking 64 tokens each) are spread over more blocks instead - at least ~512 blocks before the per-block count grows
+    int tpb = WE_TOK;
+    while (tpb > 4 && ((ntok + tpb - 1) / tpb) * cdiv(C, 256) < 512) tpb >>= 1;
+    hipLaunchKernelGGL(word_embed_kernel, dim3((unsigned)((ntok + tpb - 1) / tpb), (unsigned)cdiv(C, 256)), dim3(256), 0, as_stream(stream), tok, W,
+                       bias, lvl_pos, x, nb, nrep, l, Cvae, C, x_rows, x_off, tpb);
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;
 }

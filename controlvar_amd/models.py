@@ -176,7 +176,8 @@ class VQVAE(nn.Module):
         if c['ks'] == 1:
             M = B * Hin * Win
             out = torch.empty(M, c['cout'], device=x.device, dtype=out_dtype or T)
-            ops.gemm(x, c['w'], out, M=M, N=c['cout'], K=c['cin'], bias=c['b'], residual=residual)
+            # never split along K: with the tile kernels alone a row's sum order does not depend on M, so an image decodes / encodes to the same bits in any batch
+            ops.gemm(x, c['w'], out, M=M, N=c['cout'], K=c['cin'], bias=c['b'], residual=residual, split_k=False)
             return out, Hin, Win
         Hout = Hin * 2 if up else (Hin // 2 if stride == 2 else Hin)
         Wout = Win * 2 if up else (Win // 2 if stride == 2 else Win)
@@ -1073,8 +1074,15 @@ class ControlVAR(nn.Module):
 
     def _decode_pair(self, f_hat: torch.Tensor) -> torch.Tensor:
         vae: VQVAE = self.vae_proxy[0]
-        imgs = [vae._decode(f_hat[:, m].contiguous(), lo=-1.0, hi=1.0, mul=0.5, add=0.5) for m in range(f_hat.shape[1])]
-        return imgs[0] if len(imgs) == 1 else torch.cat(imgs, dim=2)
+        B, mf = f_hat.shape[:2]
+        if mf == 1:
+            return vae._decode(f_hat[:, 0].contiguous(), lo=-1.0, hi=1.0, mul=0.5, add=0.5)
+        # control and image maps go through the decoder as ONE batch (b-major: [b][map]): at small B every decoder launch is a handful of workgroups
+        # and latency-bound, so two passes of B images cost twice one pass of 2 B (B = 1: 78 conv + 234 GroupNorm launches -> 39 + 117).  Per-image
+        # results do not depend on the batch they ride in (tests/test_gpu_parity.py::test_batch_rows_are_independent...), so the pixels are unchanged.
+        img = vae._decode(f_hat.reshape(B * mf, *f_hat.shape[2:]), lo=-1.0, hi=1.0, mul=0.5, add=0.5)
+        H, W = img.shape[-2:]
+        return img.view(B, mf, 3, H, W).permute(0, 2, 1, 3, 4).reshape(B, 3, mf * H, W)          # control on top, RGB below (control_var.py:563-565)
 
     # ---- public API
     @torch.no_grad()

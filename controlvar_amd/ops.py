@@ -94,7 +94,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
          remap: Optional[Sequence[int]] = None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0, strideR: int = 0,
          conv: Optional[dict] = None, a_off: int = 0, w_off: int = 0, c_off: int = 0,
          pre_act: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None, gate_scale: Optional[torch.Tensor] = None,
-         split: Optional[tuple] = None, split_alpha: float = 1.0, ln: Optional[tuple] = None, small_m: bool = False):
+         split: Optional[tuple] = None, split_alpha: float = 1.0, ln: Optional[tuple] = None, small_m: bool = False, split_k: bool = True):
     """C = epilogue(A @ W^T).  Offsets (*_off) are in elements of the respective tensor.
     ln = (out, ada, scale_off, shift_off, ld_ada, rows_per, eps): also write cast(LN(C[m]) * (1 + scale) + shift) of the finished rows to ``out`` -
     the ln_modulate of the op that follows (cvar_gemm_desc.ln_out, ABI 17; fused into the split-K reduction of small-M calls).
@@ -139,7 +139,8 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
     ws = _SPLITK_WS.get((A.device.index, _stream()))
     if ws is None:
         ws = ensure_splitk_workspace(A.device)
-    d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
+    if split_k:
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
     d.tile_cfg, d.stagger, d.group_m = (12 if (small_m and GEMM_TILE_CFG == 0 and SMALL_M_KERNEL) else GEMM_TILE_CFG), GEMM_STAGGER, GEMM_GROUP_M
     if GEMM_PROFILE is None:
         check(_lib.load().cvar_gemm(C.byref(d), _stream()), 'cvar_gemm')

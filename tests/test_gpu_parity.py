@@ -422,6 +422,26 @@ def test_batch_rows_are_independent_and_deterministic(gpu_device):
     assert a.shape == (6, 3, 512, 256) and float(a.min()) >= 0.0 and float(a.max()) <= 1.0
 
 
+@pytest.mark.parametrize('dtype', [BF16, torch.float32])
+def test_an_image_decodes_and_encodes_to_the_same_bits_in_any_batch(gpu_device, dtype):
+    """The full VQVAE (ch = 160): rows 1:3 of a batch of 7 against the same two images alone - pixels of the decoder and the encoder's features
+    bit for bit.  Holds because every kernel of the tokenizer sums a row / pixel / (image, group) in an order that does not depend on the batch:
+    LDS-halo and implicit-GEMM convs per tile, GroupNorm per image, and the 1x1 convs never take split-K (models.VQVAE._conv).  autoregressive_infer_cfg
+    relies on it when it decodes the control and image maps of a batch as one batch of 2 B (models.ControlVAR._decode_pair)."""
+    vae = make_vae(160, dtype, gpu_device)
+    g = torch.Generator().manual_seed(11)
+    f_hat = (torch.randn(7, 32, 16, 16, generator=g) * 0.7).to(gpu_device)
+    with torch.no_grad():
+        big = vae.fhat_to_img(f_hat)
+        small = vae.fhat_to_img(f_hat[1:3].contiguous())
+    assert torch.equal(big[1:3], small)
+    img = synth_images(7, 256, seed=5).to(gpu_device)
+    with torch.no_grad():
+        fb = vae._encode_f(img)
+        fs = vae._encode_f(img[1:3].contiguous())
+    assert torch.equal(fb[1:3], fs)
+
+
 def test_hip_graph_replay_equals_eager(gpu_device):
     """The captured HIP graph of a whole generation (scales x blocks + decodes) reproduces the eager launch sequence bit
     for bit, and fresh labels / seeds written into its static buffers take effect on replay."""

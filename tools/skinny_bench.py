@@ -8,6 +8,7 @@ import torch
 from controlvar_amd import ops
 from controlvar_amd._lib import ACT_GELU_TANH
 
+ops.GEMM_TILE_CFG = int(os.environ.get('ISO_CFG', '0'))          # tile_cfg of the LDS-tiled arm (13 / 14: three / four LDS stages on the 128x128 tile)
 dev = torch.device('cuda:0')
 C, depth, Lmax = 1536, 24, 1360
 Ms = [int(a) for a in sys.argv[1:]] or [4, 16, 36, 64, 100, 144, 256, 400, 676, 1024]
