@@ -184,6 +184,14 @@ def side_configs(a, dev, box):
     out['latency_b1_ms'] = {'value': round(graph * 1e3, 2), 'unit': 'ms', 'steps': 10, 'ms_per_step': round(graph * 1e3, 2), 'eager_ms': round(eager * 1e3, 2),
                             'config': f'd{a.depth} autoregressive_infer_cfg B=1 (2 CFG rows), one HIP graph per generation, incl. both decodes'}
     del run
+    # the regime the reference's own sampling calls run in (train_control_var_hpu.py:372 asserts batch < 50): B = 8 and B = 32 as graphs
+    for Bs in (8, 32):
+        ls, ts = torch.arange(Bs, device=dev) % 1000, torch.arange(Bs, device=dev) % 4
+        run = var.graphed_generator(Bs, cfg=a.cfg, top_k=a.top_k, top_p=a.top_p)
+        g = _timeit(lambda i: run(ls, ts, g_seed=i), 3, 1)
+        out[f'small_batch_b{Bs}'] = {'value': round(Bs / g, 1), 'unit': 'images/s', 'steps': 3, 'ms_per_step': round(g * 1e3, 2),
+                                     'config': f'd{a.depth} autoregressive_infer_cfg B={Bs}, one HIP graph per generation, incl. the decode'}
+        del run
     var._arena = None
     del var
     torch.cuda.empty_cache()

@@ -1437,7 +1437,15 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     if (ov == -1 && sizeof(T) == 2 && p.split_tiles == 0 && batch == 1 && n_ok && p.M >= 2048) {
         const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256), t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
         const double c256 = (double)((t256 + 255) / 256), c128 = 0.61 * (double)((t128 + 511) / 512);
-        if (c128 < 0.97 * c256) return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
+        if (c128 < 0.97 * c256) {
+#if CVAR_TU_PLAIN && !CVAR_TU_CONV
+            // one round of at most 256 workgroups in a transformer pass: three LDS stages (see cvar_gemm: a workgroup of this regime is latency-bound)
+            if constexpr (sizeof(T) == 2) {
+                if (p.tile_cfg == 12 && !p.conv && t128 <= 256 && p.K >= 6 * 64) return launch_cfg<T, 128, 128, 2, 2, 3>(p, batch, st);
+            }
+#endif
+            return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
+        }
     }
     if (ov != 0 && (p.M >= 2048 || (p.split_tiles > 0 && p.M > 1024)) && n_ok) return launch_cfg<T, 256, 256, 2, 4>(p, batch, st);
 #if CVAR_TU_PLAIN && !CVAR_TU_CONV

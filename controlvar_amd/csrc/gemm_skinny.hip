@@ -2,7 +2,7 @@
 //
 // Why a second GEMM kernel.  With M <= 144 rows the LDS-tiled kernels of gemm.hip have one or two row tiles; they fill the chip only by splitting K
 // (128x128 tiles x up to 16 slices) and pay a second launch that sums the slices: 9.5 + 5.2 us per GEMM at M <= 64 and 13-16 + 6.5-8 us at M = 100 ... 256
-// in a B = 1 generation (profiles/r04_small_batch_scales.txt), against 1-4 us of weight streaming.  Here the problem is cut along N instead:
+// in a B = 1 generation (profiles/r04_small_batch.txt), against 1-4 us of weight streaming.  Here the problem is cut along N instead:
 //   * a workgroup owns 16 NT output columns x 16 MT rows over the WHOLE K range: no partial sums leave the workgroup, the epilogue runs in the same launch;
 //   * its 8 waves interleave the 32-deep k-steps (wave w takes steps w, w + 8, ... of a per-workgroup rotation of K), so the workgroup streams 512 contiguous
 //     bytes of every weight row per round and different workgroups read different k-blocks of the shared activations at any moment;

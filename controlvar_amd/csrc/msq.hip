@@ -13,18 +13,20 @@ constexpr int MS_MAP = MS_C * MS_S * MS_S;   // floats per map
 
 // u <- bicubic_up(E[idx]) (or the plain gather when pn == S).  hs / u alias is handled by the caller passing
 // distinct buffers: gather -> bufA ([C][pn][pn]); rows -> tmp ([C][S][pn]); cols -> bufA ([C][S][S]).
+// NTH = threads of the workgroup (256, or 1024 for the generation-side kernel): the loops stride by it, every output keeps its own fma chain.
+template <int NTH = 256>
 __device__ void ms_gather_up(const int* __restrict__ idx, const float* __restrict__ E, const float* __restrict__ up,
                              float* bufA, float* tmp, int pn) {
     const int tid = threadIdx.x;
     const int n = pn * pn;
-    for (int i = tid; i < n * MS_C; i += 256) {
+    for (int i = tid; i < n * MS_C; i += NTH) {
         const int t = i / MS_C, c = i % MS_C;
         bufA[c * n + t] = E[(long)idx[t] * MS_C + c];
     }
     __syncthreads();
     if (pn == MS_S) return;
     // rows: tmp[c][i][x] = sum_j up[i][j] * h[c][j][x]
-    for (int o = tid; o < MS_C * MS_S * pn; o += 256) {
+    for (int o = tid; o < MS_C * MS_S * pn; o += NTH) {
         const int x = o % pn, i = (o / pn) % MS_S, c = o / (pn * MS_S);
         float a = 0.f;
         for (int j = 0; j < pn; ++j) a = fmaf(up[i * pn + j], bufA[c * n + j * pn + x], a);
@@ -32,7 +34,7 @@ __device__ void ms_gather_up(const int* __restrict__ idx, const float* __restric
     }
     __syncthreads();
     // cols: u[c][i][i2] = sum_j up[i2][j] * tmp[c][i][j]
-    for (int o = tid; o < MS_MAP; o += 256) {
+    for (int o = tid; o < MS_MAP; o += NTH) {
         const int i2 = o % MS_S, ci = o / MS_S;          // ci = c*S + i
         float a = 0.f;
         for (int j = 0; j < pn; ++j) a = fmaf(up[i2 * pn + j], tmp[ci * pn + j], a);
@@ -41,50 +43,55 @@ __device__ void ms_gather_up(const int* __restrict__ idx, const float* __restric
     __syncthreads();
 }
 
-// h = 0.5*u + 0.5*(conv3x3(u) + b);  fh += h;  (fr -= h if fr != nullptr).  One thread per pixel.
+// h = 0.5*u + 0.5*(conv3x3(u) + b);  fh += h;  (fr -= h if fr != nullptr).  One thread per pixel and block of 32 / (NTH / 256) output channels
+// (NTH = 256: all 32; NTH = 1024: 8 - the 9 216-fma chain per pixel is the bulk of a generation-side call, 100 us with 256 threads).
+template <int NTH = 256>
 __device__ void ms_phi_accumulate(const float* u, const float* __restrict__ w /*[ci][9][co]*/, const float* __restrict__ bias,
                                   float* fh, float* fr) {
-    const int pix = threadIdx.x;                 // 256 threads == S*S pixels
+    constexpr int NCO = MS_C / (NTH / 256);
+    const int pix = threadIdx.x & 255;           // S*S pixels
+    const int co0 = (threadIdx.x >> 8) * NCO;
     const int y = pix / MS_S, x = pix % MS_S;
-    float acc[MS_C];
+    float acc[NCO];
 #pragma unroll
-    for (int co = 0; co < MS_C; ++co) acc[co] = bias[co];
+    for (int co = 0; co < NCO; ++co) acc[co] = bias[co0 + co];
     for (int ci = 0; ci < MS_C; ++ci) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
             const float v = (yy >= 0 && yy < MS_S && xx >= 0 && xx < MS_S) ? u[ci * 256 + yy * MS_S + xx] : 0.f;
-            const float* wr = w + (ci * 9 + tap) * MS_C;
+            const float* wr = w + (ci * 9 + tap) * MS_C + co0;
 #pragma unroll
-            for (int co = 0; co < MS_C; ++co) acc[co] = fmaf(v, wr[co], acc[co]);
+            for (int co = 0; co < NCO; ++co) acc[co] = fmaf(v, wr[co], acc[co]);
         }
     }
 #pragma unroll
-    for (int co = 0; co < MS_C; ++co) {
-        const float h = u[co * 256 + pix] * 0.5f + acc[co] * 0.5f;
-        fh[co * 256 + pix] += h;
-        if (fr) fr[co * 256 + pix] -= h;
+    for (int co = 0; co < NCO; ++co) {
+        const float h = u[(co0 + co) * 256 + pix] * 0.5f + acc[co] * 0.5f;
+        fh[(co0 + co) * 256 + pix] += h;
+        if (fr) fr[(co0 + co) * 256 + pix] -= h;
     }
     __syncthreads();
 }
 
 // area-pool src ([C][S][S]) to pn x pn; result token-major: dst[t][c].  tmp: [C][pn][S].
+template <int NTH = 256>
 __device__ void ms_area_tokens(const float* src, const float* __restrict__ down /*[pn][S]*/, float* tmp, float* dst, int pn,
                                bool dst_global) {
     const int tid = threadIdx.x;
     if (pn == MS_S) {
-        for (int o = tid; o < MS_MAP; o += 256) { const int c = o % MS_C, t = o / MS_C; dst[o] = src[c * 256 + t]; }
+        for (int o = tid; o < MS_MAP; o += NTH) { const int c = o % MS_C, t = o / MS_C; dst[o] = src[c * 256 + t]; }
         if (!dst_global) __syncthreads();
         return;
     }
-    for (int o = tid; o < MS_C * pn * MS_S; o += 256) {
+    for (int o = tid; o < MS_C * pn * MS_S; o += NTH) {
         const int x = o % MS_S, i = (o / MS_S) % pn, c = o / (MS_S * pn);
         float a = 0.f;
         for (int yy = 0; yy < MS_S; ++yy) a = fmaf(down[i * MS_S + yy], src[c * 256 + yy * MS_S + x], a);
         tmp[o] = a;
     }
     __syncthreads();
-    for (int o = tid; o < pn * pn * MS_C; o += 256) {
+    for (int o = tid; o < pn * pn * MS_C; o += NTH) {
         const int c = o % MS_C, t = o / MS_C;
         const int i = t / pn, j = t % pn;
         float a = 0.f;
@@ -95,11 +102,13 @@ __device__ void ms_area_tokens(const float* src, const float* __restrict__ down 
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ms_next_input_kernel(const int* __restrict__ idx, const float* __restrict__ E,
+constexpr int MS_NI_THREADS = 1024;       // 16 waves: the phi conv of a map is split over 4 blocks of 8 output channels (4 x shorter chain per thread)
+__global__ __launch_bounds__(MS_NI_THREADS) void ms_next_input_kernel(const int* __restrict__ idx, const float* __restrict__ E,
                                                            const float* __restrict__ phi_w, const float* __restrict__ phi_b,
                                                            const float* __restrict__ up, const float* __restrict__ down,
                                                            float* __restrict__ f_hat, float* __restrict__ tok_out,
                                                            int nmaps, int pn, int pn_next) {
+    constexpr int NTH = MS_NI_THREADS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* bufA = lds;                 // [C][S][S]
     float* fh = lds + MS_MAP;
@@ -107,13 +116,13 @@ __global__ __launch_bounds__(256) void ms_next_input_kernel(const int* __restric
     const int map = blockIdx.x % nmaps;
     const long b = blockIdx.x / nmaps;
     float* fg = f_hat + (b * nmaps + map) * (long)MS_MAP;
-    for (int o = threadIdx.x; o < MS_MAP; o += 256) fh[o] = fg[o];
-    ms_gather_up(idx + (b * nmaps + map) * (long)(pn * pn), E, up, bufA, tmp, pn);
-    ms_phi_accumulate(bufA, phi_w, phi_b, fh, nullptr);
-    for (int o = threadIdx.x; o < MS_MAP; o += 256) fg[o] = fh[o];
+    for (int o = threadIdx.x; o < MS_MAP; o += NTH) fh[o] = fg[o];
+    ms_gather_up<NTH>(idx + (b * nmaps + map) * (long)(pn * pn), E, up, bufA, tmp, pn);
+    ms_phi_accumulate<NTH>(bufA, phi_w, phi_b, fh, nullptr);
+    for (int o = threadIdx.x; o < MS_MAP; o += NTH) fg[o] = fh[o];
     if (tok_out) {
         float* dst = tok_out + ((b * nmaps + map) * (long)(pn_next * pn_next)) * MS_C;
-        ms_area_tokens(fh, down, tmp, dst, pn_next, true);
+        ms_area_tokens<NTH>(fh, down, tmp, dst, pn_next, true);
     }
 }
 
@@ -126,7 +135,7 @@ extern "C" int cvar_ms_next_input(const int32_t* idx, const float* codebook, con
     if (tok_out && (pn_next <= 0 || pn_next > S || (pn_next != S && !down_mat))) return CVAR_EINVAL;
     const size_t lds = 3 * MS_MAP * sizeof(float);
     (void)hipFuncSetAttribute((const void*)ms_next_input_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(ms_next_input_kernel, dim3((unsigned)((long)nb * nmaps)), dim3(256), lds, as_stream(stream), idx, codebook, phi_w, phi_b,
+    hipLaunchKernelGGL(ms_next_input_kernel, dim3((unsigned)((long)nb * nmaps)), dim3(MS_NI_THREADS), lds, as_stream(stream), idx, codebook, phi_w, phi_b,
                        up_mat, down_mat, f_hat, tok_out, nmaps, pn, pn_next);
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;

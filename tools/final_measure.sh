@@ -14,7 +14,7 @@ rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write --output-format csv -- $BENCH > $O/pm
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_train --output-format csv -- python $R/bench.py --mode train --steps 3 --warmup 1 > $O/${TAG}_prof_train.log 2>&1
 cd $R
 python tools/pmc_mfma_util.py gpurun_out/pmc_mfma gpurun_out/${TAG}_pmc_mfma_util.json > /dev/null
-python tools/pmc_traffic.py "one d24 B=384 generation x 3 (bench.py --steps 2 --warmup 1), round ${TAG}" > /dev/null
+python tools/pmc_traffic.py "one d24 B=512 generation x 3 (bench.py --steps 2 --warmup 1), round ${TAG}" > /dev/null
 cp gpurun_out/gemm_hbm_traffic.json gpurun_out/${TAG}_gemm_hbm_traffic.json
 for d in ${TAG}_prof ${TAG}_prof_train; do f=$(find gpurun_out/$d -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f gpurun_out/${d}_kernel_stats.csv; done
 f=$(find gpurun_out/${TAG}_prof -name "*agent_info.csv" | head -1); [ -n "$f" ] && cp $f gpurun_out/${TAG}_agent_info.csv

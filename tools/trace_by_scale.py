@@ -62,8 +62,8 @@ def main():
         print('decode launches (family, workgroups x threads, us):')
         for r in g:
             if n >= 10:
-                wg = int(r['Workgroup_Size']) if r.get('Workgroup_Size') else 0
-                gs = int(r['Grid_Size']) if r.get('Grid_Size') else 0
+                wg = int(r.get('Workgroup_Size_X') or 0) * max(int(r.get('Workgroup_Size_Y') or 1), 1) * max(int(r.get('Workgroup_Size_Z') or 1), 1)
+                gs = int(r.get('Grid_Size_X') or 0) * max(int(r.get('Grid_Size_Y') or 1), 1) * max(int(r.get('Grid_Size_Z') or 1), 1)
                 print('  %-10s %6d x %4d  %8.1f  %s' % (fam(r['Kernel_Name']), gs // max(wg, 1), wg, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3, r['Kernel_Name'][:60]))
             if 'cfg_sample' in r['Kernel_Name']:
                 n += 1
