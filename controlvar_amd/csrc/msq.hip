@@ -152,27 +152,33 @@ struct MsEncodeParams {
     int Ltot;
 };
 
-__global__ __launch_bounds__(256) void ms_encode_kernel(const MsEncodeParams p) {
+// NTH = 256: one wave per SIMD (the pyramid fills the LDS), both search forms.  NTH = 512 (round 4): 8 waves - the lane-owns-a-code search with two waves
+// per SIMD to hide its loads (1024 threads would cap the kernel at 128 registers: 1.2 KB of scratch per lane), the phi conv split over two blocks of output channels; fast search form only (cvar_ms_encode picks the instance).  Every
+// distance / conv output is the same fma chain in both, and the merges keep the first minimum: identical ids.
+template <int NTH>
+__global__ __launch_bounds__(NTH) void ms_encode_kernel(const MsEncodeParams p) {
+    constexpr int NW = NTH / 64;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* bufA = lds;
     float* fh = lds + MS_MAP;
     float* tmp = lds + 2 * MS_MAP;
     float* fr = lds + 3 * MS_MAP;
-    __shared__ float red_d[256], red_d2[256];
-    __shared__ int red_i[256];
+    __shared__ float red_d[NTH == 256 ? 256 : 1], red_d2[NTH == 256 ? 256 : 1];
+    __shared__ int red_i[NTH == 256 ? 256 : 1];
     __shared__ int sidx[256];
-    __shared__ float wave_bd[4][256];
-    __shared__ int wave_bi[4][256];
     __shared__ float zzs[256];
+    // per-wave best (distance, index) of a token: [NW][256] each, parked in `tmp` - free between the area pooling and the gather (NW <= 16: 32 KB = one map)
+    float (*wave_bd)[256] = (float (*)[256])tmp;
+    int (*wave_bi)[256] = (int (*)[256])(tmp + NW * 256);
     const int tid = threadIdx.x;
     const long b = blockIdx.x;
-    for (int o = tid; o < MS_MAP; o += 256) { fr[o] = p.f[b * MS_MAP + o]; fh[o] = 0.f; }
+    for (int o = tid; o < MS_MAP; o += NTH) { fr[o] = p.f[b * MS_MAP + o]; fh[o] = 0.f; }
     __syncthreads();
     for (int si = 0; si < p.nscale; ++si) {
         const int pn = p.pn[si], n = pn * pn;
         // z[t][c] = area(f_rest) -> bufA (token-major)
-        ms_area_tokens(fr, p.down + p.down_off[si], tmp, bufA, pn, false);
-        if (!p.margin_out && (p.V & 255) == 0) {
+        ms_area_tokens<NTH>(fr, p.down + p.down_off[si], tmp, bufA, pn, false);
+        if (NTH != 256 || (!p.margin_out && (p.V & 255) == 0)) {
             // ---- nearest code, fast form (no margin requested).  The pyramid fills the LDS, so a workgroup is one wave per SIMD
             // and nothing hides a load: the token-per-thread search below walks the 512 KB codebook row by row at ~1000 cycles a
             // code (86 % of the kernel).  Here a LANE owns a code: wave w searches codes [w V/4, (w+1) V/4) in groups of 64 (one
@@ -188,8 +194,8 @@ __global__ __launch_bounds__(256) void ms_encode_kernel(const MsEncodeParams p) 
                 zzs[tid] = zz;
             }
             __syncthreads();
-            const int per_wave = p.V / 4, groups = per_wave / 64;
-            constexpr int TB = 8;
+            const int per_wave = p.V / NW, groups = per_wave / 64;
+            constexpr int TB = NTH == 256 ? 8 : 4;           // tokens per pass over a wave's codes (512 threads: half the register budget per lane)
             for (int t0 = 0; t0 < n; t0 += TB) {
                 float bd8[TB]; int bi8[TB];
 #pragma unroll
@@ -246,13 +252,13 @@ __global__ __launch_bounds__(256) void ms_encode_kernel(const MsEncodeParams p) 
             if (tid < n) {
                 float bd = wave_bd[0][tid]; int bi = wave_bi[0][tid];
 #pragma unroll
-                for (int q = 1; q < 4; ++q)                                      // waves hold increasing code ranges: strict '<'
+                for (int q = 1; q < NW; ++q)                                     // waves hold increasing code ranges: strict '<'
                     if (wave_bd[q][tid] < bd) { bd = wave_bd[q][tid]; bi = wave_bi[q][tid]; }
                 sidx[tid] = bi;
                 p.idx_out[b * p.Ltot + p.idx_off[si] + tid] = bi;
             }
             __syncthreads();
-        } else {
+        } else if constexpr (NTH == 256) {
         // nearest code: thread = (token, part)
         const int P = n >= 256 ? 1 : 256 / n;
         const int t = tid / P, part = tid % P;
@@ -296,12 +302,12 @@ __global__ __launch_bounds__(256) void ms_encode_kernel(const MsEncodeParams p) 
         __syncthreads();
         }
         // stages with more than 256 tokens do not occur (S*S == 256)
-        ms_gather_up(sidx, p.E, p.up + p.up_off[si], bufA, tmp, pn);
+        ms_gather_up<NTH>(sidx, p.E, p.up + p.up_off[si], bufA, tmp, pn);
         const int k = p.phi_map[si];
-        ms_phi_accumulate(bufA, p.phi_w + (long)k * MS_C * 9 * MS_C, p.phi_b + k * MS_C, fh, fr);
+        ms_phi_accumulate<NTH>(bufA, p.phi_w + (long)k * MS_C * 9 * MS_C, p.phi_b + k * MS_C, fh, fr);
     }
     if (p.f_hat_out)
-        for (int o = tid; o < MS_MAP; o += 256) p.f_hat_out[b * MS_MAP + o] = fh[o];
+        for (int o = tid; o < MS_MAP; o += NTH) p.f_hat_out[b * MS_MAP + o] = fh[o];
 }
 
 extern "C" int cvar_ms_encode(const float* f, const float* codebook, int V, const float* phi_w, const float* phi_b,
@@ -324,8 +330,10 @@ extern "C" int cvar_ms_encode(const float* f, const float* codebook, int V, cons
     }
     p.Ltot = io;
     const size_t lds = 4 * MS_MAP * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)ms_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(ms_encode_kernel, dim3(B), dim3(256), lds, as_stream(stream), p);
+    // (round 4, measured and not used: the <512> instance - 8 waves, token blocks of 4 to fit 256 registers - runs 3.27 ms per call against 2.67 ms: the
+    //  halved token block doubles the passes over the codebook, and that costs more than the second wave per SIMD hides.)
+    (void)hipFuncSetAttribute((const void*)ms_encode_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ms_encode_kernel<256>, dim3(B), dim3(256), lds, as_stream(stream), p);
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;
 }
