@@ -780,7 +780,7 @@ class ControlVAR(nn.Module):
         # Small passes (early scales, small batches): proj / fc2 also produce the adaLN input of the op that follows (cvar_gemm_desc.ln_out) - their split-K
         # reduction finishes rows, so LayerNorm + modulation ride in that launch instead of a cvar_ln_modulate of their own (same bits).  Large passes keep the
         # separate launch: their GEMMs finish tiles, not rows.
-        fuse_ln = M <= 1024
+        fuse_ln = M < 2048            # calls up to here can be sliced along K (small-M split-K, or the long-K rule of 256x256 tiles for 1024 < M < 2048)
         ah = cfg.depth * 6 * C
         ops.ln_modulate(x, ada, 2 * C, 4 * C, n_ada, l, u, M, C, cfg.norm_eps)
         for i in range(cfg.depth):

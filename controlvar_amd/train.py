@@ -674,9 +674,9 @@ class Trainer:
     def tokenize(self, images: torch.Tensor, masks: torch.Tensor, mask_first: bool = True):
         """frozen tokenizer + 'interleave_append' (mask first unless bidirectional drew image first): train_control_var_hpu.py:157-204"""
         # one tokenizer pass over [masks ; images] (the reference makes two calls, :160-176): the ten-scale residual quantiser is one latency-bound
-        # launch of ~2.7 ms whatever the batch, and the conv stack sees twice the tiles.  Every image is quantised on its own, so in fp32 mode the ids
-        # equal the two-call form's exactly; in bf16 mode a GEMM may pick another tile / split-K partition for 2B rows, which can move an id at a
-        # near-tie (measured, not assumed: tests/test_gpu_train.py::test_tokenize_one_pass_equals_the_two_call_form)
+        # launch of ~2.7 ms whatever the batch, and the conv stack sees twice the tiles.  Every image is encoded and quantised on its own and no kernel of the
+        # tokenizer sums in a batch-dependent order, so the ids equal the two-call form's exactly in both precision modes
+        # (tests/test_gpu_train.py::test_tokenize_one_pass_equals_the_two_call_form)
         B = masks.shape[0]
         both = self.vae.img_to_idxBl(torch.cat((masks, images), dim=0))
         hboth = self.vae.idxBl_to_h(both)
