@@ -13,6 +13,15 @@
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// timing ablations (tools/build_variant.py conv_halo.hip <tag> -DCH_ABL=n; WRONG results, A/B timing only): 1 no weight DMA inside the loop, 2 no halo DMA
+// inside the loop, 3 both, 4 no epilogue traffic, 5 half the MFMAs (row block 0 only), 6 no per-step barrier
+#ifndef CH_ABL
+#define CH_ABL 0
+#endif
+#ifndef CH_EPI_LDS
+#define CH_EPI_LDS 1
+#endif
+
 struct ConvHaloParams {
     const bf16_t* X; const bf16_t* Wt; const float* bias; const bf16_t* res; void* out;
     int B, H, W, Cin, Cout, tiles_x, tiles_y, nchunk;
@@ -47,6 +56,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
     const int b = t_ / p.tiles_y;
     const int ty0 = ty * 16, tx0 = tx * 16;
     const int cout0 = blockIdx.y * (32 * CH_NB);
+#ifdef CH_STAGGER
+    // experiment: the second workgroup of every CU (blocks 256 .. 511 of the launch, as dispatch goes) starts CH_STAGGER shader cycles late, so that the two
+    // co-resident workgroups do not reach their epilogues together
+    if (blockIdx.y == 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < (unsigned long long)CH_STAGGER) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     const bf16_t* ximg = p.X + (long)b * p.Hin * p.Win * p.Cin;
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ximg, 0, p.Hin * p.Win * p.Cin * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Wt + (long)cout0 * 9 * p.Cin), 0, min(32 * CH_NB, p.Cout - cout0) * 9 * p.Cin * 2, 0x00020000);
@@ -143,10 +160,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             int issued = 0;
-            if (t < 6 && c + 1 < p.nchunk) issued += issue_halo(c + 1, t);
+            if (CH_ABL != 2 && CH_ABL != 3 && t < 6 && c + 1 < p.nchunk) issued += issue_halo(c + 1, t);
             {
                 const int c2 = t + 2 >= 9 ? c + 1 : c, t2 = t + 2 >= 9 ? t + 2 - 9 : t + 2;
-                if (c2 < p.nchunk) issued += issue_w(c2, t2);
+                if (CH_ABL != 1 && CH_ABL != 3 && c2 < p.nchunk) issued += issue_w(c2, t2);
             }
             const char* wb = smem + 2 * CH_HALO_BYTES + (t % 3) * CH_W_BYTES + b_lane;
             bf16x8_t w[2][CH_NB];
@@ -162,9 +179,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
 #pragma unroll
                 for (int j = 0; j < CH_NB; ++j)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][j], af[t & 1][i][ks], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < (CH_ABL == 5 ? 1 : 2); ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][j], af[t & 1][i][ks], acc[i][j], 0, 0, 0);
             wait_vm(issued);
-            __builtin_amdgcn_s_barrier();
+            if (CH_ABL != 6) __builtin_amdgcn_s_barrier();
         }
         // nine taps per chunk: the prefetched set is 1 after tap 8 - move it to set 0 so that every chunk starts alike
 #pragma unroll
@@ -177,6 +194,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
     // All residual loads of a row block are issued before its first store: vmcnt retires in order and counts stores, so a load queued
     // behind stores would wait for their latency as well (+13 % on the residual convs).  The bias comes straight from global memory (L2
     // hits): a second static LDS array for it cost 6 % on every shape.
+    if (CH_ABL == 4 && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int yy = 4 * wave + 2 * i + (lrow >> 4), xx = lrow & 15;
@@ -195,6 +213,55 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
                         else op[co] = f32_to_bf16(v);
                     }
                 }
+        } else if constexpr (CH_EPI_LDS != 0 && CH_NB == 5) {
+            // Row-major epilogue through LDS (round 4).  In the accumulator layout a store instruction writes 16 B to each of 32 pixels (32 cache lines, 2 560
+            // partial-line requests per wave and tile) and a residual load reads the same way; that burst also sits in front of the co-resident workgroup's
+            // DMA stream, which is why the epilogue (19 % of the 160->160 conv at 256^2, 28 % with the residual: tools ablation, profiles/r04_conv_ablation.txt)
+            // did not hide behind the partner's MFMAs.  Here the wave's 32 pixels x 160 couts of this row block pass through its own slice of the (now free)
+            // pipeline LDS as [pixel][cout] rows of 336 B: residual in by 16-byte row-contiguous loads, summed in the accumulator layout in fp32 exactly as
+            // before (acc + bias + residual, one rounding), out by 16-byte row-contiguous stores - 160 full-line requests per wave and tile.
+            constexpr int PS = 336;
+            char* stg = smem + wave * 19200;
+            const float* bp = p.bias ? p.bias + cout0 + 4 * hi : nullptr;
+            // chunk q = 64 k + lane of the row block: pixel q / 20, 16-byte part q % 20; offsets relative to the image (32-bit)
+            const long img = (long)b * p.H * p.W * p.Cout;
+            auto chunk = [&](int k, int& go, int& lo) {
+                const int q = k * 64 + lane, pq = q / 20, part = q - pq * 20;
+                go = ((ty0 + 4 * wave + 2 * i + (pq >> 4)) * p.W + tx0 + (pq & 15)) * p.Cout + cout0 + part * 8;
+                lo = pq * PS + part * 16;
+            };
+            if (p.res) {
+                const bf16_t* rimg = p.res + img;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    bf16x8_t rr[5];
+                    int lo[5];
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) { int go; chunk(5 * h + k, go, lo[k]); rr[k] = *(const bf16x8_t*)(rimg + go); }
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) *(bf16x8_t*)(stg + lo[k]) = rr[k];
+                }
+            }
+            char* mine = stg + lrow * PS + 8 * hi;
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = 32 * j + 8 * g;
+                    f32x4_t bq = {0.f, 0.f, 0.f, 0.f};
+                    if (bp) bq = *(const f32x4_t*)(bp + co);
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bq[e];
+                    if (p.res) {
+                        const bf16x4_t rq = *(const bf16x4_t*)(mine + co * 2);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += bf16_to_f32((bf16_t)rq[e]);
+                    }
+                    *(bf16x4_t*)(mine + co * 2) = pack_bf16x4(v);
+                }
+#pragma unroll
+            for (int k = 0; k < 10; ++k) { int go, lo; chunk(k, go, lo); *(bf16x8_t*)((bf16_t*)p.out + img + go) = *(const bf16x8_t*)(stg + lo); }
         } else {
             bf16_t* op = (bf16_t*)p.out + gpix * p.Cout + cout0 + 4 * hi;
             const bf16_t* rp = p.res ? p.res + gpix * p.Cout + cout0 + 4 * hi : nullptr;

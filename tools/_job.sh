@@ -1,5 +1,10 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O
 cd $R
-timeout 900 python tools/parity_report.py --run > $O/s5_parity.log 2>&1; tail -3 $O/s5_parity.log | cut -c1-400
-(timeout 900 python tools/fuzz_gemm.py 1200 41 2>&1 | tail -3; timeout 400 python tools/fuzz_attn.py 300 42 2>&1 | tail -2) > $O/r04_fuzz_final.txt 2>&1; cat $O/r04_fuzz_final.txt
-SMALLM=1 LAT_B=1,8 timeout 300 python tools/latency_bench.py 2>/dev/null
+timeout 600 python -m pytest tests/test_gpu_kernels.py -q -x -k "conv or halo or sweep_inside" 2>&1 | tail -3
+for v in epiold base epiold base; do
+  echo "=== $v"
+  if [ $v = base ]; then L=$R/controlvar_amd/libcvar_hip.so; else L=$R/ab/libcvar_$v.so; fi
+  CVAR_LIB=$L timeout 200 python tools/conv_halo_ab.py 5 2>&1 | grep "res=" | sed 's/| implicit.*//'
+done > $O/s5_conv_epi.txt 2>&1
+cat $O/s5_conv_epi.txt
+for v in epiold base; do if [ $v = base ]; then L=$R/controlvar_amd/libcvar_hip.so; else L=$R/ab/libcvar_$v.so; fi; echo "== vae_bench $v"; CVAR_LIB=$L timeout 200 python tools/vae_bench.py 2>&1 | tail -1; done
