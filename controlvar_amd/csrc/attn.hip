@@ -158,6 +158,17 @@ template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_wa
 #ifndef CVAR_ATTN_PIPE
 #define CVAR_ATTN_PIPE 0
 #endif
+// timing ablations of attn_mfma_bf16_kernel (tools/build_variant.py attn.hip ablN -DATTN_ABL=N; WRONG results): 1 no v_exp, 2 no row sum, 3 no row maximum after the
+// first tile, 4 no K/V tile traffic after the first tile, 5 no barriers, 6 a quarter of the PV MFMAs
+#ifndef ATTN_ABL
+#define ATTN_ABL 0
+#endif
+// CVAR_ATTN_DMA = 1: K / V tiles by buffer_load ... lds into two tile pairs, one barrier per tile - built, correct (35 tests, fuzz 400 / 400), exactly NEUTRAL
+// (profiles/r04_attn_ablation.txt): what the ablation attributed to the tile traffic is the bytes a CU pulls (~13 B/clk/CU at the last scale), not the
+// register round trip.  Compiled out by default.
+#ifndef CVAR_ATTN_DMA
+#define CVAR_ATTN_DMA 0
+#endif
 #if CVAR_ATTN_PIPE
 template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma_bf16_pipe_kernel(const AttnParams p);
 #endif
@@ -474,7 +485,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     constexpr int D = 64, KT = 64;
     // one K and one V tile, two barriers per tile.  (Two buffers and one barrier per tile: 7 % SLOWER - profiles/r03_attn_ab3_lds_double_buffer_rejected.txt.)
     constexpr int TILE_B = KT * 128;
-    __shared__ __attribute__((aligned(16))) char KVs[2 * TILE_B];
+    // DMA form (round 4, CVAR_ATTN_DMA): K and V tiles go global -> LDS by buffer_load ... lds (no register round trip, no ds_write, nothing to wait for at the head of
+    // a tile) into TWO tile pairs; the pieces of tile t + 1 are issued at the head of tile t and one barrier per tile - behind vmcnt(0) - both publishes them and
+    // releases the pair tile t was read from.  The ablation that removed the tile traffic (profiles/r04_attn_ablation.txt) took 23 % off the last scale, 39 % at l = 128.
+    constexpr bool DMA = CVAR_ATTN_DMA != 0;
+    __shared__ __attribute__((aligned(1024))) char KVs[(DMA ? 4 : 2) * TILE_B];
     char* const Ks = KVs;
     char* const Vs = KVs + TILE_B;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -536,6 +551,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             *(bf16x8_t*)(Vs + key * 128 + ((((k_chunk >> 1) ^ (key & 3)) << 5) | ((k_chunk & 1) << 4))) = vreg[i];
         }
     };
+    // DMA pieces of a tile: 8 of K + 8 of V (1 KiB = 8 keys each), two of each per wave.  The LDS image is lane-linear (lane -> key 8 j + (lane >> 3), physical chunk
+    // lane & 7), so the swizzles of store_tile are applied on the SOURCE side: the lane fetches the logical chunk that belongs in its physical slot.
+    int dk_off[2], dv_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int key = 8 * (2 * w + i) + (lane >> 3), cp = lane & 7;
+        dk_off[i] = key * row_bytes + ((cp ^ ((key >> 1) & 7)) << 4);
+        dv_off[i] = key * row_bytes + ((((((cp >> 1) ^ (key & 3)) << 1) | (cp & 1))) << 4);
+    }
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto dma_tile = [&](int kt0, int pb) {
+        const int so = kt0 * row_bytes;
+        char* const kb_ = KVs + pb * 2 * TILE_B;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lptr_t)(kb_ + (2 * w + i) * 1024), 16, dk_off[i], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lptr_t)(kb_ + TILE_B + (2 * w + i) * 1024), 16, dv_off[i], so, 0, 0);
+        }
+    };
     // transpose-read addressing of V: lane l of a 16-lane group points at key row (l & 15) >> 2 of a [4 keys][16 d] block, d columns
     // 4 (l & 3) .. +3; the two groups of a half-wave are the two 16-d halves of a 32-d MFMA block, the upper half-wave takes the keys
     // 4 further (the key order of an 8-key fragment is 4 hi + {0..3}, 8 + 4 hi + {0..3} - the order the swapped QK^T leaves P in)
@@ -561,9 +595,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // inference, all but the level-boundary ones under the training mask) run without any per-score compare / select - left
     // as a run-time flag the compiler if-converts the masking into ~100 extra vector instructions on every tile.
     auto tile = [&](int kt0, auto MASK, auto FIRST) {
-        store_tile();
-        __syncthreads();
-        if (kt0 + KT < kv_end) load_tile(kt0 + KT);
+        const int boff = DMA ? ((kt0 / KT) & 1) * 2 * TILE_B : 0;
+        if constexpr (DMA) {
+            if (ATTN_ABL != 4 && kt0 + KT < kv_end) dma_tile(kt0 + KT, ((kt0 / KT) & 1) ^ 1);
+        } else {
+            if (ATTN_ABL != 4 || kt0 == 0) store_tile();
+            if (ATTN_ABL != 5) __syncthreads();
+            if (ATTN_ABL != 4 && kt0 + KT < kv_end) load_tile(kt0 + KT);
+        }
         if (active) {
         // ---- S^T = K Q^T (+ the bias k-step: - m~), invisible keys -> -inf
         f32x16_t s[2];
@@ -575,7 +614,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 if constexpr (QPRE && !decltype(FIRST)::value) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_ones, q_m, s[kb], 0, 0, 0);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8_t kf = *(const bf16x8_t*)(Ks + (32 * kb + lrow) * 128 + (((2 * ks + hi) ^ sw) << 4));
+                    const bf16x8_t kf = *(const bf16x8_t*)(Ks + boff + (32 * kb + lrow) * 128 + (((2 * ks + hi) ^ sw) << 4));
                     s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
                 }
             }
@@ -628,7 +667,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             // tile's row sum, a wave-uniform test of the sum sends the rare tile through a careful second pass.  16 v_max3 fewer per tile,
             // but the second copy of the tile body costs registers (spills around the loops) and the short scales lose 20-30 %.)
             if (decltype(FIRST)::value) shift(true);
-            else if (__any(row_max() > 2.0f + fabsf(m) * 0.015625f)) shift(false);
+            else if (ATTN_ABL != 3 && __any(row_max() > 2.0f + fabsf(m) * 0.015625f)) shift(false);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -636,8 +675,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     float pr[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        pr[j] = __builtin_amdgcn_exp2f(s[kb][8 * t + j]);
-                        lsum += pr[j];
+                        pr[j] = ATTN_ABL == 1 ? s[kb][8 * t + j] : __builtin_amdgcn_exp2f(s[kb][8 * t + j]);
+                        if (ATTN_ABL != 2) lsum += pr[j];
                     }
                     pf[kb][t] = pack_bf16x8(pr);
                 }
@@ -674,18 +713,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const char* vp = v_lane[db] + (32 * kb + 16 * t) * 128;
+                    const char* vp = v_lane[db] + boff + (32 * kb + 16 * t) * 128;
                     const s16x4_t v0 = lds_tr16_b64(vp);
                     const s16x4_t v1 = lds_tr16_b64(vp + 8 * 128);
                     const bf16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][t], o[db], 0, 0, 0);
+                    if (ATTN_ABL != 6 || (kb == 0 && t == 0)) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][t], o[db], 0, 0, 0);
                 }
         }
-        __syncthreads();
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ATTN_ABL != 5) __syncthreads();
     };
     typedef std::integral_constant<bool, true> Yes;
     typedef std::integral_constant<bool, false> No;
-    load_tile(0);
+    if constexpr (DMA) {
+        dma_tile(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
+        load_tile(0);
+    }
     int kt0 = 0;
     // wave_min_kv is wave-uniform per construction but tiles are shared by the workgroup (barriers inside): the split point
     // must be the same for all four waves, so it is taken over the workgroup's first query
