@@ -153,6 +153,10 @@ __global__ __launch_bounds__(256) void attn_rowwise_kernel(const AttnParams p) {
 // (a template takes its launch bounds from the FIRST declaration: without them here the kernels are compiled for 1024-thread groups, 128 VGPRs)
 template <bool HOLES, bool QPRE> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_mfma_bf16_kernel(const AttnParams p);
 template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_mfma_bf16_v1_kernel(const AttnParams p);
+template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma_bf16_q64_kernel(const AttnParams p);
+#ifndef CVAR_ATTN_Q64
+#define CVAR_ATTN_Q64 1
+#endif
 // round 4: wave-internally pipelined form of the prescaled kernel - built, correct (35 tests, fuzz 600 / 600), 16 % SLOWER at the last scale
 // (profiles/r04_attn_pipe_rejected.txt); compiled only with -DCVAR_ATTN_PIPE=1
 #ifndef CVAR_ATTN_PIPE
@@ -231,6 +235,16 @@ static int cvar_attention_impl(const void* qkv, const void* q, int dtype, int R,
             return CVAR_OK;
         }
 #endif
+        // prescaled queries, long scales: 64 queries per wave (K / V fragments, tiles and barriers shared by two query groups)
+        // (only where the last 256-query workgroup is nearly full: l = 512 runs 1.371 -> 1.285 ms per call at B = 128, l = 338 - 82 queries in its second workgroup -
+        //  0.685 -> 0.82 ms and stays on the 128-query kernel; profiles/r04_attn_ablation.txt)
+        if (CVAR_ATTN_Q64 && qpre && l >= 256 && cdiv(l, 256) * 256 - l < 64) {
+            const dim3 grid64((unsigned)((long)cdiv(l, 256) * H * R));
+            if (holes) hipLaunchKernelGGL((attn_mfma_bf16_q64_kernel<true>), grid64, block, 0, as_stream(stream), p);
+            else hipLaunchKernelGGL((attn_mfma_bf16_q64_kernel<false>), grid64, block, 0, as_stream(stream), p);
+            CVAR_CHECK_LAUNCH();
+            return CVAR_OK;
+        }
         if (holes) { if (qpre) hipLaunchKernelGGL((attn_mfma_bf16_kernel<true, true>), grid, block, 0, as_stream(stream), p);
                      else hipLaunchKernelGGL((attn_mfma_bf16_kernel<true, false>), grid, block, 0, as_stream(stream), p); }
         else { if (qpre) hipLaunchKernelGGL((attn_mfma_bf16_kernel<false, true>), grid, block, 0, as_stream(stream), p);
@@ -756,6 +770,221 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 for (int e = 0; e < 4; ++e) ov[e] = o[db][4 * g + e] * inv;
                 *(bf16x4_t*)(op + 32 * db + 8 * g + 4 * hi) = pack_bf16x4(ov);
             }
+    }
+}
+
+
+// ================================================================================================
+// attn_mfma_bf16_q64_kernel (round 4, second half; inference form with prescaled queries, scales of >= 256 queries): the QPRE kernel above with TWO 32-query
+// groups per wave - a workgroup owns 256 queries of one (row, head).  Every K fragment read out of LDS, every transposed V fragment, every K / V tile a CU
+// pulls and every barrier now serve 64 queries of the wave instead of 32: the ablation table (profiles/r04_attn_ablation.txt) puts the tile traffic at 23 %
+// and the kernel at ~13 B per clock and CU.  Costs ~100 registers: two waves per SIMD instead of three.  Same arithmetic per query as the kernel above
+// (same tile order, same shift rule per 32-query group): bit-identical output.
+// ================================================================================================
+template <bool HOLES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma_bf16_q64_kernel(const AttnParams p) {
+    constexpr int D = 64, KT = 64, G = 2;
+    constexpr int TILE_B = KT * 128;
+    __shared__ __attribute__((aligned(16))) char KVs[2 * TILE_B];
+    char* const Ks = KVs;
+    char* const Vs = KVs + TILE_B;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lrow = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
+    const int nqb = (p.l + 255) >> 8, pairs = p.R * p.H;
+    int qb, pair;
+    {
+        const int id = blockIdx.x;
+        if ((pairs & 7) == 0) { const int xcd = id & 7, local = id >> 3; qb = local % nqb; pair = (local / nqb) * 8 + xcd; }
+        else { qb = id % nqb; pair = id / nqb; }
+    }
+    const int h = pair % p.H;
+    const long r = pair / p.H;
+    const int C3 = p.ldkv;
+    const bf16_t* base = (const bf16_t*)p.qkv + r * (long)p.Lmax * C3;
+    const bf16_t* kbase = base + p.k_col + h * D;
+    const bf16_t* vbase = base + p.v_col + h * D;
+
+    const int q0 = qb * 256 + w * 64;
+    const bool active = q0 < p.l;
+    int qi[G];
+    Vis vis[G];
+    bf16x8_t qf[G][4];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        qi[g] = q0 + 32 * g + lrow;
+        const int qrow = min(qi[g], p.l - 1);
+        vis[g] = vis_of(p, p.q_off + qrow);
+        const bf16_t* qp = (const bf16_t*)p.q + (r * p.q_rows + (p.q_off + qrow - p.q_pos0)) * (long)p.ldq + h * D;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[g][ks] = *(const bf16x8_t*)(qp + (2 * ks + hi) * 8);
+    }
+    const int kv_end = kv_len_of(p, p.q_off + min(p.l, (qb + 1) * 256) - 1);
+
+    const int k_key = tid >> 3, k_chunk = tid & 7;
+    bf16x8_t kreg[2], vreg[2];
+    const int row_bytes = C3 * 2;
+    const int rec = (kv_end - 1) * row_bytes + 128;
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, rec, 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, rec, 0x00020000);
+    int ld_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ld_off[i] = (k_key + 32 * i) * row_bytes + k_chunk * 16;
+    typedef int v4i_t __attribute__((ext_vector_type(4)));
+    auto load_tile = [&](int kt0) {
+        const int so = kt0 * row_bytes;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            kreg[i] = __builtin_bit_cast(bf16x8_t, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(k_rsrc, ld_off[i], so, 0));
+            vreg[i] = __builtin_bit_cast(bf16x8_t, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(v_rsrc, ld_off[i], so, 0));
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = k_key + 32 * i;
+            *(bf16x8_t*)(Ks + key * 128 + ((k_chunk ^ ((key >> 1) & 7)) << 4)) = kreg[i];
+            *(bf16x8_t*)(Vs + key * 128 + ((((k_chunk >> 1) ^ (key & 3)) << 5) | ((k_chunk & 1) << 4))) = vreg[i];
+        }
+    };
+    const int v_jrow = (lane & 15) >> 2, v_g = (lane >> 4) & 1;
+    const char* v_lane[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) v_lane[db] = Vs + (4 * hi + v_jrow) * 128 + (((2 * db + v_g) ^ v_jrow) << 5) + (lane & 3) * 8;
+
+    f32x16_t o[G][2];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[g][db][i] = 0.f;
+    float m[G] = {0.f, 0.f}, lsum[G] = {0.f, 0.f};
+    const short one_bf = hi == 0 ? (short)0x3f80 : (short)0;
+    const bf16x8_t k_ones = {one_bf, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8_t q_m[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) q_m[g] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+
+    auto tile = [&](int kt0, auto MASK, auto FIRST) {
+        store_tile();
+        __syncthreads();
+        if (kt0 + KT < kv_end) load_tile(kt0 + KT);
+        if (active) {
+        f32x16_t s[G][2];
+        // ---- S^T = K Q^T for both query groups off ONE K fragment
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[g][kb][i] = 0.f;
+                if constexpr (!decltype(FIRST)::value) s[g][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_ones, q_m[g], s[g][kb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8_t kf = *(const bf16x8_t*)(Ks + (32 * kb + lrow) * 128 + (((2 * ks + hi) ^ sw) << 4));
+#pragma unroll
+                for (int g = 0; g < G; ++g) s[g][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[g][ks], s[g][kb], 0, 0, 0);
+            }
+        }
+        bf16x8_t pf[G][2][2];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if constexpr (decltype(MASK)::value) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = kt0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hi;
+                        if (!vis_key_t<HOLES>(vis[g], key)) s[g][kb][i] = -INFINITY;
+                    }
+            }
+            auto row_max = [&]() {
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, s[g][kb][i]);
+                return fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            };
+            auto shift = [&](bool always) {
+                const float tmax = row_max();
+                const bool need = always || tmax > 2.0f + fabsf(m[g]) * 0.015625f;
+                const float m_new = need ? bf16_to_f32(f32_to_bf16(m[g] + tmax)) : m[g];
+                const float delta = m_new - m[g];
+                if (!always) {
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+                    lsum[g] *= alpha;
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) o[g][db][i] *= alpha;
+                }
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) s[g][kb][i] -= delta;
+                m[g] = m_new;
+                q_m[g][0] = hi == 0 ? (short)f32_to_bf16(-m_new) : (short)0;
+            };
+            if (decltype(FIRST)::value) shift(true);
+            else if (__any(row_max() > 2.0f + fabsf(m[g]) * 0.015625f)) shift(false);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float pr[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        pr[j] = __builtin_amdgcn_exp2f(s[g][kb][8 * t + j]);
+                        lsum[g] += pr[j];
+                    }
+                    pf[g][kb][t] = pack_bf16x8(pr);
+                }
+        }
+        // ---- O^T += V^T P^T for both groups off ONE transposed V fragment
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const char* vp = v_lane[db] + (32 * kb + 16 * t) * 128;
+                    const s16x4_t v0 = lds_tr16_b64(vp);
+                    const s16x4_t v1 = lds_tr16_b64(vp + 8 * 128);
+                    const bf16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+                    for (int g = 0; g < G; ++g) o[g][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[g][kb][t], o[g][db], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    };
+    typedef std::integral_constant<bool, true> Yes;
+    typedef std::integral_constant<bool, false> No;
+    load_tile(0);
+    int kt0 = 0;
+    const int wg_min_kv = range_full_prefix(p, p.q_off + min(qb * 256, p.l - 1), p.q_off + min(p.l, (qb + 1) * 256) - 1);
+    if (KT <= wg_min_kv) tile(0, No{}, Yes{}); else tile(0, Yes{}, Yes{});
+    kt0 = KT;
+    for (; kt0 + KT <= wg_min_kv && kt0 < kv_end; kt0 += KT) tile(kt0, No{}, No{});
+    for (; kt0 < kv_end; kt0 += KT) tile(kt0, Yes{}, No{});
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const float ls = lsum[g] + __shfl_xor(lsum[g], 32, 64);
+        if (qi[g] < p.l) {
+            if (p.lse && hi == 0) p.lse[(r * p.H + h) * (long)p.l + qi[g]] = (m[g] + log2f(ls)) * 0.6931471805599453f;
+            const float inv = 1.0f / ls;
+            bf16_t* op = (bf16_t*)p.out + (r * p.l + qi[g]) * (long)(p.H * D) + h * D;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    float ov[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[e] = o[g][db][4 * gg + e] * inv;
+                    *(bf16x4_t*)(op + 32 * db + 8 * gg + 4 * hi) = pack_bf16x4(ov);
+                }
+        }
     }
 }
 
