@@ -238,7 +238,8 @@ static int cvar_attention_impl(const void* qkv, const void* q, int dtype, int R,
         // prescaled queries, long scales: 64 queries per wave (K / V fragments, tiles and barriers shared by two query groups)
         // (only where the last 256-query workgroup is nearly full: l = 512 runs 1.371 -> 1.285 ms per call at B = 128, l = 338 - 82 queries in its second workgroup -
         //  0.685 -> 0.82 ms and stays on the 128-query kernel; profiles/r04_attn_ablation.txt)
-        if (CVAR_ATTN_Q64 && qpre && l >= 256 && cdiv(l, 256) * 256 - l < 64) {
+        // and only where the halved workgroup count still fills the chip twice over (a B = 1 generation has 48 (row, head) pairs)
+        if (CVAR_ATTN_Q64 && qpre && l >= 256 && cdiv(l, 256) * 256 - l < 64 && (long)cdiv(l, 256) * H * R >= 512) {
             const dim3 grid64((unsigned)((long)cdiv(l, 256) * H * R));
             if (holes) hipLaunchKernelGGL((attn_mfma_bf16_q64_kernel<true>), grid64, block, 0, as_stream(stream), p);
             else hipLaunchKernelGGL((attn_mfma_bf16_q64_kernel<false>), grid64, block, 0, as_stream(stream), p);

@@ -21,6 +21,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #ifndef CH_EPI_LDS
 #define CH_EPI_LDS 1
 #endif
+// CH_WIDE_TILE = 1: 32-pixel-wide tiles on 8 waves (one workgroup per CU) - built, bit-identical, 1-6 % SLOWER than two independent 4-wave workgroups per CU on every
+// shape but 640 -> 640 at 32^2 (profiles/r04_conv_ablation.txt): what the halved weight traffic saves, the 8-wave barrier and the lost independence of the pair cost.
+#ifndef CH_WIDE_TILE
+#define CH_WIDE_TILE 0
+#endif
 
 struct ConvHaloParams {
     const bf16_t* X; const bf16_t* Wt; const float* bias; const bf16_t* res; void* out;
@@ -28,9 +33,9 @@ struct ConvHaloParams {
     int up, Hin, Win;          // up = 1: the conv reads its input through a nearest x2 upsample (Hin = H / 2), vae_modules.py:28
 };
 
-constexpr int CH_HROW = 20;                   // halo row stride in pixels (18 used): a multiple of 4, so that the bank slot depends on the column only
-constexpr int CH_HALO_PIECES = 23;            // 18 rows x 20 pixels x 64 B = 23 040 B -> 23 DMA pieces of 1 KiB
-constexpr int CH_HALO_BYTES = CH_HALO_PIECES * 1024;
+// Tile width TW = 16 (4 waves, two workgroups per CU: the shipped form) or 32 (8 waves, one workgroup per CU: round-4 experiment, -DCH_WIDE_TILE=1 - the weight
+// tiles, a seventh of the kernel's time by the ablation table, are fetched once for 512 pixels instead of once per 256; same K order per output, bit-identical
+// results; measured slower, see CH_WIDE_TILE).  Halo row stride TW + 4 pixels (TW + 2 used): a multiple of 4, so that the bank slot depends on the column only.
 
 // LDS images: 64-byte rows (one pixel / one cout x 32 channels) whose four 16-B chunks are XOR-swizzled so that every lane group of a
 // ds_read_b128 covers all 64 banks once.  The hardware's groups are NOT 16 consecutive lanes: group 0 = lanes {0-3, 12-15, 20-27} etc.
@@ -41,11 +46,16 @@ constexpr int CH_HALO_BYTES = CH_HALO_PIECES * 1024;
 // the halo reads are 4 of the 14 fragment reads of a step - but it also freed 33 VGPRs of address state.)
 // CH_NB = 32-wide cout blocks per tile: 5 (the 160-multiples of the VQVAE) or 1 (conv_out's 3 channels: couts beyond Cout are zero rows of the
 // weight tile and are not stored).  TO = output element type (bf16, or fp32 for conv_out).
-template <int CH_NB, typename TO>
-__global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHaloParams p) {
+template <int CH_NB, typename TO, int TW = 16>
+__global__ __launch_bounds__(TW * 16, 2) void conv3x3_halo_bf16_kernel(const ConvHaloParams p) {
+    constexpr int NW = TW / 4;                        // waves: 64 pixels each
+    constexpr int CH_HROW = TW + 4;
+    constexpr int CH_HALO_PIECES = (18 * CH_HROW * 64 + 1023) / 1024;        // 23 (TW = 16) / 41 (TW = 32) DMA pieces of 1 KiB
+    constexpr int CH_HALO_BYTES = CH_HALO_PIECES * 1024;
+    constexpr int H_PER_WAVE = (CH_HALO_PIECES + NW - 1) / NW;               // 6 / 6
     constexpr int CH_W_BYTES = CH_NB * 2048;          // 32 CH_NB rows x 64 B
     constexpr int W_PIECES = CH_NB * 2;               // 1-KiB DMA pieces per weight tile
-    constexpr int W_PER_WAVE = (W_PIECES + 3) / 4;
+    constexpr int W_PER_WAVE = (W_PIECES + NW - 1) / NW;
     __shared__ __attribute__((aligned(1024))) char smem[2 * CH_HALO_BYTES + 3 * CH_W_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -54,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
     const int tx = t_ % p.tiles_x; t_ /= p.tiles_x;
     const int ty = t_ % p.tiles_y;
     const int b = t_ / p.tiles_y;
-    const int ty0 = ty * 16, tx0 = tx * 16;
+    const int ty0 = ty * 16, tx0 = tx * TW;
     const int cout0 = blockIdx.y * (32 * CH_NB);
 #ifdef CH_STAGGER
     // experiment: the second workgroup of every CU (blocks 256 .. 511 of the launch, as dispatch goes) starts CH_STAGGER shader cycles late, so that the two
@@ -69,27 +79,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Wt + (long)cout0 * 9 * p.Cin), 0, min(32 * CH_NB, p.Cout - cout0) * 9 * p.Cin * 2, 0x00020000);
 
     // DMA piece q of an image = 16-B slot q of the LDS image: row q >> 2, physical chunk q & 3 <- logical chunk (q & 3) ^ ((row >> 2) & 3)
-    unsigned h_off[6], w_off[W_PER_WAVE];
+    unsigned h_off[H_PER_WAVE], w_off[W_PER_WAVE];
 #pragma unroll
-    for (int jj = 0; jj < 6; ++jj) {
-        const int q = (wave + 4 * jj) * 64 + lane;
+    for (int jj = 0; jj < H_PER_WAVE; ++jj) {
+        const int q = (wave + NW * jj) * 64 + lane;
         const int hp = q >> 2;
         const int hy = hp / CH_HROW, hx = hp - hy * CH_HROW;
         const int lc = (q & 3) ^ ((hx >> 2) & 3);
         const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-        const bool ok = hy < 18 && hx < 18 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const bool ok = hy < 18 && hx < TW + 2 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         // out of range -> the DMA writes zeros (the conv's zero padding); upsample: output-grid pixel (gy, gx) reads input (gy >> 1, gx >> 1)
         const int sy = p.up ? gy >> 1 : gy, sx = p.up ? gx >> 1 : gx;
         h_off[jj] = ok ? (unsigned)(((sy * p.Win + sx) * p.Cin + lc * 8) * 2) : 0x80000000u;
     }
 #pragma unroll
     for (int jj = 0; jj < W_PER_WAVE; ++jj) {
-        const int q = (wave + 4 * jj) * 64 + lane;
+        const int q = (wave + NW * jj) * 64 + lane;
         const int n = q >> 2, lc = (q & 3) ^ ((n >> 2) & 3);
         w_off[jj] = (n < 32 * CH_NB && cout0 + n < p.Cout) ? (unsigned)((n * 9 * p.Cin + lc * 8) * 2) : 0x80000000u;   // rows past Cout: zeros
     }
     auto issue_halo = [&](int c, int jj) -> int {
-        const int j = wave + 4 * jj;
+        const int j = wave + NW * jj;
         if (j >= CH_HALO_PIECES) return 0;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lptr_t)(smem + (c & 1) * CH_HALO_BYTES + j * 1024), 16, (int)h_off[jj], c * 64, 0, 0);
         return 1;
@@ -99,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
         int n = 0;
 #pragma unroll
         for (int jj = 0; jj < W_PER_WAVE; ++jj) {
-            const int j = wave + 4 * jj;
+            const int j = wave + NW * jj;
             if (j < W_PIECES) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(smem + 2 * CH_HALO_BYTES + (t % 3) * CH_W_BYTES + j * 1024), 16,
                                                          (int)w_off[jj], (t * p.Cin + c * 32) * 2, 0, 0);
@@ -117,8 +127,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
-    // fragment addressing: pixel of lane = (4 wave + 2 i + (lrow >> 4), lrow & 15) of the tile -> halo row (y + dy) * 18 + (x + dx)
-    const int hpb = (4 * wave + (lrow >> 4)) * CH_HROW + (lrow & 15);
+    // fragment addressing: pixel of lane = ((64 / TW) wave + (32 / TW) i + lrow / TW, lrow % TW) of the tile -> halo pixel (y + dy) * CH_HROW + (x + dx)
+    constexpr int RPI = 32 / TW;                      // image rows of a 32-pixel MFMA row block
+    const int px = lrow & (TW - 1), py0 = 2 * RPI * wave + lrow / TW;
+    const int hpb = py0 * CH_HROW + px;
     const int swb = (lrow >> 2) & 3;
     const int b_lane = lrow * 64;
 
@@ -131,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
 #pragma unroll
-    for (int jj = 0; jj < 6; ++jj) issue_halo(0, jj);
+    for (int jj = 0; jj < H_PER_WAVE; ++jj) issue_halo(0, jj);
     issue_w(0, 0);
     issue_w(0, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -144,10 +156,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
     // landed by tap 6 - so a step starts its MFMAs as soon as the first weight fragment is back from LDS (+1-3 %).  af[set][i][ks]
     bf16x8_t af[2][2][2];
     auto read_a = [&](int set, const char* hbuf, int d) {
-        const int sw = (((lrow & 15) + d % CH_HROW) >> 2) & 3;          // column of the lane's pixel + the tap's column shift
+        const int sw = ((px + d % CH_HROW) >> 2) & 3;          // column of the lane's pixel + the tap's column shift
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int hp = hpb + 2 * CH_HROW * i + d;
+            const int hp = hpb + RPI * CH_HROW * i + d;
             const char* ap = hbuf + hp * 64;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) af[set][i][ks] = *(const bf16x8_t*)(ap + (((2 * ks + hi) ^ sw) << 4));
@@ -160,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             int issued = 0;
-            if (CH_ABL != 2 && CH_ABL != 3 && t < 6 && c + 1 < p.nchunk) issued += issue_halo(c + 1, t);
+            if (CH_ABL != 2 && CH_ABL != 3 && t < H_PER_WAVE && c + 1 < p.nchunk) issued += issue_halo(c + 1, t);
             {
                 const int c2 = t + 2 >= 9 ? c + 1 : c, t2 = t + 2 >= 9 ? t + 2 - 9 : t + 2;
                 if (CH_ABL != 1 && CH_ABL != 3 && c2 < p.nchunk) issued += issue_w(c2, t2);
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
     if (CH_ABL == 4 && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int yy = 4 * wave + 2 * i + (lrow >> 4), xx = lrow & 15;
+        const int yy = py0 + RPI * i, xx = px;
         const long gpix = ((long)b * p.H + ty0 + yy) * p.W + tx0 + xx;
         if constexpr (CH_NB == 1) {
             // narrow output (conv_out: 3 channels): element-wise predicated stores of the couts that exist, no residual
@@ -221,13 +233,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_halo_bf16_kernel(const ConvHal
             // pipeline LDS as [pixel][cout] rows of 336 B: residual in by 16-byte row-contiguous loads, summed in the accumulator layout in fp32 exactly as
             // before (acc + bias + residual, one rounding), out by 16-byte row-contiguous stores - 160 full-line requests per wave and tile.
             constexpr int PS = 336;
-            char* stg = smem + wave * 19200;
+            char* stg = smem + wave * ((2 * CH_HALO_BYTES + 3 * CH_W_BYTES) / NW / 64 * 64);
             const float* bp = p.bias ? p.bias + cout0 + 4 * hi : nullptr;
             // chunk q = 64 k + lane of the row block: pixel q / 20, 16-byte part q % 20; offsets relative to the image (32-bit)
             const long img = (long)b * p.H * p.W * p.Cout;
             auto chunk = [&](int k, int& go, int& lo) {
                 const int q = k * 64 + lane, pq = q / 20, part = q - pq * 20;
-                go = ((ty0 + 4 * wave + 2 * i + (pq >> 4)) * p.W + tx0 + (pq & 15)) * p.Cout + cout0 + part * 8;
+                go = ((ty0 + 2 * RPI * wave + RPI * i + pq / TW) * p.W + tx0 + (pq & (TW - 1))) * p.Cout + cout0 + part * 8;
                 lo = pq * PS + part * 16;
             };
             if (p.res) {
@@ -304,6 +316,15 @@ int cvar_conv3x3_halo_bf16(const void* X, const void* Wt, const float* bias, con
     const long tiles = (long)B * p.tiles_x * p.tiles_y;
     if (tiles <= 0 || tiles > 0x7fffffffL) return CVAR_EINVAL;
     if (Cout % 160 == 0 && !out_f32) {
+        // 32-pixel-wide tiles wherever the image has them (chosen by the image width only; same bits as the 16-wide kernel)
+        if (CH_WIDE_TILE && W % 32 == 0) {
+            p.tiles_x = W / 32;
+            const long tiles32 = (long)B * p.tiles_x * p.tiles_y;
+            if (tiles32 <= 0 || tiles32 > 0x7fffffffL) return CVAR_EINVAL;
+            hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<5, bf16_t, 32>), dim3((unsigned)tiles32, Cout / 160), dim3(512), 0, st, p);
+            CVAR_CHECK_LAUNCH();
+            return CVAR_OK;
+        }
         hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<5, bf16_t>), dim3((unsigned)tiles, Cout / 160), dim3(256), 0, st, p);
     } else if (Cout <= 32 && !residual) {
         if (out_f32) hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<1, float>), dim3((unsigned)tiles, 1), dim3(256), 0, st, p);
