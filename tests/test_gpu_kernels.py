@@ -873,3 +873,41 @@ def test_gemm_with_the_adaln_of_the_next_op_is_bit_identical_to_two_calls(gpu_de
         assert torch.equal(x1, x2)
     else:
         assert (x1 - x2).abs().max() < 1e-3 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize('q_off,l,levels', [(848, 512, None), (0, 512, (2, 10, 28, 60, 110, 182, 310, 512))])
+def test_attention_64_queries_per_wave_kernel_equals_the_128_query_kernel_bit_for_bit(gpu_device, q_off, l, levels):
+    """cvar_attention_prescaled sends scales whose last 256-query workgroup is nearly full AND whose grid still fills the chip (>= 512 workgroups) to
+    attn_mfma_bf16_q64_kernel (two 32-query groups per wave share every K / V fragment, tile and barrier); everything else runs the 128-query kernel.  Same
+    arithmetic per query: rows 0:2 of an R = 12 call (24 heads x 12 rows x 2 workgroups = 576: the 64-query kernel) equal an R = 2 call (96 workgroups of 256
+    queries would not fill the chip: the 128-query kernel) bit for bit, and both match the fp64 softmax."""
+    H, Lmax, R = 24, 1360, 12
+    C = H * 64
+    g = torch.Generator().manual_seed(19)
+    kv = (torch.randn(R, Lmax, 2 * C, generator=g) * 0.7).to(torch.bfloat16).to(gpu_device)
+    kv[1, (q_off + l) // 2, :C] *= 9.0                       # a dominating key in row 1: the running maximum jumps late
+    scale = 0.125
+    q = torch.randn(R, l, C, generator=g)
+    qp = (q.to(torch.bfloat16).float() * (scale * 1.4426950408889634)).to(torch.bfloat16).to(gpu_device)
+    out_big = torch.full((R * l, C), float('nan'), device=gpu_device, dtype=torch.bfloat16)
+    lse_big = torch.empty(R, H, l, device=gpu_device)
+    ops.attention(kv, out_big, R, H, Lmax, q_off, l, scale, levels, q=qp.view(R * l, C), prescaled=True, lse=lse_big)
+    out_small = torch.full((2 * l, C), float('nan'), device=gpu_device, dtype=torch.bfloat16)
+    lse_small = torch.empty(2, H, l, device=gpu_device)
+    ops.attention(kv[:2].contiguous(), out_small, 2, H, Lmax, q_off, l, scale, levels, q=qp[:2].reshape(2 * l, C).contiguous(), prescaled=True, lse=lse_small)
+    assert not torch.isnan(out_big.float()).any()
+    assert torch.equal(out_big[:2 * l], out_small) and torch.equal(lse_big[:2], lse_small)
+    # and the function itself on rows 0:2 (fp64 softmax of the same bf16 operands, log2 domain)
+    kf = kv[:2].double().cpu()[:, :, :C].view(2, Lmax, H, 64).permute(0, 2, 1, 3)
+    vf = kv[:2].double().cpu()[:, :, C:].view(2, Lmax, H, 64).permute(0, 2, 1, 3)
+    qf = qp[:2].double().cpu().view(2, l, H, 64).permute(0, 2, 1, 3)
+    s2 = qf @ kf.transpose(-1, -2)
+    pos, keys = torch.arange(q_off, q_off + l), torch.arange(Lmax)
+    if levels:
+        ends = torch.tensor(levels)
+        vis = keys[None, :] < ends[torch.searchsorted(ends, pos, right=True)][:, None]
+    else:
+        vis = (keys[None, :] < q_off + l).expand(l, Lmax)
+    pr = torch.softmax(s2.masked_fill(~vis, float('-inf')) * math.log(2.0), dim=-1)
+    ref = (pr @ vf).permute(0, 2, 1, 3).reshape(2 * l, C)
+    assert (out_small.double().cpu() - ref).abs().max().item() < 1.2e-2 * ref.abs().max().item()
