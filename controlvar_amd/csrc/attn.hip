@@ -157,6 +157,9 @@ template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_wa
 #ifndef CVAR_ATTN_Q64
 #define CVAR_ATTN_Q64 1
 #endif
+#ifndef CVAR_ATTN_Q64_MINL
+#define CVAR_ATTN_Q64_MINL 192      // l = 200 (one workgroup of 256 instead of two of 128): 0.315 -> 0.308 ms per call at B = 128
+#endif
 // round 4: wave-internally pipelined form of the prescaled kernel - built, correct (35 tests, fuzz 600 / 600), 16 % SLOWER at the last scale
 // (profiles/r04_attn_pipe_rejected.txt); compiled only with -DCVAR_ATTN_PIPE=1
 #ifndef CVAR_ATTN_PIPE
@@ -239,7 +242,7 @@ static int cvar_attention_impl(const void* qkv, const void* q, int dtype, int R,
         // (only where the last 256-query workgroup is nearly full: l = 512 runs 1.371 -> 1.285 ms per call at B = 128, l = 338 - 82 queries in its second workgroup -
         //  0.685 -> 0.82 ms and stays on the 128-query kernel; profiles/r04_attn_ablation.txt)
         // and only where the halved workgroup count still fills the chip twice over (a B = 1 generation has 48 (row, head) pairs)
-        if (CVAR_ATTN_Q64 && qpre && l >= 256 && cdiv(l, 256) * 256 - l < 64 && (long)cdiv(l, 256) * H * R >= 512) {
+        if (CVAR_ATTN_Q64 && qpre && l >= CVAR_ATTN_Q64_MINL && cdiv(l, 256) * 256 - l < 64 && (long)cdiv(l, 256) * H * R >= 512) {
             const dim3 grid64((unsigned)((long)cdiv(l, 256) * H * R));
             if (holes) hipLaunchKernelGGL((attn_mfma_bf16_q64_kernel<true>), grid64, block, 0, as_stream(stream), p);
             else hipLaunchKernelGGL((attn_mfma_bf16_q64_kernel<false>), grid64, block, 0, as_stream(stream), p);
