@@ -49,19 +49,6 @@ extern "C" int cvar_gemm_dbg_read(unsigned long long* host) { return (int)hipMem
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// tile origin of virtual block id v: bijective XCD remap, then grouped-M ordering (shared by the kernel body and the fused split-K tail)
-__device__ __forceinline__ void gemm_tile_origin(const GemmParams& p, int v, int BM, int BN, int& m0_, int& n0_) {
-    const int nblk_all = p.tiles_m * p.tiles_n;
-    const int xcd = v & 7, q = nblk_all >> 3, r = nblk_all & 7, local = v >> 3;
-    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
-    const int GM = p.group_m;             // row tiles per group: the tiles of GM consecutive rows share each W tile out of L2
-    const int group_sz = GM * p.tiles_n;
-    const int grp = bid / group_sz, first_m = grp * GM;
-    const int gm = min(p.tiles_m - first_m, GM);
-    m0_ = (first_m + (bid % group_sz) % gm) * BM;
-    n0_ = ((bid % group_sz) / gm) * BN;
-}
-
 // 16-byte fp32 store / load at DEVICE scope (sc1): written through to / fetched from the point all eight XCD L2s agree on.  The fused split-K
 // hand-over uses these per access instead of a release / acquire fence pair - on this part a fence is `buffer_wbl2 sc1` + `buffer_inv sc1`, a
 // write-back and an invalidate of the whole 4 MB L2 by every slice (measured: 63 us per small GEMM, B = 1 generation 36 -> 90 ms).

@@ -51,6 +51,20 @@ static void make_fast_div(long d, unsigned* magic, int* shift) {
 }
 
 
+// tile origin of virtual block id v: bijective XCD remap, then grouped-M ordering (shared by the kernel body and the fused split-K tail)
+__device__ __forceinline__ void gemm_tile_origin(const GemmParams& p, int v, int BM, int BN, int& m0_, int& n0_) {
+    const int nblk_all = p.tiles_m * p.tiles_n;
+    const int xcd = v & 7, q = nblk_all >> 3, r = nblk_all & 7, local = v >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    const int GM = p.group_m;             // row tiles per group: the tiles of GM consecutive rows share each W tile out of L2
+    const int group_sz = GM * p.tiles_n;
+    const int grp = bid / group_sz, first_m = grp * GM;
+    const int gm = min(p.tiles_m - first_m, GM);
+    m0_ = (first_m + (bid % group_sz) % gm) * BM;
+    n0_ = ((bid % group_sz) / gm) * BN;
+}
+
+
 // The complete epilogue of one output quad (row m, columns n .. n+3) on the fp32 sums v:
 //   x = alpha * v + bias -> [pre_act copy] -> activation -> gate -> residual -> store (row remap / column split), cvar.h.
 // Every path that finishes a GEMM outside the tile kernels' own epilogue (split-K reduction, skinny kernel) goes through here.

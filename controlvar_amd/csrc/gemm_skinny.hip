@@ -338,3 +338,4 @@ int cvar_splitk_rowfin_launch(const float* part, int nsplit, const GemmParams& p
     if (d->ln_out_dtype == CVAR_BF16) return rowfin_dispatch<bf16_t>(part, nsplit, p, ln, st);
     return rowfin_dispatch<float>(part, nsplit, p, ln, st);
 }
+
