@@ -339,3 +339,4 @@ int cvar_splitk_rowfin_launch(const float* part, int nsplit, const GemmParams& p
     return rowfin_dispatch<float>(part, nsplit, p, ln, st);
 }
 
+
