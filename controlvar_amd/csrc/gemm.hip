@@ -1440,6 +1440,10 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         if (p.tile_cfg == 13 && !p.conv) return launch_cfg<T, 128, 128, 2, 2, 3>(p, batch, st);
         if (p.tile_cfg == 14 && !p.conv) return launch_cfg<T, 128, 128, 2, 2, 4>(p, batch, st);
+        // transformer passes (tile_cfg 12) that end up here unsliced - 1024 < M < 2048, or N not a 256-tile width - take the third stage as well when
+        // all their workgroups fit the chip at once
+        if (p.tile_cfg == 12 && !p.conv && batch == 1 && p.split_tiles == 0 && p.K >= 6 * 64 &&
+            (long)((p.M + 127) / 128) * ((p.N + 127) / 128) <= 256) return launch_cfg<T, 128, 128, 2, 2, 3>(p, batch, st);
     }
 #endif
     return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
