@@ -20,6 +20,14 @@
 // Math: basic_var.py:43-51,92,119,207-209 (same functions as gemm.hip / ops.hip; accumulation order differs from the tile kernels, fp32 sums).
 #include "gemm_params.h"
 
+// cache policy of the weight stream (aux of buffer_load): 0 default, 2 = nt (each weight byte is read by ONE workgroup, once)
+#ifndef CVAR_SKINNY_NT2
+#define CVAR_SKINNY_NT2 1
+#endif
+#ifndef CVAR_SKINNY_W_AUX
+#define CVAR_SKINNY_W_AUX 0
+#endif
+
 typedef __attribute__((ext_vector_type(4))) int v4i_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bfv8_t;
 
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(512) void cvar_gemm_skinny_kernel(const GemmParams 
         const int st = 8 * blk(b) + wave;                                          // this wave's step of the block
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-            wf[slot][j] = __builtin_bit_cast(bf16x8_t, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, st < S ? offW[j] : 0x80000000u, (unsigned)(ks_lo + st) * 64u, 0));
+            wf[slot][j] = __builtin_bit_cast(bf16x8_t, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(w_rsrc, st < S ? offW[j] : 0x80000000u, (unsigned)(ks_lo + st) * 64u, CVAR_SKINNY_W_AUX));
     };
     f32x4_t acc[MT][NT];
 #pragma unroll
@@ -160,7 +168,9 @@ static int skinny_launch_cfg(const GemmParams& p, int slices, hipStream_t st) {
 //   one row group (M <= 64):  qkv 8.9-12.4 / 11.6-16.9, fc1 9.4-12.9 / 13.2-18.8, proj 8.5-10.4 / 12.0-15.1, fc2 (K = 6144 as 4 slices + row finish) 14.8-21.0 / 18.8-21.7
 //   more row groups:          wins only for the small square call (proj, N K <= 4 M: 13.5-15.8 / 17.7-22.5 up to M = 256); qkv / fc1 / fc2 tie or lose from M = 100 on
 // - every extra row group re-reads the weights and multiplies the workgroups past what is resident (two per CU).  16 columns per workgroup always (nt = 2 halves
-// the activation re-reads but needs 161 registers: one workgroup per CU, two rounds).  Slices: the fewest that keep a workgroup's bytes under 320 KB.
+// the activation re-reads but needs 161 registers: one workgroup per CU - two rounds when there is more than one row group; with ONE 64-row group and N >= 4096
+// (qkv, fc1: 144 / 192 workgroups) it wins 1.2-1.9 us per call and is used).  Slices: the fewest that keep a workgroup's bytes under 320 KB.
+// nt weight loads (aux = 2): neutral, not used.
 int cvar_gemm_skinny_plan(int M, int N, int K, long lda, long ldw, int want_rowfin, int have_ws, int* mt_, int* nt_, int* slices_) {
     (void)want_rowfin;
     if (M <= 0 || M > 256 || (K & 31) || (N & 15) || (lda & 7) || (ldw & 7)) return 0;
@@ -172,7 +182,11 @@ int cvar_gemm_skinny_plan(int M, int N, int K, long lda, long ldw, int want_rowf
     for (int sl = 1; sl <= 8; sl *= 2) {
         if (sl > 1 && (!have_ws || gy > 1 || nks % sl || (nks / sl) % 8 || nks / sl < 16)) continue;          // a K slice is whole 256-k blocks, at least 512 deep
         if ((double)(16 * mt + 16) * (K / sl) * 2.0 > 320.0 * 1024) continue;
-        *mt_ = mt; *nt_ = 1; *slices_ = sl;
+        // 32 columns per workgroup halve the activation re-reads - worth it where the activations are the bulk (64-row groups) and the halved grid still
+        // has >= 128 workgroups (qkv, fc1); CVAR_SKINNY_NT2 = 0 keeps 16 columns everywhere
+        const int nt = (CVAR_SKINNY_NT2 && mt == 4 && gy == 1 && sl == 1 && (N & 31) == 0 && N / 32 >= 128) ? 2 : 1;
+        if ((double)(16 * mt + 16 * nt) * (K / sl) * 2.0 > 320.0 * 1024) continue;
+        *mt_ = mt; *nt_ = nt; *slices_ = sl;
         return 1;
     }
     return 0;
