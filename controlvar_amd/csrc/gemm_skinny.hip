@@ -21,6 +21,12 @@
 #include "gemm_params.h"
 
 // cache policy of the weight stream (aux of buffer_load): 0 default, 2 = nt (each weight byte is read by ONE workgroup, once)
+#ifndef CVAR_SKINNY_T8_TWO
+#define CVAR_SKINNY_T8_TWO 1     // the 64x32 tile compiled for two workgroups per CU (<= 128 registers)
+#endif
+#ifndef CVAR_SKINNY_BIG_GY
+#define CVAR_SKINNY_BIG_GY 4
+#endif
 #ifndef CVAR_SKINNY_NT2
 #define CVAR_SKINNY_NT2 1
 #endif
@@ -32,13 +38,13 @@ typedef __attribute__((ext_vector_type(4))) int v4i_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bfv8_t;
 
 template <int MT, int NT, bool PARTIAL>
-__global__ __launch_bounds__(512) void cvar_gemm_skinny_kernel(const GemmParams p) {
+__global__ __launch_bounds__(512, (MT * NT == 8 && CVAR_SKINNY_T8_TWO) ? 4 : 2) void cvar_gemm_skinny_kernel(const GemmParams p) {
     constexpr int T = MT * NT, RM = 16 * MT;
     static_assert(T <= 8, "one output quad per thread");
     constexpr int STAGE = RM * 512;                              // one activation block: RM rows x 256 k (512 B per row)
     constexpr int RED = 8 * T * 64 * 16;
     constexpr int LDS_BYTES = 2 * STAGE > RED ? 2 * STAGE : RED;
-    constexpr int WPF = 8;                                       // weight fragments in flight per wave: 8 blocks ahead (K = 1536: all of them)
+    constexpr int WPF = (MT * NT == 8 && CVAR_SKINNY_T8_TWO) ? 4 : 8;      // weight fragments in flight per wave, in blocks (K = 1536: 6 blocks); 64x32 tiles keep 4 to fit 128 registers
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -177,14 +183,19 @@ int cvar_gemm_skinny_plan(int M, int N, int K, long lda, long ldw, int want_rowf
     if ((long)M * lda * 2 >= (1L << 31) || (long)N * ldw * 2 >= (1L << 31)) return 0;
     const int mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
     const int gy = (M + 16 * mt - 1) / (16 * mt);
-    if (gy > 1 && (long)N * K > (4L << 20)) return 0;
+    // big calls (qkv, fc1) with more than one row group: only as 64x32 tiles (two workgroups per CU since the tile fits 128 registers) and up to CVAR_SKINNY_BIG_GY groups
+    const bool big = (long)N * K > (4L << 20);
+    // (measured, us per call, 64x32 streaming / three-stage tiles: M = 100 qkv 15.9 / 18.4, fc1 16.8 / 20.8; M = 144 qkv 16.7 / 18.6, fc1 22.9 / 20.9; M = 200-256 lose:
+    //  at most 432 workgroups - two per CU resident, a little tail)
+    if (gy > 1 && big && (gy > CVAR_SKINNY_BIG_GY || (N & 31) || mt != 4 || (long)(N / 32) * gy > 432)) return 0;
     const int nks = K >> 5;
     for (int sl = 1; sl <= 8; sl *= 2) {
         if (sl > 1 && (!have_ws || gy > 1 || nks % sl || (nks / sl) % 8 || nks / sl < 16)) continue;          // a K slice is whole 256-k blocks, at least 512 deep
         if ((double)(16 * mt + 16) * (K / sl) * 2.0 > 320.0 * 1024) continue;
         // 32 columns per workgroup halve the activation re-reads - worth it where the activations are the bulk (64-row groups) and the halved grid still
         // has >= 128 workgroups (qkv, fc1); CVAR_SKINNY_NT2 = 0 keeps 16 columns everywhere
-        const int nt = (CVAR_SKINNY_NT2 && mt == 4 && gy == 1 && sl == 1 && (N & 31) == 0 && N / 32 >= 128) ? 2 : 1;
+        const int nt = (CVAR_SKINNY_NT2 && mt == 4 && (gy == 1 || big) && sl == 1 && (N & 31) == 0 && N / 32 >= 128) ? 2 : 1;
+        if (gy > 1 && big && nt != 2) continue;
         if ((double)(16 * mt + 16 * nt) * (K / sl) * 2.0 > 320.0 * 1024) continue;
         *mt_ = mt; *nt_ = nt; *slices_ = sl;
         return 1;
