@@ -24,6 +24,12 @@
 #ifndef CVAR_SKINNY_T8_TWO
 #define CVAR_SKINNY_T8_TWO 1     // the 64x32 tile compiled for two workgroups per CU (<= 128 registers)
 #endif
+#ifndef CVAR_SKINNY_NT2_SLICED
+#define CVAR_SKINNY_NT2_SLICED 1
+#endif
+#ifndef CVAR_SKINNY_SLICED_GY
+#define CVAR_SKINNY_SLICED_GY 1      // K slices with two row groups (fc2 at M = 100 ... 128): 22.2 vs 22.0 us for the tiles - neutral, off
+#endif
 #ifndef CVAR_SKINNY_BIG_GY
 #define CVAR_SKINNY_BIG_GY 4
 #endif
@@ -190,11 +196,11 @@ int cvar_gemm_skinny_plan(int M, int N, int K, long lda, long ldw, int want_rowf
     if (gy > 1 && big && (gy > CVAR_SKINNY_BIG_GY || (N & 31) || mt != 4 || (long)(N / 32) * gy > 432)) return 0;
     const int nks = K >> 5;
     for (int sl = 1; sl <= 8; sl *= 2) {
-        if (sl > 1 && (!have_ws || gy > 1 || nks % sl || (nks / sl) % 8 || nks / sl < 16)) continue;          // a K slice is whole 256-k blocks, at least 512 deep
+        if (sl > 1 && (!have_ws || gy > CVAR_SKINNY_SLICED_GY || nks % sl || (nks / sl) % 8 || nks / sl < 16)) continue;          // a K slice is whole 256-k blocks, at least 512 deep
         if ((double)(16 * mt + 16) * (K / sl) * 2.0 > 320.0 * 1024) continue;
         // 32 columns per workgroup halve the activation re-reads - worth it where the activations are the bulk (64-row groups) and the halved grid still
         // has >= 128 workgroups (qkv, fc1); CVAR_SKINNY_NT2 = 0 keeps 16 columns everywhere
-        const int nt = (CVAR_SKINNY_NT2 && mt == 4 && (gy == 1 || big) && sl == 1 && (N & 31) == 0 && N / 32 >= 128) ? 2 : 1;
+        const int nt = (CVAR_SKINNY_NT2 && mt == 4 && (gy == 1 || big) && (sl == 1 || CVAR_SKINNY_NT2_SLICED) && (N & 31) == 0 && (long)(N / 32) * sl >= 128) ? 2 : 1;
         if (gy > 1 && big && nt != 2) continue;
         if ((double)(16 * mt + 16 * nt) * (K / sl) * 2.0 > 320.0 * 1024) continue;
         *mt_ = mt; *nt_ = nt; *slices_ = sl;
