@@ -30,6 +30,12 @@
 #ifndef CVAR_SKINNY_SLICED_GY
 #define CVAR_SKINNY_SLICED_GY 1      // K slices with two row groups (fc2 at M = 100 ... 128): 22.2 vs 22.0 us for the tiles - neutral, off
 #endif
+#ifndef CVAR_SKINNY_PROJ_SLICED
+#define CVAR_SKINNY_PROJ_SLICED 1
+#endif
+#ifndef CVAR_SKINNY_MOST_SLICES
+#define CVAR_SKINNY_MOST_SLICES 1
+#endif
 #ifndef CVAR_SKINNY_BIG_GY
 #define CVAR_SKINNY_BIG_GY 4
 #endif
@@ -175,16 +181,15 @@ static int skinny_launch_cfg(const GemmParams& p, int slices, hipStream_t st) {
     return CVAR_OK;
 }
 
-// plan: rows per workgroup 16 mt, columns 16 nt, K slices (1 = none).  Returns 0 when the call is not one for this kernel.
-// Rules from tools/skinny_bench.py on the d24 calls (profiles/r04_small_batch.txt; per call incl. the adaLN where requested, us, streaming / LDS-tiled + split-K):
-//   one row group (M <= 64):  qkv 8.9-12.4 / 11.6-16.9, fc1 9.4-12.9 / 13.2-18.8, proj 8.5-10.4 / 12.0-15.1, fc2 (K = 6144 as 4 slices + row finish) 14.8-21.0 / 18.8-21.7
-//   more row groups:          wins only for the small square call (proj, N K <= 4 M: 13.5-15.8 / 17.7-22.5 up to M = 256); qkv / fc1 / fc2 tie or lose from M = 100 on
-// - every extra row group re-reads the weights and multiplies the workgroups past what is resident (two per CU).  16 columns per workgroup always (nt = 2 halves
-// the activation re-reads but needs 161 registers: one workgroup per CU - two rounds when there is more than one row group; with ONE 64-row group and N >= 4096
-// (qkv, fc1: 144 / 192 workgroups) it wins 1.2-1.9 us per call and is used).  Slices: the fewest that keep a workgroup's bytes under 320 KB.
-// nt weight loads (aux = 2): neutral, not used.
+// plan: rows per workgroup 16 mt, columns 16 nt, K slices (1 = none).  Returns 0 when the call is not one for this kernel.  Every rule below is an A/B of
+// tools/skinny_bench.py on the d24 calls (profiles/r04_small_batch.txt, sections 6 and 11: per call incl. the adaLN where requested, streaming / LDS-tiled):
+//   - one row group (M <= 64): always (qkv 9.0-12.5 / 11.6-16.7 us, fc1 9.4-12.9 / 13.1-18.8, proj 8.6-10.4 / 12.0-15.1, fc2 14.0-17.5 / 18.9-21.6);
+//   - more row groups: the small square call (proj, N K <= 4 M) up to M = 256; big calls (qkv, fc1) only as 64x32 tiles (128 registers: two workgroups per CU)
+//     with at most 432 workgroups - M <= 128, qkv M <= 192; beyond that the three-stage tiles win;
+//   - 32 columns per workgroup (halves the activation re-reads, the bulk of a 64-row workgroup's bytes) where the grid keeps >= 128 workgroups;
+//   - K slices: the fewest that keep a workgroup's bytes under 320 KB (fc2: 4), the most below 64-row groups when a row-finishing launch follows anyway
+//     (fc2 at M <= 32: 8), and two for a call with few column groups whose rows get finished anyway (proj: slices + row finish instead of GEMM + adaLN launch).
 int cvar_gemm_skinny_plan(int M, int N, int K, long lda, long ldw, int want_rowfin, int have_ws, int* mt_, int* nt_, int* slices_) {
-    (void)want_rowfin;
     if (M <= 0 || M > 256 || (K & 31) || (N & 15) || (lda & 7) || (ldw & 7)) return 0;
     if ((long)M * lda * 2 >= (1L << 31) || (long)N * ldw * 2 >= (1L << 31)) return 0;
     const int mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
@@ -195,7 +200,13 @@ int cvar_gemm_skinny_plan(int M, int N, int K, long lda, long ldw, int want_rowf
     //  at most 432 workgroups - two per CU resident, a little tail)
     if (gy > 1 && big && (gy > CVAR_SKINNY_BIG_GY || (N & 31) || mt != 4 || (long)(N / 32) * gy > 432)) return 0;
     const int nks = K >> 5;
-    for (int sl = 1; sl <= 8; sl *= 2) {
+    // a call with few column groups whose rows get finished anyway (ln_out): two K slices + the row-finishing launch instead of one slice + cvar_ln_modulate
+    const int sl0 = (CVAR_SKINNY_PROJ_SLICED && want_rowfin && have_ws && gy == 1 && N / 16 < 128) ? 2 : 1;
+    for (int it = 0; it < 4; ++it) {
+        // sliced calls that end in the row-finishing launch anyway: most slices first (shorter K walks per workgroup), otherwise fewest
+        // (fc2, 8 / 4 slices: M = 4 14.0 / 16.4 us, M = 16 15.3 / 16.5, M = 36 17.7 / 16.9, M = 64 18.9 / 17.5: only below 64-row groups)
+        const int sl = (CVAR_SKINNY_MOST_SLICES && want_rowfin && have_ws && gy == 1 && mt < 4) ? (8 >> it) : (1 << it);
+        if (sl < sl0) continue;
         if (sl > 1 && (!have_ws || gy > CVAR_SKINNY_SLICED_GY || nks % sl || (nks / sl) % 8 || nks / sl < 16)) continue;          // a K slice is whole 256-k blocks, at least 512 deep
         if ((double)(16 * mt + 16) * (K / sl) * 2.0 > 320.0 * 1024) continue;
         // 32 columns per workgroup halve the activation re-reads - worth it where the activations are the bulk (64-row groups) and the halved grid still
