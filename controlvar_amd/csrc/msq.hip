@@ -117,8 +117,12 @@ __global__ __launch_bounds__(MS_NI_THREADS) void ms_next_input_kernel(const int*
     const long b = blockIdx.x / nmaps;
     float* fg = f_hat + (b * nmaps + map) * (long)MS_MAP;
     for (int o = threadIdx.x; o < MS_MAP; o += NTH) fh[o] = fg[o];
+    // the phi weights ([ci][tap][co], 36 KB) into LDS, coalesced, while the gather runs: read through wave-uniform scalar loads they were a chain of 288 s_load
+    // round trips per thread (73 us per call at B = 1 with the conv itself at ~5 us of fma)
+    float* wl = lds + 3 * MS_MAP;
+    for (int o = threadIdx.x * 4; o < MS_C * 9 * MS_C; o += NTH * 4) *(f32x4_t*)(wl + o) = *(const f32x4_t*)(phi_w + o);
     ms_gather_up<NTH>(idx + (b * nmaps + map) * (long)(pn * pn), E, up, bufA, tmp, pn);
-    ms_phi_accumulate<NTH>(bufA, phi_w, phi_b, fh, nullptr);
+    ms_phi_accumulate<NTH>(bufA, wl, phi_b, fh, nullptr);
     for (int o = threadIdx.x; o < MS_MAP; o += NTH) fg[o] = fh[o];
     if (tok_out) {
         float* dst = tok_out + ((b * nmaps + map) * (long)(pn_next * pn_next)) * MS_C;
@@ -133,7 +137,7 @@ extern "C" int cvar_ms_next_input(const int32_t* idx, const float* codebook, con
     if (S != MS_S || Cvae != MS_C) return CVAR_EUNSUPPORTED;
     if (pn != S && !up_mat) return CVAR_EINVAL;
     if (tok_out && (pn_next <= 0 || pn_next > S || (pn_next != S && !down_mat))) return CVAR_EINVAL;
-    const size_t lds = 3 * MS_MAP * sizeof(float);
+    const size_t lds = (3 * MS_MAP + MS_C * 9 * MS_C) * sizeof(float);        // three maps + the phi weights
     (void)hipFuncSetAttribute((const void*)ms_next_input_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(ms_next_input_kernel, dim3((unsigned)((long)nb * nmaps)), dim3(MS_NI_THREADS), lds, as_stream(stream), idx, codebook, phi_w, phi_b,
                        up_mat, down_mat, f_hat, tok_out, nmaps, pn, pn_next);
