@@ -1428,7 +1428,7 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
 #if CVAR_TU_PLAIN && !CVAR_TU_CONV
             // one round of at most 256 workgroups in a transformer pass: three LDS stages (see cvar_gemm: a workgroup of this regime is latency-bound)
             if constexpr (sizeof(T) == 2) {
-                if (p.tile_cfg == 12 && !p.conv && t128 <= 256 && p.K >= 6 * 64) return launch_cfg<T, 128, 128, 2, 2, 3>(p, batch, st);
+                if (p.tile_cfg == 12 && !p.conv && t128 <= 256 && p.K >= 6 * 64) return launch_cfg<T, 128, 128, 2, 4, 3>(p, batch, st);
             }
 #endif
             return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
@@ -1436,14 +1436,16 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     }
     if (ov != 0 && (p.M >= 2048 || (p.split_tiles > 0 && p.M > 1024)) && n_ok) return launch_cfg<T, 256, 256, 2, 4>(p, batch, st);
 #if CVAR_TU_PLAIN && !CVAR_TU_CONV
-    // experiment (tile_cfg 13 / 14): the 128x128 tile with three / four LDS stages - two / three K tiles in flight per workgroup (one workgroup per CU)
+    // tile_cfg 13 / 14: the 128x128 tile with three / four LDS stages - two / three K tiles in flight per workgroup (one workgroup per CU).  The three-stage
+    // instance runs on EIGHT waves (64x32 per wave): with one wave per SIMD nothing hides the 8 DMA issues a wave has per 32 MFMAs - 4 waves / 8 waves, us per call:
+    // M = 400 qkv 19.0 / 17.7, fc1 21.5 / 18.8; M = 1024 qkv 35.0 / 31.6 (same slices; bit-identical)
     if constexpr (sizeof(T) == 2) {
-        if (p.tile_cfg == 13 && !p.conv) return launch_cfg<T, 128, 128, 2, 2, 3>(p, batch, st);
+        if (p.tile_cfg == 13 && !p.conv) return launch_cfg<T, 128, 128, 2, 4, 3>(p, batch, st);
         if (p.tile_cfg == 14 && !p.conv) return launch_cfg<T, 128, 128, 2, 2, 4>(p, batch, st);
         // transformer passes (tile_cfg 12) that end up here unsliced - 1024 < M < 2048, or N not a 256-tile width - take the third stage as well when
         // all their workgroups fit the chip at once
         if (p.tile_cfg == 12 && !p.conv && batch == 1 && p.split_tiles == 0 && p.K >= 6 * 64 &&
-            (long)((p.M + 127) / 128) * ((p.N + 127) / 128) <= 256) return launch_cfg<T, 128, 128, 2, 2, 3>(p, batch, st);
+            (long)((p.M + 127) / 128) * ((p.N + 127) / 128) <= 256) return launch_cfg<T, 128, 128, 2, 4, 3>(p, batch, st);
     }
 #endif
     return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
