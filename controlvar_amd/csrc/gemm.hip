@@ -398,6 +398,9 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
 #ifndef CVAR_GEMM_XB
 #define CVAR_GEMM_XB 1
 #endif
+#ifndef CVAR_GEMM_128_W8
+#define CVAR_GEMM_128_W8 1
+#endif
     // M16: the K loop runs on v_mfma_f32_16x16x32_bf16 (two per 32x32x16's worth of flops, 16 cycles each).  Same fragment bytes out of LDS,
     // but an accumulator register is read and written once per 32 k instead of once per 16: the chip is POWER-limited under this kernel
     // (all-zero operands run the identical instruction stream 30 % faster, profiles/r03_gemm_power.txt) and the narrower tile moves less
@@ -1367,6 +1370,17 @@ template <typename T>
 static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     // small-M problems (early scales, ada_lin) use a 64-row tile to put more blocks on the chip
     if (p.M <= 64) return launch_cfg<T, 64, 128, 1, 4>(p, batch, st);
+    // the 128x128 tile: EIGHT waves (64x32 per wave, two per SIMD) for plain bf16 GEMMs since the second half of round 4 - a wave of the 4-wave form issues 8 DMA
+    // pieces per 32 MFMAs with nothing on its SIMD to cover them; tools/gemm_iso.py 8192: 921 / 860 / 910 / 734 -> 1012 / 1118 / 1110 / 891 TFLOP/s (qkv / fc1 / fc2 /
+    // proj), bit-identical.  fp32 and the implicit-GEMM convs keep four waves.
+    auto launch_128 = [&](const GemmParams& q, int nb, hipStream_t s) -> int {
+#if CVAR_TU_PLAIN && !CVAR_TU_CONV
+        if constexpr (sizeof(T) == 2) {
+            if (CVAR_GEMM_128_W8 && !q.conv && q.tile_cfg != 26) return launch_cfg<T, 128, 128, 2, 4>(q, nb, s);
+        }
+#endif
+        return launch_cfg<T, 128, 128, 2, 2>(q, nb, s);
+    };
     // channel counts of the VQVAE (160, 320) are multiples of 160 but not of 128: a 160-wide tile wastes no MFMA work
     // few output channels (the decoder's conv_out: 160 -> 3): a 256x32 tile wastes 10x instead of 42x of the MFMA work of a
     // 128-wide tile; the kernel is then bound by streaming the activations, as it should be
@@ -1431,7 +1445,7 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
                 if (p.tile_cfg == 12 && !p.conv && t128 <= 256 && p.K >= 6 * 64) return launch_cfg<T, 128, 128, 2, 4, 3>(p, batch, st);
             }
 #endif
-            return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
+            return launch_128(p, batch, st);
         }
     }
     if (ov != 0 && (p.M >= 2048 || (p.split_tiles > 0 && p.M > 1024)) && n_ok) return launch_cfg<T, 256, 256, 2, 4>(p, batch, st);
@@ -1448,7 +1462,7 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
             (long)((p.M + 127) / 128) * ((p.N + 127) / 128) <= 256) return launch_cfg<T, 128, 128, 2, 4, 3>(p, batch, st);
     }
 #endif
-    return launch_cfg<T, 128, 128, 2, 2>(p, batch, st);
+    return launch_128(p, batch, st);
 }
 
 // gemm_skinny.hip: the weight-streaming small-M kernel and the row-finishing split-K reduction (+ adaLN of the next op)

@@ -83,7 +83,8 @@ typedef struct {
      *                 reduction launch (long K: a few K slices finished row-wise).  Same math; the fp32 summation order then depends on the plan chosen for
      *                 (M, N, K), so callers that promise bit-identical rows across batch sizes (the VQVAE) stay on 0.  The transformer's passes use 12
      *                 (which also gives mid-size calls - 64 < M <= 1024, or one round of 128x128 tiles - the three-LDS-stage tile instance);
-     *                 13 / 14: the 128x128 tile with three / four LDS stages wherever that tile is chosen (A/B measurements);
+     *                 13 / 14: the 128x128 tile with three / four LDS stages wherever that tile is chosen (A/B measurements); 26: the 128x128 tile on four
+     *                 waves instead of eight (the form before the second half of round 4; A/B measurements, bit-identical);
      *   stagger       > 0: the first workgroup of every CU starts delayed by up to this many shader cycles (by its index), which
      *                 de-phases the output bursts of equally long tiles; 0: off.  Never changes results. */
     void* ws; int64_t ws_bytes;
