@@ -401,6 +401,11 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
 #ifndef CVAR_GEMM_128_W8
 #define CVAR_GEMM_128_W8 1
 #endif
+// cost of a round of 128x128 tiles against a round of 256x256 tiles in launch_typed's partial-round rule.  Re-swept with the eight-wave 128x128 tile (generation
+// latency at B = 4 ... 64, one box): 0.45 loses 10-14 % from B = 8 on, 0.52 1-2 %, 0.70 / 0.80 within 1 % of 0.61 - kept.
+#ifndef CVAR_GEMM_C128
+#define CVAR_GEMM_C128 0.61
+#endif
     // M16: the K loop runs on v_mfma_f32_16x16x32_bf16 (two per 32x32x16's worth of flops, 16 cycles each).  Same fragment bytes out of LDS,
     // but an accumulator register is read and written once per 32 k instead of once per 16: the chip is POWER-limited under this kernel
     // (all-zero operands run the identical instruction stream 30 % faster, profiles/r03_gemm_power.txt) and the narrower tile moves less
@@ -1437,7 +1442,7 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     // K order per output is the same for both tiles: bit-identical results.
     if (ov == -1 && sizeof(T) == 2 && p.split_tiles == 0 && batch == 1 && n_ok && p.M >= 2048) {
         const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256), t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-        const double c256 = (double)((t256 + 255) / 256), c128 = 0.61 * (double)((t128 + 511) / 512);
+        const double c256 = (double)((t256 + 255) / 256), c128 = CVAR_GEMM_C128 * (double)((t128 + 511) / 512);
         if (c128 < 0.97 * c256) {
 #if CVAR_TU_PLAIN && !CVAR_TU_CONV
             // one round of at most 256 workgroups in a transformer pass: three LDS stages (see cvar_gemm: a workgroup of this regime is latency-bound)
