@@ -266,6 +266,7 @@ def test_gemm_fused_gelu_forward_keeps_preactivation_and_gelu_grad_epilogue(gpu_
                                             (50, 128, 256, 128, 256),             # fewer tokens than two K steps
                                             (777, 256, 384, 256, 384),            # Kk ends in the middle of a 256-wide column tile (ldb == Kk: the idle half reads the next token's row)
                                             (1360, 384, 128, 392, 144),           # a single half-filled column tile, NaN columns right behind the window
+                                            (1360, 512, 768, 520, 768),           # two row tiles of the 256-row (eight-wave) instance, token split, lda > Nn
                                             (43520, 1536, 1536, 1536, 1536),      # the d24 proj weight gradient at B = 32
                                             (10880, 1920, 1920, 1920, 1920)])     # d30 (C = 1920 = 7.5 column tiles) at B = 8
 def test_gemm_tn_weight_gradient(gpu_device, T, Nn, Kk, lda, ldb):
