@@ -27,7 +27,7 @@ def one_tn(case):
     """cvar_gemm_tn: dW = A^T B on token-major operands (column windows of wider NaN rows), any token count"""
     g = torch.Generator().manual_seed(case)
     T = rng.choice([1, 31, 32, 33, 200, 777, 1360, 2999])
-    Nn, Kk = rng.choice([128, 256, 384]), rng.choice([128, 256, 384, 512])
+    Nn, Kk = rng.choice([128, 256, 384, 512]), rng.choice([128, 256, 384, 512])
     lda, ldb = Nn + rng.choice([0, 8, 128]), Kk + rng.choice([0, 16, 256])
     a = torch.randn(T, Nn, generator=g); b = torch.randn(T, Kk, generator=g)
     Aw = torch.full((T, lda), float('nan')); Aw[:, :Nn] = a
