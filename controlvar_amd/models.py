@@ -511,6 +511,9 @@ class VQVAE(nn.Module):
 # =====================================================================================
 # ControlVAR / VAR
 # =====================================================================================
+FUSE_LN_BELOW = 4097       # passes with fewer rows ask proj / fc2 for the next op's adaLN (see _blocks_and_head); 2048 -> 4097: B = 8 63.0 -> 62.3 ms, B = 16 106.7 -> 106.0
+
+
 class ControlVAR(nn.Module):
     """Joint (control, image) next-scale transformer (reference: models/control_var.py:23-689).
 
@@ -780,7 +783,7 @@ class ControlVAR(nn.Module):
         # Small passes (early scales, small batches): proj / fc2 also produce the adaLN input of the op that follows (cvar_gemm_desc.ln_out) - their split-K
         # reduction finishes rows, so LayerNorm + modulation ride in that launch instead of a cvar_ln_modulate of their own (same bits).  Large passes keep the
         # separate launch: their GEMMs finish tiles, not rows.
-        fuse_ln = M < 2048            # calls up to here can be sliced along K (small-M split-K, or the long-K rule of 256x256 tiles for 1024 < M < 2048)
+        fuse_ln = M < FUSE_LN_BELOW   # calls up to here can be sliced along K (small-M split-K, the long-K rule of the 256x256 tiles); an unsliced call launches cvar_ln_modulate itself
         ah = cfg.depth * 6 * C
         ops.ln_modulate(x, ada, 2 * C, 4 * C, n_ada, l, u, M, C, cfg.norm_eps)
         for i in range(cfg.depth):

@@ -6,6 +6,7 @@ import torch
 from controlvar_amd import models, ops
 ops.GEMM_TILE_CFG = int(os.environ.get('ISO_CFG', '0'))
 ops.SMALL_M_KERNEL = os.environ.get('SMALLM', '1') != '0'        # 0: the transformer's small passes stay on the LDS-tiled kernels + split-K      # 6: every eligible 3x3 conv on the LDS-halo kernel whatever the grid size
+models.FUSE_LN_BELOW = int(os.environ.get('FUSE_LN_BELOW', models.FUSE_LN_BELOW))
 dev = torch.device('cuda:0')
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 vae = models.build_vae(ch=160).to(dev)
