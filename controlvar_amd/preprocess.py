@@ -15,8 +15,8 @@ Here JPEG decoding stays on the host; everything after it runs on the GPU from t
 * ``cvar_crop_flip_normalize`` / ``cvar_ignore_mask`` finish the sample.
 
 Random choices (crop offset, flip) are inputs: the caller owns the RNG, as with the reference's ``random`` module.
-Segmentation conditions (imagenetC.py:15-37): uncompressed COCO run lengths or decoded masks -> colour map on the device (cvar_rle_paint);
-the compressed RLE *string* of pycocotools is not decoded here (see _runs_of).
+Segmentation conditions (imagenetC.py:15-37): COCO RLE annotations (compressed strings as they lie in the reference's JSON files,
+uncompressed run lengths, or decoded masks) -> colour map on the device (cvar_rle_paint); see _runs_of for what pins each form.
 """
 from __future__ import annotations
 
@@ -152,16 +152,28 @@ def preprocess_pair(image_u8, cond_u8, image_size: int = 256, mid_res: float = 1
     return outs[0], outs[1]
 
 
-def ignore_masks(cond, patch_nums: Sequence[int], first_masked_scale: int = 5) -> Dict[str, object]:
-    """imagenetC.py:152-178 for a batch of segmentation-mask conditions (B, 3, H, W): {'ignore_mask', 'ignore_mask_'} (B, L)"""
+def ignore_masks(cond, patch_nums: Sequence[int], first_masked_scale: int = 5, separator: bool = False) -> Dict[str, object]:
+    """imagenetC.py:152-178 for a batch of segmentation-mask conditions (B, 3, H, W): {'ignore_mask', 'ignore_mask_'} (B, L).
+    ``separator`` (:158,:169-170): every half-scale but the first pair starts with one extra always-kept token (L = 1378)."""
     import torch
     from . import ops
     B, _, H, W = cond.shape
     L = sum(2 * p * p for p in patch_nums)
     out = {}
+    if separator:
+        pos, at = [], 0
+        for si, p in enumerate(patch_nums):
+            for _half in range(2):
+                at += 1 if si else 0
+                pos += range(at, at + p * p)
+                at += p * p
+        pos = torch.tensor(pos, dtype=torch.int64, device=cond.device)
+        L_sep = at
     for key, image_first in (('ignore_mask', 0), ('ignore_mask_', 1)):
         t = torch.empty(B, L, dtype=torch.float32, device=cond.device)
         ops.ignore_mask(cond.contiguous(), B, H, W, patch_nums, first_masked_scale, image_first, t, L)
+        if separator:                                                      # placement only: the separator tokens are never ignored
+            t = torch.ones(B, L_sep, dtype=torch.float32, device=cond.device).index_copy_(1, pos, t)
         out[key] = t
     return out
 
@@ -186,21 +198,82 @@ def runs_from_mask(mask) -> list:
     return ([0] + runs) if flat.size and flat[0] else runs
 
 
+_WARNED_RLE_STRING = False
+
+
+def rle_from_string(s) -> list:
+    """COCO compressed RLE string -> run lengths (pycocotools common/maskApi.c rleFrString, restated from the published algorithm:
+    6-bit characters offset by 48, 5 payload bits + continuation bit 0x20, sign-extended by bit 0x10 of the last group, and every
+    value after the third is a delta against the value two places back).  UNPINNED THIRD-PARTY FORMAT: pycocotools is neither vendored
+    by the reference nor installed in the build image, so the known answers in tests/test_preprocess.py are hand-derived."""
+    if isinstance(s, str):
+        s = s.encode('ascii')
+    cnts, p = [], 0
+    while p < len(s):
+        x, k, more = 0, 0, 1
+        while more:
+            c = s[p] - 48
+            x |= (c & 0x1f) << (5 * k)
+            more = c & 0x20
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if len(cnts) > 2:
+            x += cnts[-2]
+        cnts.append(x)
+    return cnts
+
+
+def rle_to_string(cnts: Sequence[int]) -> str:
+    """inverse of rle_from_string (maskApi.c rleToString); used by the tests and tools/coco_rle_string.py"""
+    out = bytearray()
+    for i, x in enumerate(cnts):
+        x = int(x)
+        if i > 2:
+            x -= int(cnts[i - 2])
+        more = True
+        while more:
+            c = x & 0x1f
+            x >>= 5
+            more = (x != -1) if (c & 0x10) else (x != 0)
+            if more:
+                c |= 0x20
+            out.append(c + 48)
+    return out.decode('ascii')
+
+
 def _runs_of(segmentation) -> Tuple[list, int, int]:
-    """a segmentation is a decoded (h, w) mask, or a COCO RLE dict with UNCOMPRESSED counts (a list of run lengths, column-major,
-    zeros first - the form SAM-style annotation writers emit before string compression).  The compressed counts STRING is pycocotools'
-    own wire format (maskApi.c rleFrString); that dependency is absent here and its codec could not be pinned against it, so the
-    product does not decode it (round 4): decode with pycocotools where the annotations are prepared - the reference needs it
-    installed anyway - or convert once with tools/coco_rle_string.py, which is an unpinned convenience and says so."""
+    """a segmentation is a decoded (h, w) mask, a COCO RLE dict with UNCOMPRESSED counts (a list of run lengths, column-major, zeros
+    first), or - the on-disk form the reference reads (imagenetC.py:20-21: json -> ``mask_utils.decode``) - an RLE dict whose counts
+    are pycocotools' compressed STRING.  Strings go through pycocotools itself when it is importable (the pinned route, and the
+    reference needs it installed anyway); otherwise through ``rle_from_string`` with a one-time warning that the codec is an unpinned
+    restatement of a third-party wire format."""
+    global _WARNED_RLE_STRING
     if isinstance(segmentation, np.ndarray) or (hasattr(segmentation, 'shape') and not isinstance(segmentation, dict)):
         m = np.asarray(segmentation)
         return runs_from_mask(m), int(m.shape[0]), int(m.shape[1])
     h, w = segmentation['size']
     counts = segmentation['counts']
     if isinstance(counts, (str, bytes)):
-        raise TypeError('compressed COCO RLE strings are not decoded by controlvar_amd (parity with pycocotools cannot be pinned here): '
-                        'pass pycocotools.mask.decode(segmentation) or uncompressed counts (tools/coco_rle_string.py converts)')
-    runs = [int(c) for c in counts]
+        try:
+            from pycocotools import mask as mask_utils                         # absent in the build image
+        except ImportError:
+            mask_utils = None
+        if mask_utils is not None:
+            m = np.asarray(mask_utils.decode(segmentation))
+            return runs_from_mask(m), int(m.shape[0]), int(m.shape[1])
+        if not _WARNED_RLE_STRING:
+            import warnings
+            warnings.warn('controlvar_amd.preprocess: decoding a compressed COCO RLE string with the built-in restatement of pycocotools\' '
+                          'maskApi.c (unpinned third-party format: pycocotools is not installed, so it could not be checked against it)',
+                          RuntimeWarning, stacklevel=3)
+            _WARNED_RLE_STRING = True
+        runs = rle_from_string(counts)
+        if any(r < 0 for r in runs):
+            raise ValueError('malformed COCO RLE string (negative run length)')
+    else:
+        runs = [int(c) for c in counts]
     if sum(runs) != h * w:
         raise ValueError(f'RLE covers {sum(runs)} pixels, size says {h}x{w}')
     return runs, h, w

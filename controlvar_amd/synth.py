@@ -138,3 +138,25 @@ def synth_photo_pair(h: int, w: int, seed: int):
         m = (np.mgrid[0:512, 0:512][0] - cy) ** 2 + (np.mgrid[0:512, 0:512][1] - cx) ** 2 < r * r
         cond[m] = rng.integers(0, 5, 3) * 64
     return img, cond
+
+
+def synth_annotations(seed: int, n: int = 6, size: int = 512):
+    """SAM-style segmentation annotations (imagenetC.py:15-29 consumes a list of these): n ellipses on a size x size canvas, each as
+    {'area', 'segmentation': {'size', 'counts': uncompressed column-major run lengths}, '_mask': the decoded (size, size) uint8 mask}.
+    Shared by tests/golden/make_golden.py (which feeds the decoded masks to the reference's own process_anns) and the tests."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:size, 0:size]
+    anns = []
+    for _ in range(n):
+        cy, cx = rng.integers(40, size - 40, 2)
+        ry, rx = rng.integers(10, 140, 2)
+        m = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1).astype(np.uint8)
+        flat = m.T.reshape(-1)                                       # column-major
+        change = np.flatnonzero(np.diff(flat)) + 1
+        edges = np.concatenate([[0], change, [flat.size]])
+        runs = np.diff(edges).tolist()
+        if flat[0] == 1:
+            runs = [0] + runs
+        anns.append({'area': int(m.sum()), 'segmentation': {'size': [size, size], 'counts': runs}, '_runs': runs, '_mask': m})
+    return anns

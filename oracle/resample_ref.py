@@ -62,28 +62,32 @@ def preprocess_pair(image: np.ndarray, cond: np.ndarray, image_size=256, mid_res
     return outs[0], outs[1]
 
 
-def ignore_masks(cond: np.ndarray, patch_nums, first_masked_scale=5):
-    """cond (3, H, W) float32 -> (ignore_mask, ignore_mask_) of length sum 2 pn^2 (imagenetC.py:152-178; torch 'nearest' index rule)"""
+def ignore_masks(cond: np.ndarray, patch_nums, first_masked_scale=5, separator=False):
+    """cond (3, H, W) float32 -> (ignore_mask, ignore_mask_) of length sum 2 pn^2 (imagenetC.py:152-178; torch 'nearest' index rule);
+    separator: one kept token in front of every half-scale but the first pair (:158,:169-170).  Pinned by tests/golden/preprocess.npz,
+    which make_golden.py records from the reference's own statements (lifted out of the file by ast)."""
     _, H, W = cond.shape
     bg = (cond[0] + cond[1] + cond[2]) == np.float32(-3.0)
     keep = np.where(bg, 0.0, 1.0).astype(np.float32)
     a, b = [], []
     for si, pn in enumerate(patch_nums):
-        ones = np.ones(pn * pn, np.float32)
+        ones = np.ones(pn * pn + (1 if (separator and si) else 0), np.float32)
         if si < first_masked_scale:
             a += [ones, ones]; b += [ones, ones]
         else:
             sy = np.minimum(np.floor(np.arange(pn, dtype=np.float32) * (np.float32(H) / np.float32(pn))).astype(np.int64), H - 1)
             sx = np.minimum(np.floor(np.arange(pn, dtype=np.float32) * (np.float32(W) / np.float32(pn))).astype(np.int64), W - 1)
             m = keep[sy][:, sx].reshape(-1)
+            if separator:
+                m = np.concatenate([np.ones(1, np.float32), m])
             a += [m, ones]; b += [ones, m]
     return np.concatenate(a), np.concatenate(b)
 
 
 def process_anns(anns, image_size, colormap):
     """datasets/imagenetC.py:15-29 with UNCOMPRESSED run lengths (or decoded masks) expanded explicitly, column-major, numpy only.
-    pycocotools' compressed string codec is outside the product and outside this oracle (absent dependency, parity unpinned -
-    tools/coco_rle_string.py)."""
+    Pinned by tests/golden/preprocess.npz (the reference's own process_anns text run on the decoded masks).  pycocotools' compressed
+    string codec is outside this oracle (absent dependency, parity unpinned)."""
     mask = np.zeros((image_size, image_size, 3))
     for ann in anns:
         if ann['area'] < 5000:

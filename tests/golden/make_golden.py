@@ -451,20 +451,46 @@ def case_preprocess():
             out[f'{tag}_{name}_sha'] = np.array(hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest())
             out[f'{tag}_{name}_shape'] = np.array(arr.shape)
             out[f'{tag}_{name}_sample'] = arr[::37, ::29].copy()
-    # ignore masks by the reference's own tensor code (imagenetC.py:152-178) on a normalised 256x256 condition
+    # ignore masks and annotation painting by the reference's OWN TEXT: datasets/imagenetC.py cannot be imported (torchvision,
+    # pycocotools, tqdm are absent), so - as case_checkpoint does for load_var_weight - the function definitions (:15-37) and the
+    # ``if cond_type == 'mask': ... else: ...`` statement of __getitem__ (:152-181) are lifted out of the file by ast at generation
+    # time and compiled unmodified.  The only stand-in is ``mask_utils.decode`` (pycocotools, third party): the synthetic annotations
+    # carry their DECODED masks as ``segmentation``, so decode is the identity on arrays.
+    import ast, types
+    src = open('/root/reference/datasets/imagenetC.py').read()
+    tree = ast.parse(src)
+    fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ('process_anns', 'create_color_map')]
+    assert [f.name for f in fns] == ['process_anns', 'create_color_map'] and fns[0].lineno == 15 and fns[1].lineno == 31
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == 'ImagenetCDataset'][0]
+    getitem = [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == '__getitem__'][0]
+    blocks = [n for n in getitem.body if isinstance(n, ast.If) and any(isinstance(x, ast.Name) and x.id == 'ignore_mask' for x in ast.walk(n))]
+    assert len(blocks) == 1 and blocks[0].lineno == 152, [b.lineno for b in blocks]
+    wrapper = ast.parse('def ignore_block(self, cond, cond_type):\n    pass\n    return ignore_masks, ignore_masks_').body[0]
+    wrapper.body[0] = blocks[0]
+    mod = ast.fix_missing_locations(ast.Module(body=fns + [wrapper], type_ignores=[]))
+    ns = dict(np=np, torch=torch, F=F, mask_utils=types.SimpleNamespace(decode=lambda seg: np.asarray(seg, dtype=np.uint8)))
+    exec(compile(mod, 'imagenetC.py(ast)', 'exec'), ns)
+    from controlvar_amd.synth import synth_annotations
+    colormap = ns['create_color_map']()
+    out['colormap'] = colormap
+    for seed in (2, 3, 4):
+        anns = [{'area': a['area'], 'segmentation': a['_mask']} for a in synth_annotations(seed, n=8)]
+        canvas = ns['process_anns'](anns, 512, colormap)
+        assert canvas.max() > 0 and canvas.dtype == np.float64
+        out[f'anns{seed}_canvas'] = canvas.astype(np.uint8)                       # imagenetC.py:144 casts the same way
+        out[f'anns{seed}_kept'] = np.array(sum(a['area'] >= 5000 for a in anns))
     _, cond = preproc_inputs(375, 500, 0)
     c = np.asarray(Image.fromarray(cond).resize((256, 256), Image.NEAREST)).astype(np.float32)
     ct = ((torch.from_numpy(c).permute(2, 0, 1) / 255.0) - 0.5) / 0.5
-    ignore_mask = torch.ones_like(ct.sum(dim=0))
-    ignore_mask[ct.sum(dim=0) == -3] = 0
-    a, b = [], []
-    for si, pm in enumerate(PN):
-        if si < 5:
-            a += [torch.ones(pm ** 2), torch.ones(pm ** 2)]; b += [torch.ones(pm ** 2), torch.ones(pm ** 2)]
-        else:
-            m_ = F.interpolate(ignore_mask[None, None], (pm, pm), mode='nearest').permute((0, 2, 3, 1)).reshape((-1,))
-            a += [m_, torch.ones(pm ** 2)]; b += [torch.ones(pm ** 2), m_]
-    save('preprocess', ign_cond=ct, ignore_mask=torch.concat(a), ignore_mask_=torch.concat(b), **out)
+    res = {}
+    for sep in (False, True):
+        me = types.SimpleNamespace(v_patch_nums=PN, separator=sep)
+        a, b = ns['ignore_block'](me, ct, 'mask')
+        a2, b2 = ns['ignore_block'](me, ct, 'depth')
+        assert float(a2.min()) == 1.0 and a2.shape == a.shape == b.shape == b2.shape == ((1378,) if sep else (1360,))
+        res['ignore_mask' + ('_sep' if sep else '')] = a
+        res['ignore_mask_' + ('_sep' if sep else '')] = b
+    save('preprocess', ign_cond=ct, **res, **out)
 
 
 def case_sa_block():

@@ -86,6 +86,9 @@ def test_oracle_ignore_masks_equal_reference_tensor_code():
     np.testing.assert_array_equal(a, g['ignore_mask'])
     np.testing.assert_array_equal(b, g['ignore_mask_'])
     assert a.shape == (1360,) and 0 < a.mean() < 1
+    a, b = R.ignore_masks(np.asarray(g['ign_cond']), PN, separator=True)
+    np.testing.assert_array_equal(a, g['ignore_mask_sep'])
+    np.testing.assert_array_equal(b, g['ignore_mask__sep'])
 
 
 @pytest.mark.gpu
@@ -118,6 +121,9 @@ def test_device_ignore_masks(gpu_device):
     np.testing.assert_array_equal(out['ignore_mask_'][0].cpu().numpy(), g['ignore_mask_'])
     a1, _ = R.ignore_masks(-np.ones((3, 256, 256), np.float32), PN)
     np.testing.assert_array_equal(out['ignore_mask'][1].cpu().numpy(), a1)
+    sep = P.ignore_masks(batch, PN, separator=True)                              # imagenetC.py:158,169-170
+    np.testing.assert_array_equal(sep['ignore_mask'][0].cpu().numpy(), g['ignore_mask_sep'])
+    np.testing.assert_array_equal(sep['ignore_mask_'][0].cpu().numpy(), g['ignore_mask__sep'])
     assert float(out['ignore_mask'][2].min()) == 1.0
     from controlvar_amd import ops
     with pytest.raises(Exception):
@@ -125,22 +131,24 @@ def test_device_ignore_masks(gpu_device):
 
 
 # ---------------------------------------------------------------- segmentation condition: RLE -> colour map (imagenetC.py:15-37)
-def _random_anns(seed, n=6, size=512):
-    rng = np.random.default_rng(seed)
-    yy, xx = np.mgrid[0:size, 0:size]
-    anns = []
-    for k in range(n):
-        cy, cx = rng.integers(40, size - 40, 2)
-        ry, rx = rng.integers(10, 140, 2)
-        m = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1).astype(np.uint8)
-        flat = m.T.reshape(-1)                                       # column-major
-        change = np.flatnonzero(np.diff(flat)) + 1
-        edges = np.concatenate([[0], change, [flat.size]])
-        runs = np.diff(edges).tolist()
-        if flat[0] == 1:
-            runs = [0] + runs
-        anns.append({'area': int(m.sum()), 'segmentation': {'size': [size, size], 'counts': runs}, '_runs': runs, '_mask': m})
-    return anns
+from controlvar_amd.synth import synth_annotations as _random_anns          # noqa: E402  (the generator make_golden.py feeds to the reference's text)
+
+
+def _as_masks(anns):
+    return [{'area': a['area'], 'segmentation': a['_mask']} for a in anns]
+
+
+@pytest.mark.parametrize('seed', [2, 3, 4])
+def test_oracle_process_anns_equals_the_references_own_text(seed):
+    """fixture = datasets/imagenetC.py:15-37 lifted out of the reference file by ast and run on the decoded masks (make_golden.case_preprocess)"""
+    g = golden('preprocess')
+    assert np.array_equal(P.create_color_map(), g['colormap'])
+    anns = _random_anns(seed, n=8)
+    assert sum(a['area'] >= 5000 for a in anns) == int(g[f'anns{seed}_kept']) >= 2
+    for form in (_as_masks(anns), anns):                                     # decoded masks (what the reference saw) and run lists
+        got = R.process_anns(form, 512, P.create_color_map())
+        assert got.dtype == np.float64
+        np.testing.assert_array_equal(got.astype(np.uint8), g[f'anns{seed}_canvas'])
 
 
 def test_uncompressed_rle_semantics_against_an_independent_implementation():
@@ -173,26 +181,40 @@ def test_uncompressed_rle_semantics_against_an_independent_implementation():
     assert P.create_color_map().shape == (124, 3) and tuple(P.create_color_map()[0]) == (0, 0, 64)
 
 
-def test_compressed_rle_strings_are_refused_by_the_product_and_the_tool_matches_hand_derived_answers():
-    """The product does not decode pycocotools' compressed strings (unpinnable here).  tools/coco_rle_string.py is a labelled convenience;
-    its known answers below were worked out BY HAND from the published format (6-bit groups + 48, low 5 bits payload, 0x20 = more,
-    sign = bit 0x10 of the last group, deltas against the value two back from the fourth value on):
+def test_compressed_rle_strings_decode_with_a_warning_and_match_hand_derived_answers():
+    """The reference's annotation files hold pycocotools' compressed strings (imagenetC.py:20-21).  The product decodes them - through
+    pycocotools when installed, else through its own restatement with ONE RuntimeWarning (unpinned third-party format).  Known answers
+    worked out BY HAND from the published format (6-bit groups + 48, low 5 bits payload, 0x20 = more, sign = bit 0x10 of the last group,
+    deltas against the value two back from the fourth value on):
       [0, 4]          -> '0' '4'
       [5, 3, 40, 2]   -> '5' '3', then 40 as itself (third value, no delta): 40 = 0b01000 + 32 * 1 -> groups 8|0x20 = 40 -> 'X', then 1 -> '1';
                          then 2 - 3 = -1 -> one group 0b11111 (sign bit set, rest all ones) = 31 -> 'O'
       [0, 0, 0, 35]   -> '0' '0' '0', then 35 - 0 = 35 = 3 + 32 * 1 -> 3|0x20 = 35 -> 'S', then 1 -> '1'"""
     import importlib.util
-    import os
-    spec = importlib.util.spec_from_file_location('coco_rle_string', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'coco_rle_string.py'))
-    C = importlib.util.module_from_spec(spec); spec.loader.exec_module(C)
+    import warnings
     for runs, text in (([0, 4], '04'), ([5, 3, 40, 2], '53X1O'), ([0, 0, 0, 35], '000S1')):
-        assert C.rle_to_string(runs) == text and C.rle_from_string(text) == runs
+        assert P.rle_to_string(runs) == text and P.rle_from_string(text) == runs
     rng = np.random.default_rng(0)
     for _ in range(20):
         runs = rng.integers(0, 70000, rng.integers(1, 60)).tolist()
-        assert C.rle_from_string(C.rle_to_string(runs)) == runs       # deltas (negative values) and multi-character groups
-    with pytest.raises(TypeError):
-        P.annotation_colours([{'area': 9999, 'segmentation': {'size': [512, 512], 'counts': C.rle_to_string([512 * 512])}}], 512)
+        assert P.rle_from_string(P.rle_to_string(runs)) == runs       # deltas (negative values) and multi-character groups
+    spec = importlib.util.spec_from_file_location('coco_rle_string', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'coco_rle_string.py'))
+    C = importlib.util.module_from_spec(spec); spec.loader.exec_module(C)
+    assert C.rle_from_string is P.rle_from_string                      # the converter is the product's codec, not a second copy
+    anns = _random_anns(3, n=8)
+    packed = [{'area': a['area'], 'segmentation': {'size': [512, 512], 'counts': P.rle_to_string(a['_runs'])}} for a in anns]
+    want = P.annotation_colours(anns, 512)
+    have_coco = importlib.util.find_spec('pycocotools') is not None
+    P._WARNED_RLE_STRING = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        got = P.annotation_colours(packed, 512)
+        P.annotation_colours(packed, 512)
+    assert len([x for x in w if 'unpinned third-party format' in str(x.message)]) == (0 if have_coco else 1)
+    for a_, b_ in zip(got, want):
+        assert np.array_equal(a_, b_)
+    with pytest.raises(ValueError):
+        P.annotation_colours([{'area': 9999, 'segmentation': {'size': [512, 512], 'counts': P.rle_to_string([512 * 512 - 1])}}], 512)
 
 
 def test_annotation_colours_follow_the_centroid_rule():
@@ -207,7 +229,7 @@ def test_annotation_colours_follow_the_centroid_rule():
     with pytest.raises(ValueError):
         P.annotation_colours([{'area': 9999, 'segmentation': {'size': [256, 256], 'counts': [256 * 256]}}], 512)
     # decoded masks (what pycocotools.mask.decode hands the reference, imagenetC.py:21) give the same runs / colours as the run lists
-    as_masks = [{'area': a_['area'], 'segmentation': a_['_mask']} for a_ in anns]
+    as_masks = _as_masks(anns)
     e2, o2, c2 = P.annotation_colours(as_masks, 512)
     assert np.array_equal(e2, run_ends) and np.array_equal(o2, offsets) and np.array_equal(c2, colours)
     assert np.array_equal(R.process_anns(as_masks, 512, P.create_color_map()), want)
@@ -217,8 +239,15 @@ def test_annotation_colours_follow_the_centroid_rule():
 @pytest.mark.parametrize('seed', [2, 3, 4])
 def test_device_mask_painting_equals_process_anns(gpu_device, seed):
     anns = _random_anns(seed, n=8)
-    want = R.process_anns(anns, 512, P.create_color_map()).astype(np.uint8)
+    want = golden('preprocess')[f'anns{seed}_canvas']                       # the reference's own process_anns text (make_golden.case_preprocess)
+    assert np.array_equal(R.process_anns(anns, 512, P.create_color_map()).astype(np.uint8), want)
     got = P.paint_annotations(anns, 512, gpu_device).cpu().numpy()
     np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(P.paint_annotations(_as_masks(anns), 512, gpu_device).cpu().numpy(), want)
+    packed = [{'area': a['area'], 'segmentation': {'size': [512, 512], 'counts': P.rle_to_string(a['_runs'])}} for a in anns]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        np.testing.assert_array_equal(P.paint_annotations(packed, 512, gpu_device).cpu().numpy(), want)
     empty = P.paint_annotations([a for a in anns if a['area'] < 5000], 512, gpu_device)
     assert int(empty.max()) == 0
