@@ -160,25 +160,8 @@ template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_wa
 #ifndef CVAR_ATTN_Q64_MINL
 #define CVAR_ATTN_Q64_MINL 192      // l = 200 (one workgroup of 256 instead of two of 128): 0.315 -> 0.308 ms per call at B = 128
 #endif
-// round 4: wave-internally pipelined form of the prescaled kernel - built, correct (35 tests, fuzz 600 / 600), 16 % SLOWER at the last scale
-// (profiles/r04_attn_pipe_rejected.txt); compiled only with -DCVAR_ATTN_PIPE=1
-#ifndef CVAR_ATTN_PIPE
-#define CVAR_ATTN_PIPE 0
-#endif
-// timing ablations of attn_mfma_bf16_kernel (tools/build_variant.py attn.hip ablN -DATTN_ABL=N; WRONG results): 1 no v_exp, 2 no row sum, 3 no row maximum after the
-// first tile, 4 no K/V tile traffic after the first tile, 5 no barriers, 6 a quarter of the PV MFMAs
-#ifndef ATTN_ABL
-#define ATTN_ABL 0
-#endif
-// CVAR_ATTN_DMA = 1: K / V tiles by buffer_load ... lds into two tile pairs, one barrier per tile - built, correct (35 tests, fuzz 400 / 400), exactly NEUTRAL
-// (profiles/r04_attn_ablation.txt): what the ablation attributed to the tile traffic is the bytes a CU pulls (~13 B/clk/CU at the last scale), not the
-// register round trip.  Compiled out by default.
-#ifndef CVAR_ATTN_DMA
-#define CVAR_ATTN_DMA 0
-#endif
-#if CVAR_ATTN_PIPE
-template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma_bf16_pipe_kernel(const AttnParams p);
-#endif
+// (round-4 experiments - the wave-internally pipelined form, K / V tiles by LDS-DMA, the timing ablations - are not in this file any more:
+// experiments/README.md lists the commits that hold them and the profiles/ records with their numbers)
 
 // impl: 0 = auto (MFMA flash kernel for bf16, row-wise exact kernel for fp32), 1 = row-wise
 template <typename P>
@@ -230,14 +213,6 @@ static int cvar_attention_impl(const void* qkv, const void* q, int dtype, int R,
         const long nblk = (long)cdiv(l, 128) * H * R;
         if (nblk > 0x7fffffffL) return CVAR_EUNSUPPORTED;
         const dim3 grid((unsigned)nblk), block(256);
-#if CVAR_ATTN_PIPE
-        if (qpre) {
-            if (holes) hipLaunchKernelGGL((attn_mfma_bf16_pipe_kernel<true>), grid, block, 0, as_stream(stream), p);
-            else hipLaunchKernelGGL((attn_mfma_bf16_pipe_kernel<false>), grid, block, 0, as_stream(stream), p);
-            CVAR_CHECK_LAUNCH();
-            return CVAR_OK;
-        }
-#endif
         // prescaled queries, long scales: 64 queries per wave (K / V fragments, tiles and barriers shared by two query groups)
         // (only where the last 256-query workgroup is nearly full: l = 512 runs 1.371 -> 1.285 ms per call at B = 128, l = 338 - 82 queries in its second workgroup -
         //  0.685 -> 0.82 ms and stays on the 128-query kernel; profiles/r04_attn_ablation.txt)
@@ -339,20 +314,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
     float m = -INFINITY;
     const float c2 = p.scale * 1.4426950408889634f;
-#ifdef CVAR_ATTN_MFMA_SUM
-    // (build-time experiment, OFF: -DCVAR_ATTN_MFMA_SUM)  Row sums on the matrix pipe: a third accumulator block whose A operand is
-    // "V^T" with one row of ones gives osum[0] (lanes with hi == 0) = sum_k P[k][q] for query q = lane & 31; 4 extra MFMAs per tile
-    // replace 32 v_add_f32 per lane (166 VGPRs, still 3 waves per SIMD).  Measured 2.5 % SLOWER (599 vs 615 TFLOP/s at the last scale,
-    // profiles/r02_attn_mfma_sum_ab.txt): a wave's MFMA and VALU phases do not overlap each other, so moving work between the pipes
-    // only pays if the total issue time drops.
-    f32x16_t osum;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) osum[i] = 0.f;
-    const short one_bf = lrow == 0 ? (short)0x3f80 : (short)0;               // bf16 1.0 in row 0 of the block, zeros elsewhere
-    const bf16x8_t ones = {one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf, one_bf};
-#else
     float lsum = 0.f;
-#endif
 
     // One KV tile.  MASK is a compile-time flag: tiles that every query of the wave sees completely (all but the last one at
     // inference, all but the level-boundary ones under the training mask) run without any per-score compare / select - left
@@ -389,11 +351,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const float m_new = fmaxf(m, tmax * c2);            // c2 > 0; finite from the first tile on (key 0 is always visible)
         if (!__all(m_new == m)) {                           // rescale only when some row's running max moved (exact skip)
             const float alpha = __builtin_amdgcn_exp2f(m - m_new);
-#ifdef CVAR_ATTN_MFMA_SUM
-            osum[0] *= alpha;
-#else
             lsum *= alpha;
-#endif
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -409,9 +367,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     pr[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][8 * t + j], c2, -m));
-#ifndef CVAR_ATTN_MFMA_SUM
                     lsum += pr[j];
-#endif
                 }
                 pf[kb][t] = pack_bf16x8(pr);
             }
@@ -428,12 +384,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     const bf16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][t], o[db], 0, 0, 0);
                 }
-#ifdef CVAR_ATTN_MFMA_SUM
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int t = 0; t < 2; ++t) osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[kb][t], osum, 0, 0, 0);
-#endif
         __syncthreads();
     };
     typedef std::integral_constant<bool, true> MaskOn;
@@ -445,11 +395,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int wg_min_kv = range_full_prefix(p, p.q_off + min((int)blockIdx.x * 128, p.l - 1), p.q_off + min(p.l, (int)(blockIdx.x + 1) * 128) - 1);
     for (; kt0 + KT <= wg_min_kv && kt0 < kv_end; kt0 += KT) tile(kt0, MaskOff{});
     for (; kt0 < kv_end; kt0 += KT) tile(kt0, MaskOn{});
-#ifdef CVAR_ATTN_MFMA_SUM
-    const float lsum = __shfl(osum[0], lrow, 64);            // the sum sits in row 0 of the block: register 0 of the hi == 0 lane of each query
-#else
     lsum += __shfl_xor(lsum, 32, 64);
-#endif
     if (qi < p.l) {
         if (p.lse && hi == 0) p.lse[(r * p.H + h) * (long)p.l + qi] = (m + log2f(lsum)) * 0.6931471805599453f;
         const float inv = 1.0f / lsum;
@@ -503,11 +449,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     constexpr int D = 64, KT = 64;
     // one K and one V tile, two barriers per tile.  (Two buffers and one barrier per tile: 7 % SLOWER - profiles/r03_attn_ab3_lds_double_buffer_rejected.txt.)
     constexpr int TILE_B = KT * 128;
-    // DMA form (round 4, CVAR_ATTN_DMA): K and V tiles go global -> LDS by buffer_load ... lds (no register round trip, no ds_write, nothing to wait for at the head of
-    // a tile) into TWO tile pairs; the pieces of tile t + 1 are issued at the head of tile t and one barrier per tile - behind vmcnt(0) - both publishes them and
-    // releases the pair tile t was read from.  The ablation that removed the tile traffic (profiles/r04_attn_ablation.txt) took 23 % off the last scale, 39 % at l = 128.
-    constexpr bool DMA = CVAR_ATTN_DMA != 0;
-    __shared__ __attribute__((aligned(1024))) char KVs[(DMA ? 4 : 2) * TILE_B];
+    __shared__ __attribute__((aligned(1024))) char KVs[2 * TILE_B];
     char* const Ks = KVs;
     char* const Vs = KVs + TILE_B;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -569,25 +511,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             *(bf16x8_t*)(Vs + key * 128 + ((((k_chunk >> 1) ^ (key & 3)) << 5) | ((k_chunk & 1) << 4))) = vreg[i];
         }
     };
-    // DMA pieces of a tile: 8 of K + 8 of V (1 KiB = 8 keys each), two of each per wave.  The LDS image is lane-linear (lane -> key 8 j + (lane >> 3), physical chunk
-    // lane & 7), so the swizzles of store_tile are applied on the SOURCE side: the lane fetches the logical chunk that belongs in its physical slot.
-    int dk_off[2], dv_off[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int key = 8 * (2 * w + i) + (lane >> 3), cp = lane & 7;
-        dk_off[i] = key * row_bytes + ((cp ^ ((key >> 1) & 7)) << 4);
-        dv_off[i] = key * row_bytes + ((((((cp >> 1) ^ (key & 3)) << 1) | (cp & 1))) << 4);
-    }
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    auto dma_tile = [&](int kt0, int pb) {
-        const int so = kt0 * row_bytes;
-        char* const kb_ = KVs + pb * 2 * TILE_B;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lptr_t)(kb_ + (2 * w + i) * 1024), 16, dk_off[i], so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lptr_t)(kb_ + TILE_B + (2 * w + i) * 1024), 16, dv_off[i], so, 0, 0);
-        }
-    };
     // transpose-read addressing of V: lane l of a 16-lane group points at key row (l & 15) >> 2 of a [4 keys][16 d] block, d columns
     // 4 (l & 3) .. +3; the two groups of a half-wave are the two 16-d halves of a 32-d MFMA block, the upper half-wave takes the keys
     // 4 further (the key order of an 8-key fragment is 4 hi + {0..3}, 8 + 4 hi + {0..3} - the order the swapped QK^T leaves P in)
@@ -613,14 +536,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // inference, all but the level-boundary ones under the training mask) run without any per-score compare / select - left
     // as a run-time flag the compiler if-converts the masking into ~100 extra vector instructions on every tile.
     auto tile = [&](int kt0, auto MASK, auto FIRST) {
-        const int boff = DMA ? ((kt0 / KT) & 1) * 2 * TILE_B : 0;
-        if constexpr (DMA) {
-            if (ATTN_ABL != 4 && kt0 + KT < kv_end) dma_tile(kt0 + KT, ((kt0 / KT) & 1) ^ 1);
-        } else {
-            if (ATTN_ABL != 4 || kt0 == 0) store_tile();
-            if (ATTN_ABL != 5) __syncthreads();
-            if (ATTN_ABL != 4 && kt0 + KT < kv_end) load_tile(kt0 + KT);
-        }
+        store_tile();
+        __syncthreads();
+        if (kt0 + KT < kv_end) load_tile(kt0 + KT);
         if (active) {
         // ---- S^T = K Q^T (+ the bias k-step: - m~), invisible keys -> -inf
         f32x16_t s[2];
@@ -632,7 +550,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 if constexpr (QPRE && !decltype(FIRST)::value) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_ones, q_m, s[kb], 0, 0, 0);
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8_t kf = *(const bf16x8_t*)(Ks + boff + (32 * kb + lrow) * 128 + (((2 * ks + hi) ^ sw) << 4));
+                    const bf16x8_t kf = *(const bf16x8_t*)(Ks + (32 * kb + lrow) * 128 + (((2 * ks + hi) ^ sw) << 4));
                     s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
                 }
             }
@@ -685,7 +603,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             // tile's row sum, a wave-uniform test of the sum sends the rare tile through a careful second pass.  16 v_max3 fewer per tile,
             // but the second copy of the tile body costs registers (spills around the loops) and the short scales lose 20-30 %.)
             if (decltype(FIRST)::value) shift(true);
-            else if (ATTN_ABL != 3 && __any(row_max() > 2.0f + fabsf(m) * 0.015625f)) shift(false);
+            else if (__any(row_max() > 2.0f + fabsf(m) * 0.015625f)) shift(false);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -693,8 +611,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     float pr[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        pr[j] = ATTN_ABL == 1 ? s[kb][8 * t + j] : __builtin_amdgcn_exp2f(s[kb][8 * t + j]);
-                        if (ATTN_ABL != 2) lsum += pr[j];
+                        pr[j] = __builtin_amdgcn_exp2f(s[kb][8 * t + j]);
+                        lsum += pr[j];
                     }
                     pf[kb][t] = pack_bf16x8(pr);
                 }
@@ -731,25 +649,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const char* vp = v_lane[db] + boff + (32 * kb + 16 * t) * 128;
+                    const char* vp = v_lane[db] + (32 * kb + 16 * t) * 128;
                     const s16x4_t v0 = lds_tr16_b64(vp);
                     const s16x4_t v1 = lds_tr16_b64(vp + 8 * 128);
                     const bf16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    if (ATTN_ABL != 6 || (kb == 0 && t == 0)) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][t], o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][t], o[db], 0, 0, 0);
                 }
         }
-        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (ATTN_ABL != 5) __syncthreads();
+        __syncthreads();
     };
     typedef std::integral_constant<bool, true> Yes;
     typedef std::integral_constant<bool, false> No;
-    if constexpr (DMA) {
-        dma_tile(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    } else {
-        load_tile(0);
-    }
+    load_tile(0);
     int kt0 = 0;
     // wave_min_kv is wave-uniform per construction but tiles are shared by the workgroup (barriers inside): the split point
     // must be the same for all four waves, so it is taken over the workgroup's first query
@@ -1007,253 +918,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //             region 2   QK^T(t+1), key block 1 + PV(t)                                       ||  exp / row sum / pack of tile t
 //             barrier - K(t+2), V(t+1) registers -> LDS - barrier - global loads of K(t+3), V(t+2)
 // ================================================================================================
-#if CVAR_ATTN_PIPE
-template <bool HOLES>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_mfma_bf16_pipe_kernel(const AttnParams p) {
-    constexpr int D = 64, KT = 64;
-    constexpr int TILE_B = KT * 128;
-    __shared__ __attribute__((aligned(16))) char KVs[2 * TILE_B];
-    char* const Ks = KVs;
-    char* const Vs = KVs + TILE_B;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int lrow = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
-    const int nqb = (p.l + 127) >> 7, pairs = p.R * p.H;
-    int qb, pair;
-    {
-        const int id = blockIdx.x;
-        if ((pairs & 7) == 0) { const int xcd = id & 7, local = id >> 3; qb = local % nqb; pair = (local / nqb) * 8 + xcd; }
-        else { qb = id % nqb; pair = id / nqb; }
-    }
-    const int h = pair % p.H;
-    const long r = pair / p.H;
-    const int C3 = p.ldkv;
-    const bf16_t* base = (const bf16_t*)p.qkv + r * (long)p.Lmax * C3;
-    const bf16_t* kbase = base + p.k_col + h * D;
-    const bf16_t* vbase = base + p.v_col + h * D;
-    const int q0 = qb * 128 + w * 32;
-    const bool active = q0 < p.l;
-    const int qi = q0 + lrow;
-    const int qrow = min(qi, p.l - 1);
-    const Vis vis = vis_of(p, p.q_off + qrow);
-    const int kv_end = kv_len_of(p, p.q_off + min(p.l, (qb + 1) * 128) - 1);
-    bf16x8_t qf[4];
-    {
-        const bf16_t* qp = (const bf16_t*)p.q + (r * p.q_rows + (p.q_off + qrow - p.q_pos0)) * (long)p.ldq + h * D;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8_t*)(qp + (2 * ks + hi) * 8);
-    }
-    const int k_key = tid >> 3, k_chunk = tid & 7;
-    bf16x8_t kreg[2], vreg[2];
-    const int row_bytes = C3 * 2;
-    const int rec = (kv_end - 1) * row_bytes + 128;
-    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, rec, 0x00020000);
-    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, rec, 0x00020000);
-    int ld_off[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) ld_off[i] = (k_key + 32 * i) * row_bytes + k_chunk * 16;
-    typedef int v4i_t __attribute__((ext_vector_type(4)));
-    // K runs one tile ahead of V: tile bases are scalars, rows past kv_end come back as zeros
-    auto load_k = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) kreg[i] = __builtin_bit_cast(bf16x8_t, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(k_rsrc, ld_off[i], kt * row_bytes, 0));
-    };
-    auto load_v = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) vreg[i] = __builtin_bit_cast(bf16x8_t, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(v_rsrc, ld_off[i], kt * row_bytes, 0));
-    };
-    auto store_k = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { const int key = k_key + 32 * i; *(bf16x8_t*)(Ks + key * 128 + ((k_chunk ^ ((key >> 1) & 7)) << 4)) = kreg[i]; }
-    };
-    auto store_v = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { const int key = k_key + 32 * i; *(bf16x8_t*)(Vs + key * 128 + ((((k_chunk >> 1) ^ (key & 3)) << 5) | ((k_chunk & 1) << 4))) = vreg[i]; }
-    };
-    const int v_jrow = (lane & 15) >> 2, v_g = (lane >> 4) & 1;
-    const char* v_lane[2];
-#pragma unroll
-    for (int db = 0; db < 2; ++db) v_lane[db] = Vs + (4 * hi + v_jrow) * 128 + (((2 * db + v_g) ^ v_jrow) << 5) + (lane & 3) * 8;
-    const char* k_lane = Ks + lrow * 128;
-
-    f32x16_t o[2];
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[db][i] = 0.f;
-    float m = 0.f, lsum = 0.f;                     // m~ (a bf16 value): the shift the bias k-step applies
-    const short one_bf = hi == 0 ? (short)0x3f80 : (short)0;
-    const bf16x8_t k_ones = {one_bf, 0, 0, 0, 0, 0, 0, 0};
-    bf16x8_t q_m = {0, 0, 0, 0, 0, 0, 0, 0};
-    f32x16_t sA[2], sB[2];
-    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto kfrag = [&](int kb, int ks) { return *(const bf16x8_t*)(k_lane + 32 * kb * 128 + (((2 * ks + hi) ^ sw) << 4)); };
-    const int wg_min_kv = range_full_prefix(p, p.q_off + min(qb * 128, p.l - 1), p.q_off + min(p.l, (qb + 1) * 128) - 1);
-    typedef std::integral_constant<bool, true> Yes;
-    typedef std::integral_constant<bool, false> No;
-    bool first = true;
-    int kt0 = 0;
-
-    // one step: softmax + PV of the tile at kt0 (scores in `cur`), S^T of the tile behind it into `nxt`
-    // (One body for every tile: MASK / last-tile variants as template flags made the compiler copy both score blocks at the joins of the
-    // variants - 70 v_mov per step and 60 spilled registers.  The mask is a wave-uniform branch around an in-place pass instead, and the
-    // last tile computes the scores of a tile that does not exist - zeros out of the range-checked loads, never used, 10 idle MFMAs.)
-    auto step = [&](f32x16_t (&cur)[2], f32x16_t (&nxt)[2]) {
-        constexpr bool have_next = true;
-        const bool masked = kt0 + KT > wg_min_kv;
-        if (active) {
-            // ---- region 1: next tile's key block 0 on the matrix pipe; mask + row maximum of this tile on the vector pipe
-            if constexpr (have_next) {
-                bf16x8_t kf[4];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) kf[ks] = kfrag(0, ks);
-                nxt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_ones, q_m, zero16, 0, 0, 0);
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) nxt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], nxt[0], 0, 0, 0);
-            }
-            if (masked) {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int key = kt0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hi;
-                        if (!vis_key_t<HOLES>(vis, key)) cur[kb][i] = -INFINITY;
-                    }
-            }
-            float tmax = -INFINITY;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, cur[kb][i]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            // m~ is set by the first tile and moves later only when a tile's maximum exceeds it by more than 2 + |m~|/64 (log2 domain)
-            auto shift = [&](bool always) {
-                const bool need = always || tmax > 2.0f + fabsf(m) * 0.015625f;
-                const float m_new = need ? bf16_to_f32(f32_to_bf16(m + tmax)) : m;
-                const float delta = m_new - m;
-                if (!always) {           // the first tile has nothing to rescale; its delta may be hugely negative (2^-delta = inf, 0 * inf = NaN)
-                    const float alpha = __builtin_amdgcn_exp2f(-delta);
-                    lsum *= alpha;
-#pragma unroll
-                    for (int db = 0; db < 2; ++db)
-#pragma unroll
-                        for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
-                }
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) cur[kb][i] -= delta;
-                if constexpr (have_next) {            // the next tile's block 0 was biased with the old m~
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) nxt[0][i] -= delta;
-                }
-                m = m_new;
-                q_m[0] = hi == 0 ? (short)f32_to_bf16(-m_new) : (short)0;
-            };
-            if (first) shift(true);
-            else if (__any(tmax > 2.0f + fabsf(m) * 0.015625f)) shift(false);
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- region 2: 8 softmax chunks of 4 scores; MFMA tokens 0..4 = QK^T of the next tile's key block 1 (0: bias step), 5..12 = PV
-            constexpr int NTOK = 13, TOK0 = have_next ? 0 : 5;
-            bf16x8_t pf[2][2];
-            bf16x8_t kf_n = {0, 0, 0, 0, 0, 0, 0, 0};
-            s16x4_t vf_n0 = {0, 0, 0, 0}, vf_n1 = {0, 0, 0, 0};
-            auto prefetch_for = [&](int t) {          // the LDS fragments token t multiplies
-                if (t >= 1 && t <= 4) { if constexpr (have_next) kf_n = kfrag(1, t - 1); }
-                else if (t >= 5 && t < NTOK) {
-                    const int j = t - 5, pfi = j >> 1, db = j & 1;
-                    const char* vp = v_lane[db] + (32 * (pfi >> 1) + 16 * (pfi & 1)) * 128;
-                    vf_n0 = lds_tr16_b64(vp);
-                    vf_n1 = lds_tr16_b64(vp + 8 * 128);
-                }
-            };
-            if constexpr (TOK0 != 0) prefetch_for(TOK0);          // token 0 (the bias step) multiplies registers only
-            int tok = TOK0;
-            float pr[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int kb = c >> 2, t = (c >> 1) & 1, half = c & 1;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    pr[4 * half + j] = __builtin_amdgcn_exp2f(cur[kb][8 * t + 4 * half + j]);
-                    lsum += pr[4 * half + j];
-                }
-                if (half == 1) pf[kb][t] = pack_bf16x8(pr);
-                // tokens due after chunk c: evenly dealt, (tok - TOK0 + 1) * 8 <= (c + 1) * (NTOK - TOK0)
-#pragma unroll
-                for (int rep = 0; rep < 3; ++rep) {
-                    // a PV token also needs its P fragment packed: fragment pfi is complete behind chunk 2 pfi + 1
-                    if (tok < NTOK && (tok - TOK0 + 1) * 8 <= (c + 1) * (NTOK - TOK0) && (tok < 5 || c >= 2 * ((tok - 5) >> 1) + 1)) {
-                        const bf16x8_t kf_c = kf_n;
-                        const s16x4_t v0 = vf_n0, v1 = vf_n1;
-                        if (tok + 1 < NTOK) prefetch_for(tok + 1);
-                        if (tok == 0) { if constexpr (have_next) nxt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_ones, q_m, zero16, 0, 0, 0); }
-                        else if (tok <= 4) { if constexpr (have_next) nxt[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf_c, qf[tok - 1], nxt[1], 0, 0, 0); }
-                        else {
-                            const int j = tok - 5, pfi = j >> 1, db = j & 1;
-                            const bf16x8_t vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[pfi >> 1][pfi & 1], o[db], 0, 0, 0);
-                        }
-                        ++tok;
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        first = false;
-        __syncthreads();                   // everybody has read K(t+1) and V(t)
-        store_k();                         // K(t+2)
-        store_v();                         // V(t+1)
-        __syncthreads();
-        load_k(kt0 + 3 * KT);
-        load_v(kt0 + 2 * KT);
-        kt0 += KT;
-    };
-    // ---- prologue: K(0) -> LDS, S^T of tile 0 (no bias step: m~ = 0), then K(1) / V(0) -> LDS, K(2) / V(1) -> registers
-    load_k(0);
-    store_k();
-    __syncthreads();
-    load_k(KT);
-    load_v(0);
-    if (active) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            sA[kb] = zero16;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) sA[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(kb, ks), qf[ks], sA[kb], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    store_k();
-    store_v();
-    __syncthreads();
-    load_k(2 * KT);
-    load_v(KT);
-    // ---- tiles: the two score blocks swap roles every step.  MASK is compile-time (tiles every query of the workgroup sees completely
-    // run without per-score compares); the last tile has no successor to compute.
-    for (;;) {
-        step(sA, sB);
-        if (kt0 >= kv_end) break;
-        step(sB, sA);
-        if (kt0 >= kv_end) break;
-    }
-    lsum += __shfl_xor(lsum, 32, 64);
-    if (qi < p.l) {
-        if (p.lse && hi == 0) p.lse[(r * p.H + h) * (long)p.l + qi] = (m + log2f(lsum)) * 0.6931471805599453f;
-        const float inv = 1.0f / lsum;
-        bf16_t* op = (bf16_t*)p.out + (r * p.l + qi) * (long)(p.H * D) + h * D;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float ov[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) ov[e] = o[db][4 * g + e] * inv;
-                *(bf16x4_t*)(op + 32 * db + 8 * g + 4 * hi) = pack_bf16x4(ov);
-            }
-    }
-}
-
-#endif   // CVAR_ATTN_PIPE
 
 extern "C" int cvar_attention_rowwise(const void* qkv, const void* q, int dtype, int R, int H, int Lmax, int q_off, int l, float scale,
                                       const int* lvl_end_host, int n_lvl, const int* hole_host, void* out, float* lse, void* stream) {

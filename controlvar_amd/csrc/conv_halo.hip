@@ -13,19 +13,11 @@
 
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// timing ablations (tools/build_variant.py conv_halo.hip <tag> -DCH_ABL=n; WRONG results, A/B timing only): 1 no weight DMA inside the loop, 2 no halo DMA
-// inside the loop, 3 both, 4 no epilogue traffic, 5 half the MFMAs (row block 0 only), 6 no per-step barrier
-#ifndef CH_ABL
-#define CH_ABL 0
-#endif
 #ifndef CH_EPI_LDS
 #define CH_EPI_LDS 1
 #endif
-// CH_WIDE_TILE = 1: 32-pixel-wide tiles on 8 waves (one workgroup per CU) - built, bit-identical, 1-6 % SLOWER than two independent 4-wave workgroups per CU on every
-// shape but 640 -> 640 at 32^2 (profiles/r04_conv_ablation.txt): what the halved weight traffic saves, the 8-wave barrier and the lost independence of the pair cost.
-#ifndef CH_WIDE_TILE
-#define CH_WIDE_TILE 0
-#endif
+// (round-4 experiments - timing ablations, 32-pixel-wide tiles on 8 waves: 1-6 % slower, profiles/r04_conv_ablation.txt - live in the commits listed in
+// experiments/README.md, not here)
 
 struct ConvHaloParams {
     const bf16_t* X; const bf16_t* Wt; const float* bias; const bf16_t* res; void* out;
@@ -33,9 +25,7 @@ struct ConvHaloParams {
     int up, Hin, Win;          // up = 1: the conv reads its input through a nearest x2 upsample (Hin = H / 2), vae_modules.py:28
 };
 
-// Tile width TW = 16 (4 waves, two workgroups per CU: the shipped form) or 32 (8 waves, one workgroup per CU: round-4 experiment, -DCH_WIDE_TILE=1 - the weight
-// tiles, a seventh of the kernel's time by the ablation table, are fetched once for 512 pixels instead of once per 256; same K order per output, bit-identical
-// results; measured slower, see CH_WIDE_TILE).  Halo row stride TW + 4 pixels (TW + 2 used): a multiple of 4, so that the bank slot depends on the column only.
+// Tile width TW = 16 (4 waves, two workgroups per CU).  Halo row stride TW + 4 pixels (TW + 2 used): a multiple of 4, so that the bank slot depends on the column only.
 
 // LDS images: 64-byte rows (one pixel / one cout x 32 channels) whose four 16-B chunks are XOR-swizzled so that every lane group of a
 // ds_read_b128 covers all 64 banks once.  The hardware's groups are NOT 16 consecutive lanes: group 0 = lanes {0-3, 12-15, 20-27} etc.
@@ -66,14 +56,6 @@ __global__ __launch_bounds__(TW * 16, 2) void conv3x3_halo_bf16_kernel(const Con
     const int b = t_ / p.tiles_y;
     const int ty0 = ty * 16, tx0 = tx * TW;
     const int cout0 = blockIdx.y * (32 * CH_NB);
-#ifdef CH_STAGGER
-    // experiment: the second workgroup of every CU (blocks 256 .. 511 of the launch, as dispatch goes) starts CH_STAGGER shader cycles late, so that the two
-    // co-resident workgroups do not reach their epilogues together
-    if (blockIdx.y == 0 && blockIdx.x >= 256 && blockIdx.x < 512) {
-        const unsigned long long t0 = __builtin_readcyclecounter();
-        while (__builtin_readcyclecounter() - t0 < (unsigned long long)CH_STAGGER) __builtin_amdgcn_s_sleep(8);
-    }
-#endif
     const bf16_t* ximg = p.X + (long)b * p.Hin * p.Win * p.Cin;
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ximg, 0, p.Hin * p.Win * p.Cin * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.Wt + (long)cout0 * 9 * p.Cin), 0, min(32 * CH_NB, p.Cout - cout0) * 9 * p.Cin * 2, 0x00020000);
@@ -172,10 +154,10 @@ __global__ __launch_bounds__(TW * 16, 2) void conv3x3_halo_bf16_kernel(const Con
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             int issued = 0;
-            if (CH_ABL != 2 && CH_ABL != 3 && t < H_PER_WAVE && c + 1 < p.nchunk) issued += issue_halo(c + 1, t);
+            if (t < H_PER_WAVE && c + 1 < p.nchunk) issued += issue_halo(c + 1, t);
             {
                 const int c2 = t + 2 >= 9 ? c + 1 : c, t2 = t + 2 >= 9 ? t + 2 - 9 : t + 2;
-                if (CH_ABL != 1 && CH_ABL != 3 && c2 < p.nchunk) issued += issue_w(c2, t2);
+                if (c2 < p.nchunk) issued += issue_w(c2, t2);
             }
             const char* wb = smem + 2 * CH_HALO_BYTES + (t % 3) * CH_W_BYTES + b_lane;
             bf16x8_t w[2][CH_NB];
@@ -191,9 +173,9 @@ __global__ __launch_bounds__(TW * 16, 2) void conv3x3_halo_bf16_kernel(const Con
 #pragma unroll
                 for (int j = 0; j < CH_NB; ++j)
 #pragma unroll
-                    for (int i = 0; i < (CH_ABL == 5 ? 1 : 2); ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][j], af[t & 1][i][ks], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks][j], af[t & 1][i][ks], acc[i][j], 0, 0, 0);
             wait_vm(issued);
-            if (CH_ABL != 6) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
         }
         // nine taps per chunk: the prefetched set is 1 after tap 8 - move it to set 0 so that every chunk starts alike
 #pragma unroll
@@ -206,7 +188,6 @@ __global__ __launch_bounds__(TW * 16, 2) void conv3x3_halo_bf16_kernel(const Con
     // All residual loads of a row block are issued before its first store: vmcnt retires in order and counts stores, so a load queued
     // behind stores would wait for their latency as well (+13 % on the residual convs).  The bias comes straight from global memory (L2
     // hits): a second static LDS array for it cost 6 % on every shape.
-    if (CH_ABL == 4 && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int yy = py0 + RPI * i, xx = px;
@@ -316,15 +297,9 @@ int cvar_conv3x3_halo_bf16(const void* X, const void* Wt, const float* bias, con
     const long tiles = (long)B * p.tiles_x * p.tiles_y;
     if (tiles <= 0 || tiles > 0x7fffffffL) return CVAR_EINVAL;
     if (Cout % 160 == 0 && !out_f32) {
-        // 32-pixel-wide tiles wherever the image has them (chosen by the image width only; same bits as the 16-wide kernel)
-        if (CH_WIDE_TILE && W % 32 == 0) {
-            p.tiles_x = W / 32;
-            const long tiles32 = (long)B * p.tiles_x * p.tiles_y;
-            if (tiles32 <= 0 || tiles32 > 0x7fffffffL) return CVAR_EINVAL;
-            hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<5, bf16_t, 32>), dim3((unsigned)tiles32, Cout / 160), dim3(512), 0, st, p);
-            CVAR_CHECK_LAUNCH();
-            return CVAR_OK;
-        }
+        // the row-major epilogue moves 16-byte vectors at 32-bit element offsets inside an image: callers whose output / residual are only
+        // 8-byte aligned or whose images exceed 2^31 elements stay on the implicit-GEMM tiles
+        if ((((uintptr_t)out | (uintptr_t)residual) & 15) != 0 || (long)H * W * Cout >= 0x7fffffffL) return CVAR_EUNSUPPORTED;
         hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<5, bf16_t>), dim3((unsigned)tiles, Cout / 160), dim3(256), 0, st, p);
     } else if (Cout <= 32 && !residual) {
         if (out_f32) hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<1, float>), dim3((unsigned)tiles, 1), dim3(256), 0, st, p);

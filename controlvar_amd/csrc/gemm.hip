@@ -49,36 +49,9 @@ extern "C" int cvar_gemm_dbg_read(unsigned long long* host) { return (int)hipMem
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// 16-byte fp32 store / load at DEVICE scope (sc1): written through to / fetched from the point all eight XCD L2s agree on.  The fused split-K
-// hand-over uses these per access instead of a release / acquire fence pair - on this part a fence is `buffer_wbl2 sc1` + `buffer_inv sc1`, a
-// write-back and an invalidate of the whole 4 MB L2 by every slice (measured: 63 us per small GEMM, B = 1 generation 36 -> 90 ms).
-__device__ __forceinline__ void store_f32x4_sc1(float* ptr, f32x4_t v) { asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(ptr), "v"(v) : "memory"); }
-// eight loads and the wait for them in ONE asm statement: the compiler does not know that a load issued by inline asm arrives later, so the
-// destination registers must not be visible to it before the s_waitcnt
-__device__ __forceinline__ void load8_f32x4_sc1(f32x4_t (&w)[8], const float* const (&ptr)[8]) {
-    asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
-                 "global_load_dwordx4 %1, %9, off sc1\n\t"
-                 "global_load_dwordx4 %2, %10, off sc1\n\t"
-                 "global_load_dwordx4 %3, %11, off sc1\n\t"
-                 "global_load_dwordx4 %4, %12, off sc1\n\t"
-                 "global_load_dwordx4 %5, %13, off sc1\n\t"
-                 "global_load_dwordx4 %6, %14, off sc1\n\t"
-                 "global_load_dwordx4 %7, %15, off sc1\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(w[0]), "=&v"(w[1]), "=&v"(w[2]), "=&v"(w[3]), "=&v"(w[4]), "=&v"(w[5]), "=&v"(w[6]), "=&v"(w[7])
-                 : "v"(ptr[0]), "v"(ptr[1]), "v"(ptr[2]), "v"(ptr[3]), "v"(ptr[4]), "v"(ptr[5]), "v"(ptr[6]), "v"(ptr[7])
-                 : "memory");
-}
-
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2, bool FAST = false, bool CUP = false, bool PERS = false, bool SC1 = false>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2, bool FAST = false, bool CUP = false>
 __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
     static_assert(!CUP || (CONV && FAST), "CUP (nearest x2 upsample folded into the conv) is a conv FAST variant");
-    // PERS (round 4): one workgroup per CU stays resident and walks over output tiles.  The workgroup timeline of the one-tile-per-workgroup
-    // kernel (profiles/r04_gemm_wg_timeline.txt, K = 1536: 41 us per tile) shows 1.7 us of dispatch gap + 2.3 us from entry to the first MFMA +
-    // an epilogue that ends in the drain of its own stores - a fifth of a CU's time outside the K loop, which is what hipBLASLt's persistent
-    // kernel does not pay.  Here the DMA stream simply runs on across the tile boundary: the last two K iterations of a tile fetch the first
-    // K tile of the NEXT output tile, the epilogue's stores drain under the next tile's first K iterations, nothing is dispatched in between.
-    static_assert(!PERS || (FAST && !CONV && sizeof(T) == 2 && NSTAGE == 2), "PERS is the plain bf16 FAST kernel");
     constexpr int NW = WM * WN;
     constexpr bool FRAG_PIPE = (BM == 256) && (!CONV || FAST);
 #ifndef CVAR_DMA_EARLY
@@ -136,33 +109,9 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
         }
     }
 
-    // ---- tile coordinates: bijective XCD remap, then grouped-M ordering.  v = virtual block id: the block index of the one-tile kernel; the
-    // persistent kernel walks v = blockIdx.x, blockIdx.x + gridDim.x (two static rounds), then local indices handed out by its XCD's counter
-    // (gridDim.x is a multiple of 8, so v & 7 - the XCD whose L2 holds this part of the tile space - never changes for a workgroup)
-    const int nblk_all = p.tiles_m * p.tiles_n;
-    auto tile_origin = [&](int v, int& m0_, int& n0_) { gemm_tile_origin(p, v, BM, BN, m0_, n0_); };
-    // persistent tile ids: this tile, the next one (needed two K tiles before this one ends) and - through pers_slot - the one after
-    __shared__ int pers_slot;
-    int vtile = (int)blockIdx.x;
-    int vnext = (PERS && (int)(blockIdx.x + gridDim.x) < nblk_all) ? (int)(blockIdx.x + gridDim.x) : -1;
-    // wave 0, lane 0: the RAW counter value fetched one epilogue ago (>= 0), turned into a tile id only when it is published at the next
-    // epilogue - touching the returned value any earlier puts an s_waitcnt vmcnt(0) for the atomic's round trip (1-2 us) into the epilogue
-    int pend = -1;
-    auto fetch_raw = [&]() { return (int)__hip_atomic_fetch_add(p.pers_ctr + ((int)blockIdx.x & 7), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    auto tile_of_raw = [&](int raw) {    // local index 2 G + raw of this workgroup's XCD; -1 when its part of the tile space is used up
-        const int x = (int)blockIdx.x & 7, G = (int)gridDim.x >> 3;
-        const int v = (2 * G + raw) * 8 + x;
-        return (raw >= 0 && v < nblk_all) ? v : -1;
-    };
-    bool pers_more = PERS && vnext >= 0;      // wave 0, lane 0: keep fetching (cleared once a published id came out as -1)
-    if (PERS && wave == 0 && lane == 0 && pers_more) pend = fetch_raw();
-    int cur = 0;                         // LDS stage of the K tile being computed; carried from tile to tile by the persistent kernel
-    bool pers_first = true;
-    for (;;) {                           // ---- one pass per output tile (a single pass unless PERS)
+    // ---- tile coordinates: bijective XCD remap, then grouped-M ordering
     int m0, n0;
-    tile_origin(vtile, m0, n0);
-    int m0n = m0, n0n = n0;              // PERS: origin of the next tile (this tile again when there is none: its prefetch is then a harmless re-read)
-    if (PERS && vnext >= 0) tile_origin(vnext, m0n, n0n);
+    gemm_tile_origin(p, (int)blockIdx.x, BM, BN, m0, n0);
     const long zb = blockIdx.z;
 
     const char* const zero = (const char*)cvar_zero_chunk;
@@ -204,17 +153,11 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
     unsigned a_off[A_PER_W], w_off[B_PER_W];
     const char* const a_tile = CONV ? Abase : Abase + (long)m0 * p.lda * ES;
     const char* const w_tile = Wbase + (long)n0 * p.ldw * ES;
-    // PERS: row offsets are NOT clamped (they then do not depend on the tile); rows past M fall outside the resource's range and read zeros
-    const long a_bytes = ((long)(p.M - m0 - 1) * p.lda + p.K) * ES;
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_tile, 0, CONV ? (int)p.conv_bytes : PERS ? (int)min(a_bytes, (long)0x7fffffff) : 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a_tile, 0, CONV ? (int)p.conv_bytes : 0x7fffffff, 0x00020000);
     // W's range ends with the last row of the matrix: when K is not a multiple of the K tile (conv: K = 9 Cin) the last row's
     // tail would otherwise read whatever follows the weights - the A side is zero there, but 0 x Inf/NaN garbage is NaN
     const long w_bytes = ((long)(p.N - n0 - 1) * p.ldw + p.K) * ES;
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)w_tile, 0, (int)min(w_bytes, (long)0x7fffffff), 0x00020000);
-    // PERS: the same two resources for the next output tile
-    const long a_bytes_n = ((long)(p.M - m0n - 1) * p.lda + p.K) * ES, w_bytes_n = ((long)(p.N - n0n - 1) * p.ldw + p.K) * ES;
-    const __amdgpu_buffer_rsrc_t a_rsrc_n = __builtin_amdgcn_make_buffer_rsrc((void*)(Abase + (long)m0n * p.lda * ES), 0, (int)min(a_bytes_n, (long)0x7fffffff), 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rsrc_n = __builtin_amdgcn_make_buffer_rsrc((void*)(Wbase + (long)n0n * p.ldw * ES), 0, (int)min(w_bytes_n, (long)0x7fffffff), 0x00020000);
     // conv FAST (stride 1, no upsample, Cin % 32 == 0, input < 2 GiB): each 32-element half of a K tile lies inside ONE tap, so
     // (tap, channel) of the two halves are wave-uniform scalars advanced per K tile; a lane keeps its pixel's byte offset and a
     // 9-bit mask of in-range taps per piece, and because the swizzled chunk of a lane is the same for all its pieces
@@ -228,7 +171,7 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
 #pragma unroll
         for (int jj = 0; jj < A_PER_W; ++jj) {
             const int row = (wave + jj * NW) * 8 + lr;
-            a_off[jj] = (unsigned)(PERS ? row : min(row, p.M - 1 - m0)) * (unsigned)(p.lda * ES) + (unsigned)((slot ^ ((row >> 1) & 7)) * 16);
+            a_off[jj] = (unsigned)min(row, p.M - 1 - m0) * (unsigned)(p.lda * ES) + (unsigned)((slot ^ ((row >> 1) & 7)) * 16);
         }
     }
     if (FAST && CONV) {
@@ -267,7 +210,7 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
 #pragma unroll
         for (int jj = 0; jj < B_PER_W; ++jj) {
             const int row = w_piece(jj) * 8 + lr;
-            w_off[jj] = (unsigned)(PERS ? row : min(row, p.N - 1 - n0)) * (unsigned)(p.ldw * ES) + (unsigned)((slot ^ ((row >> 1) & 7)) * 16);
+            w_off[jj] = (unsigned)min(row, p.N - 1 - n0) * (unsigned)(p.ldw * ES) + (unsigned)((slot ^ ((row >> 1) & 7)) * 16);
         }
     }
     // conv FAST: lane offset / tap of the NEXT tile to issue, then advance the scalar (tap, channel) state by one K tile
@@ -308,22 +251,8 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
     // one 1-KiB DMA piece of tile kt: idx < A_PER_W -> A operand, else W operand
     // the K loop issues pieces unconditionally (past the last tile it re-fetches the last one into a stage nobody reads), so
     // that its body is one basic block and the scheduler can place DMA issue and address math between MFMAs
-    const int nk_pers = p.K / KT;          // PERS: K tiles per output tile (K % KT == 0 on the FAST path)
     auto issue_one = [&](int kt, int stage, int idx) {
         char* sbase = smem + stage * STAGE;
-        if constexpr (PERS) {
-            // K tile index kt >= nk_pers addresses K tile kt - nk_pers of the NEXT output tile (wave-uniform selects of two SGPR quads)
-            const bool nx = kt >= nk_pers;
-            const int koff = (nx ? kt - nk_pers : kt) * 128;
-            if (idx < A_PER_W) {
-                if (nx) __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc_n, (lptr_t)(sbase + (wave + idx * NW) * 1024), 16, (int)a_off[idx], koff, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lptr_t)(sbase + (wave + idx * NW) * 1024), 16, (int)a_off[idx], koff, 0, 0);
-            } else {
-                if (nx) __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc_n, (lptr_t)(sbase + BM * 128 + w_piece(idx - A_PER_W) * 1024), 16, (int)w_off[idx - A_PER_W], koff, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lptr_t)(sbase + BM * 128 + w_piece(idx - A_PER_W) * 1024), 16, (int)w_off[idx - A_PER_W], koff, 0, 0);
-            }
-            return;
-        }
         if (FAST) {
             // buffer_load_dwordx4 v_off, s[rsrc], s_koff offen lds: resource and K offset are scalar, the lane offset is fixed
             if (idx < A_PER_W) {
@@ -437,8 +366,7 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
     // (b) nobody reads tile kt's stage any more.  Behind it, under the tile's remaining MFMAs, the wave reads the FIRST fragments of tile kt+1 out
     // of the other stage and starts the DMA of tile kt+2 into the stage just released (one piece per two MFMAs, running over into the next
     // tile's first MFMAs), so the MFMA stream continues through the loop edge.  Two LDS stages, two tiles in flight, one barrier per tile.
-    constexpr bool XB2 = M16 && NSTAGE == 2 && (CVAR_GEMM_XB == 2 || (CVAR_GEMM_XB == 3 && NW < 8));   // see the XB2 loop below
-    constexpr bool XB = M16 && NSTAGE == 2 && (CVAR_GEMM_XB != 0) && !XB2;
+    constexpr bool XB = M16 && NSTAGE == 2 && (CVAR_GEMM_XB != 0);
     constexpr int RING = XB ? 4 : 3;                              // A-fragment ring: 2 MI16 % RING == 0 keeps the slot numbering across tiles
     constexpr int NM16 = MI16 * NJ16;                             // MFMAs per 32-deep k-step
     constexpr int XB_PM = (2 * MI16 - 2) * NJ16;                  // first MFMA behind the barrier
@@ -448,40 +376,16 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
     auto xb_same_iter = [](int t) { return XB_PM + 1 + 2 * t < 2 * NM16; };
     constexpr int XB_N2 = NL < NJ16 ? NL : NJ16;                  // pieces with xb_same_iter: 2 NM16 - XB_PM = 2 NJ16 MFMAs lie behind the barrier
     bf16x8_t a3[RING], bw[2][M16 ? NJ16 : 1];
-    bf16x8_t fa[2][XB2 ? MI16 : 1], fb[2][XB2 ? NJ16 : 1];      // XB2: complete fragment sets of both k-steps
-    static_assert(!PERS || XB, "the persistent kernel runs the XB loop");
-    if constexpr (!PERS) cur = 0;
-    if constexpr (XB2) {
-        // tiles kt_lo and kt_lo + 1 in flight; the first tile's k-step-0 fragments are read before the loop
+    int cur = 0;                         // LDS stage of the K tile being computed
+    if constexpr (XB) {
 #pragma unroll
-        for (int idx = 0; idx < NL; ++idx) issue_one(kt_lo, 0, idx);
-#pragma unroll
-        for (int idx = 0; idx < NL; ++idx) issue_one(min(kt_lo + 1, nk - 1), 1, idx);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
-        __builtin_amdgcn_s_barrier();
-        const int l15 = lane & 15, kq = lane >> 4, sw16 = (l15 >> 1) & 7;
-        const char* A16 = smem + (wm * SUB_M + l15) * 128;
-        const char* B16 = smem + BM * 128 + (wn * SUB_N + l15) * 128;
-#pragma unroll
-        for (int j = 0; j < NJ16; ++j) fb[0][j] = *(const bf16x8_t*)(B16 + j * 16 * 128 + ((kq ^ sw16) * 16));
-#pragma unroll
-        for (int i = 0; i < MI16; ++i) fa[0][i] = *(const bf16x8_t*)(A16 + i * 16 * 128 + ((kq ^ sw16) * 16));
-    } else if constexpr (XB) {
-        // PERS, every tile but the first: K tile 0 already lies in stage `cur` (fetched by the previous tile's last two iterations, landed and
-        // met before its epilogue); the first half of K tile 1 goes into the other stage, which held the epilogue's staging rows until the
-        // barrier just passed.  Nothing to wait for.
-        if (!PERS || pers_first) {
-#pragma unroll
-            for (int idx = 0; idx < NL; ++idx) issue_one(kt_lo, cur, idx);
-        }
+        for (int idx = 0; idx < NL; ++idx) issue_one(kt_lo, cur, idx);
 #pragma unroll
         for (int t = 0; t < NL; ++t)
-            if (xb_same_iter(t)) issue_one(PERS ? kt_lo + 1 : min(kt_lo + 1, nk - 1), cur ^ 1, t);
-        if (!PERS || pers_first) {
-            // the pieces of the first tile have landed when at most the XB_N2 later ones are outstanding (vmcnt retires in order)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XB_N2) : "memory");
-            __builtin_amdgcn_s_barrier();
-        }
+            if (xb_same_iter(t)) issue_one(min(kt_lo + 1, nk - 1), cur ^ 1, t);
+        // the pieces of the first tile have landed when at most the XB_N2 later ones are outstanding (vmcnt retires in order)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(XB_N2) : "memory");
+        __builtin_amdgcn_s_barrier();
         {
             const int l15 = lane & 15, kq = lane >> 4, sw16 = (l15 >> 1) & 7;
             const char* A16 = smem + cur * STAGE + (wm * SUB_M + l15) * 128;
@@ -509,11 +413,11 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
 #ifdef CVAR_GEMM_TIMING
         const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
 #endif
-        if constexpr (!XB && !XB2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * NL) : "memory");   // uniform: dead pieces keep the count regular
+        if constexpr (!XB) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PF - 1) * NL) : "memory");   // uniform: dead pieces keep the count regular
 #ifdef CVAR_GEMM_TIMING
         const unsigned long long tq1 = __builtin_amdgcn_s_memtime();
 #endif
-        if constexpr (!XB && !XB2) __builtin_amdgcn_s_barrier();
+        if constexpr (!XB) __builtin_amdgcn_s_barrier();
 #ifdef CVAR_GEMM_TIMING
         const unsigned long long tq2 = __builtin_amdgcn_s_memtime();
         if (kt > kt_lo) dbg_comp += tq0 - dbg_last;
@@ -523,54 +427,7 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
         if (FAST && CONV) conv_next();
         const char* As = smem + cur * STAGE + (wm * SUB_M + lrow) * 128;
         const char* Bs = smem + cur * STAGE + BM * 128 + (wn * SUB_N + lrow) * 128;
-        if constexpr (XB2) {
-            // XB2 = hipBLASLt's register plan (profiles/r04_gemm_isa_vs_hipblaslt.txt): BOTH k-steps' complete fragment sets live in registers.
-            // k-step 0 computes on set 0 while set 1 is read out of this tile's stage (all reads issued in its first three quarters, in order of
-            // use); the barrier sits at the k-step boundary - every LDS read of the tile is done by then - and k-step 1 computes on set 1 while
-            // the NEXT tile's set 0 is read out of the other stage and the DMA of tile kt+2 refills this one.  No wait inside a k-step except
-            // the ones the compiler derives for first uses; one barrier per tile; DMA pieces fly for a whole tile.
-            typedef __attribute__((ext_vector_type(8))) __bf16 bfv8;
-            const int l15 = lane & 15, kq = lane >> 4, sw16 = (l15 >> 1) & 7;
-            const char* A16 = smem + cur * STAGE + (wm * SUB_M + l15) * 128;
-            const char* B16 = smem + cur * STAGE + BM * 128 + (wn * SUB_N + l15) * 128;
-            const char* A16n = smem + nxt * STAGE + (wm * SUB_M + l15) * 128;
-            const char* B16n = smem + nxt * STAGE + BM * 128 + (wn * SUB_N + l15) * 128;
-            constexpr int NR = MI16 + NJ16;
-            // read r of a set: W fragments first (every MFMA row needs all of them), then the A fragments in row order
-            auto rd_set = [&](int set, const char* Ab, const char* Bb, int s32, int r) {
-                const int c = ((4 * s32 + kq) ^ sw16) * 16;
-                if (r < NJ16) fb[set][r] = *(const bf16x8_t*)(Bb + r * 16 * 128 + c);
-                else fa[set][r - NJ16] = *(const bf16x8_t*)(Ab + (r - NJ16) * 16 * 128 + c);
-            };
-            constexpr int RSPAN = (3 * NM16) / 4;                // reads of the other set go behind the first RSPAN MFMAs of a k-step
-#pragma unroll
-            for (int s32 = 0; s32 < 2; ++s32) {
-#pragma unroll
-                for (int i = 0; i < MI16; ++i) {
-#pragma unroll
-                    for (int j = 0; j < NJ16; ++j) {
-                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bfv8, fb[s32][j]), __builtin_bit_cast(bfv8, fa[s32][i]), acc4[i][j], 0, 0, 0);
-                        const int q = i * NJ16 + j;                 // MFMA index inside the k-step
-#pragma unroll
-                        for (int r = 0; r < NR; ++r)
-                            if ((r * RSPAN) / NR == q) {
-                                if (s32 == 0) rd_set(1, A16, B16, 1, r);          // this tile's k-step 1
-                                else rd_set(0, A16n, B16n, 0, r);                 // next tile's k-step 0 (behind the barrier)
-                            }
-                        if (s32 == 1) {
-#pragma unroll
-                            for (int t = 0; t < NL; ++t)
-                                if ((t * (NM16 - 2)) / NL + 1 == q) issue_one(min(kt + 2, nk - 1), cur, t);     // tile kt+2 into the stage this tile has finished reading
-                        }
-                        if (s32 == 0 && q == NM16 - 1) {
-                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // set 1 arrived (issued >= NM16 / 4 MFMAs ago); own pieces of tile kt+1 landed
-                            __builtin_amdgcn_s_barrier();
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            }
-        } else if constexpr (M16) {
+        if constexpr (M16) {
             typedef __attribute__((ext_vector_type(8))) __bf16 bfv8;
             const int l15 = lane & 15, kq = lane >> 4, sw16 = (l15 >> 1) & 7;
             const char* A16 = smem + cur * STAGE + (wm * SUB_M + l15) * 128;
@@ -613,9 +470,9 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
 #pragma unroll
                             for (int t = 0; t < NL; ++t)
                                 if (xb_pos(t) == m) {
-                                    // PERS: indices >= nk run on into the next output tile (issue_one); else dead re-reads of the last tile
-                                    if (xb_same_iter(t)) issue_one(PERS ? kt + 2 : min(kt + 2, nk - 1), cur, t);     // tile kt+2 into the stage this tile releases
-                                    else issue_one(PERS ? kt + 1 : min(kt + 1, nk - 1), nxt, t);                      // the rest of the group started behind the previous barrier
+                                    // (indices past the last tile are dead re-reads of the last tile)
+                                    if (xb_same_iter(t)) issue_one(min(kt + 2, nk - 1), cur, t);     // tile kt+2 into the stage this tile releases
+                                    else issue_one(min(kt + 1, nk - 1), nxt, t);                      // the rest of the group started behind the previous barrier
                                 }
                             if (m == XB_PM - 1) {
                                 // every LDS read of this tile has been issued: wait for them and for this wave's pieces of tile kt+1, then meet
@@ -711,26 +568,15 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
                                               : __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
             }
         }
-        if constexpr (!XB && !XB2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // XB: the next tile's first fragments stay in flight over the loop edge
+        if constexpr (!XB) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // XB: the next tile's first fragments stay in flight over the loop edge
         cur = (cur + 1) % NSTAGE;
     }
-    if constexpr (XB || XB2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // dead pieces of the last tiles must not land in the epilogue's staging rows
+    if constexpr (XB) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // dead pieces of the last tiles must not land in the epilogue's staging rows
 #ifdef CVAR_GEMM_TIMING
     const unsigned long long dbg_t1 = __builtin_amdgcn_s_memtime();
     const unsigned long long dbg_rt_loop_end = __builtin_amdgcn_s_memrealtime();
 #endif
     __syncthreads();
-    if constexpr (PERS) {
-        // every wave has passed the barrier: nobody reads pers_slot any more (it is read right behind the barrier that follows the epilogue).
-        // Publish the id fetched one epilogue ago (the tile after next) and fetch another one; its value is not needed for a whole tile.
-        if (wave == 0 && lane == 0) {
-            const int v = pers_more ? tile_of_raw(pend) : -1;
-            pers_slot = v;
-            pers_more = v >= 0;
-            if (pers_more) pend = fetch_raw();
-        }
-    }
-
     // ---- epilogue: accumulators -> LDS (per-wave region, 32 rows at a time) -> row-major 8-wide vectors, so that
     // bias / gate / residual loads and the C stores are 16-byte and coalesced (128-B rows per 8 lanes).
     // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -744,26 +590,15 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
     // 64-85 B/clk); rows of EROW = SUB_N + 4 floats keep the 8-lane store groups on distinct banks.
     constexpr bool FULL32 = TRANS && !M16;                // 16x16 blocks (M16) are staged one block row = 16 output rows at a time
     constexpr int SROWS = FULL32 ? 32 : 16;
-#ifndef CVAR_GEMM_EPI_PIPE
-#define CVAR_GEMM_EPI_PIPE 0
-#endif
-    // EPI_PIPE (round 4, 16x16-block kernels; built, bit-identical, measured: plain bf16 epilogue neutral, GELU / gate + residual epilogues 3-7 %
-    // SLOWER - 256 VGPRs + 52 B of scratch in the 8-wave kernel, profiles/r04_gemm_epilogue_pipe_rejected.txt; -DCVAR_GEMM_EPI_PIPE=1 to build it):
-    // two staging regions per wave and the row-major reads of block row ih + 1 issued BEFORE the arithmetic and the stores of block row ih -
-    // the LDS write -> read round trip (~250 cycles, once per 16 output rows, eight times per wave) sits in front of every pass
-    constexpr bool EPI_PIPE = (CVAR_GEMM_EPI_PIPE != 0) && M16 && !PERS;
-    constexpr int NSTG = EPI_PIPE ? 2 : 1;
-    static_assert(NW * SROWS * EROW * 4 * NSTG <= (PERS ? 1 : NSTAGE) * STAGE, "epilogue staging must fit the pipeline LDS");
-    // PERS: stage `cur` already holds the first K tile of the next output tile; the staging rows live in the other one (whose last reader
-    // finished before the barrier above)
-    float* stg = (float*)(smem + (PERS ? (cur ^ 1) * STAGE : 0)) + wave * (SROWS * EROW * NSTG);
+    static_assert(NW * SROWS * EROW * 4 <= NSTAGE * STAGE, "epilogue staging must fit the pipeline LDS");
+    float* stg = (float*)smem + wave * (SROWS * EROW);
     // rows of block i land in the staging region: the whole transposed block at once (4 x b128 per 32 columns), or - tiles whose
     // pipeline LDS is too small for 32 staged rows per wave keep the plain MFMA layout (lane = column) - 16 rows as b32 stores
     auto stage_block = [&](int i, int half) {
         if constexpr (M16) {                  // 16x16 blocks: lane & 15 = row inside the block, lane >> 4 selects 4 of its 16 columns
             const int l15 = lane & 15, cq = lane >> 4;
 #pragma unroll
-            for (int j = 0; j < NJ16; ++j) *(f32x4_t*)(stg + (EPI_PIPE ? half * (SROWS * EROW) : 0) + l15 * EROW + j * 16 + 4 * cq) = acc4[2 * i + half][j];
+            for (int j = 0; j < NJ16; ++j) *(f32x4_t*)(stg + l15 * EROW + j * 16 + 4 * cq) = acc4[2 * i + half][j];
         } else if (FULL32) {
             if (half != 0) return;
 #pragma unroll
@@ -860,35 +695,18 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
                 }
             };
             if constexpr (gate || res != 0 || act == CVAR_ACT_GELU_GRAD) fetch_operands(0);
-            // EPI_PIPE: the staged values of a block row, read one block row ahead (unconditionally: the staging rows always exist)
-            f32x4_t pa[2][EPI_PIPE ? NPASS : 1][2];
-            auto read_rows = [&](int ihh) {
-#pragma unroll
-                for (int ps = 0; ps < NPASS; ++ps) {
-                    const float* sp = stg_r + (ihh & 1) * (SROWS * EROW) + (ps * RPP) * EROW;
-                    pa[ihh & 1][ps][0] = *(const f32x4_t*)sp;
-                    pa[ihh & 1][ps][1] = *(const f32x4_t*)(sp + 4);
-                }
-            };
-            if constexpr (EPI_PIPE) { stage_block(0, 0); read_rows(0); }
 #pragma clang loop unroll(full)
             for (int ih = 0; ih < 2 * MI; ++ih) {
                 const int i = ih >> 1, half = ih & 1, bsel = ih & 1;
                 if constexpr (gate || res != 0 || act == CVAR_ACT_GELU_GRAD) { if (ih + 1 < 2 * MI) fetch_operands(ih + 1); }
-                if constexpr (EPI_PIPE) {
-                    if (ih + 1 < 2 * MI) { stage_block((ih + 1) >> 1, (ih + 1) & 1); read_rows(ih + 1); }
-                } else stage_block(i, half);
+                stage_block(i, half);
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) {
                     const int roff = i * 32 + 16 * half + ps * RPP;          // wave-uniform, known at compile time
                     const int m = mrow + roff;
                     if (lane_on && m < p.M && ((16 % RPP == 0) || ps * RPP + erow < 16)) {
-                        f32x4_t a0, a1;
-                        if constexpr (EPI_PIPE) { a0 = pa[ih & 1][ps][0]; a1 = pa[ih & 1][ps][1]; }
-                        else {
-                            a0 = *(const f32x4_t*)(stg_r + (ps * RPP + srow_half * half) * EROW);
-                            a1 = *(const f32x4_t*)(stg_r + (ps * RPP + srow_half * half) * EROW + 4);
-                        }
+                        const f32x4_t a0 = *(const f32x4_t*)(stg_r + (ps * RPP + srow_half * half) * EROW);
+                        const f32x4_t a1 = *(const f32x4_t*)(stg_r + (ps * RPP + srow_half * half) * EROW + 4);
                         float v[8];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) { v[e] = a0[e] * p.alpha + bias8[e]; v[4 + e] = a1[e] * p.alpha + bias8[4 + e]; }
@@ -936,8 +754,7 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
                             *(bf16x8_t*)cp = pack_bf16x8(v);
                         } else {
                             const f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                            if constexpr (SC1) { store_f32x4_sc1((float*)cp, o0); store_f32x4_sc1((float*)(cp + 16), o1); }
-                            else { *(f32x4_t*)cp = o0; *(f32x4_t*)(cp + 16) = o1; }
+                            *(f32x4_t*)cp = o0; *(f32x4_t*)(cp + 16) = o1;
                         }
                     }
                 }
@@ -990,7 +807,7 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
             if (!lane_on || rr >= 16 || m >= p.M) continue;
             float v[8];
             {
-                const float* sg = stg + (EPI_PIPE ? half * (SROWS * EROW) : 0);             // EPI_PIPE: block row ih lies in staging region ih & 1
+                const float* sg = stg;
                 const f32x4_t a0 = *(const f32x4_t*)(sg + (rr + srow_half * half) * EROW + ecol);
                 const f32x4_t a1 = *(const f32x4_t*)(sg + (rr + srow_half * half) * EROW + ecol + 4);
 #pragma unroll
@@ -1045,16 +862,12 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
                         for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
                     }
                 }
-#if defined(CVAR_ABL_NOSTORE)
-                if (v[0] == 1.2345e30f)
-#endif
                 if (p.out_dtype == CVAR_BF16) {
                     *(bf16x8_t*)((bf16_t*)Cdst + cbase) = pack_bf16x8(v);
                 } else {
                     float* cp = (float*)Cdst + cbase;
                     const f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                    if constexpr (SC1) { store_f32x4_sc1(cp, o0); store_f32x4_sc1(cp + 4, o1); }
-                    else { *(f32x4_t*)cp = o0; *(f32x4_t*)(cp + 4) = o1; }
+                    *(f32x4_t*)cp = o0; *(f32x4_t*)(cp + 4) = o1;
                 }
             } else {
                 for (int e = 0; e < 8; ++e) {
@@ -1073,12 +886,12 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
     }
     }   // generic epilogue
 #ifdef CVAR_GEMM_TIMING
-    if (lane == 0 && wave == 0 && (PERS ? vtile : (int)blockIdx.x) < CVAR_DBG_WG_MAX && blockIdx.y == 0 && blockIdx.z == 0) {
-        if (!PERS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the stores of this wave have been acknowledged (the persistent kernel lets them drain under the next tile)
+    if (lane == 0 && wave == 0 && (int)blockIdx.x < CVAR_DBG_WG_MAX && blockIdx.y == 0 && blockIdx.z == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the stores of this wave have been acknowledged
         unsigned hwid, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long* o = cvar_gemm_dbg_wg + (size_t)(PERS ? vtile : (int)blockIdx.x) * 5;
+        unsigned long long* o = cvar_gemm_dbg_wg + (size_t)blockIdx.x * 5;
         o[0] = dbg_rt_entry; o[1] = dbg_rt_loop; o[2] = dbg_rt_loop_end; o[3] = __builtin_amdgcn_s_memrealtime(); o[4] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
     }
     if (lane == 0 && blockIdx.x < 64) {
@@ -1092,66 +905,19 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
         atomicAdd(&cvar_gemm_dbg_tot[6], dbg_ew); atomicAdd(&cvar_gemm_dbg_tot[3], dbg_vm); atomicAdd(&cvar_gemm_dbg_tot[4], dbg_bar); atomicAdd(&cvar_gemm_dbg_tot[5], dbg_comp);
     }
 #endif
-    if constexpr (!PERS) break;
-    if (vnext < 0) break;                 // wave-uniform: this workgroup's part of the tile space is used up
-    __syncthreads();                      // all staging rows have been read (the next tile's K tile 1 is about to land on them); pers_slot is published
-    vtile = vnext;
-    vnext = __builtin_amdgcn_readfirstlane(pers_slot);
-    pers_first = false;
-#ifdef CVAR_GEMM_TIMING
-    dbg_rt_entry = __builtin_amdgcn_s_memrealtime();
-#endif
-    }   // tile loop
-    if constexpr (PERS) {
-        // exit protocol: the last workgroup out clears the launch's counters for the slot's next user
-        if (wave == 0 && lane == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the pending tile fetch has been performed
-            const unsigned old = __hip_atomic_fetch_add(p.pers_ctr + 8, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == gridDim.x - 1) {
-#pragma unroll
-                for (int x = 0; x < 9; ++x) __hip_atomic_store(p.pers_ctr + x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2, bool FAST = false, bool CUP = false, bool PERS = false>
+template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2, bool FAST = false, bool CUP = false>
 __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParams p) {
-    cvar_gemm_tile<T, BM, BN, WM, WN, CONV, NSTAGE, FAST, CUP, PERS>(p);
+    cvar_gemm_tile<T, BM, BN, WM, WN, CONV, NSTAGE, FAST, CUP>(p);
 }
 
 // One output quad of a split-K GEMM: the slices' fp32 partials summed in slice order (bit-reproducible), then the complete epilogue of `p`.
-template <bool SC1 = false>
 __device__ __forceinline__ void splitk_finish_quad(const GemmParams& p, const float* __restrict__ part, int nsplit, int m, int n) {
     f32x4_t v;
     const float* const q0 = part + (long)m * p.N + n;
     const long sstride = (long)p.M * p.N;
-    if constexpr (SC1) {
-        // slices 0 .. 7 in one batch (slots past the last slice re-read the last one and are ignored), then further batches of eight
-        f32x4_t w[8];
-        const float* ptr[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) ptr[u] = q0 + (long)min(u, nsplit - 1) * sstride;
-        load8_f32x4_sc1(w, ptr);
-        v = w[0];
-#pragma unroll
-        for (int u = 1; u < 8; ++u)
-            if (u < nsplit) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += w[u][e];
-            }
-        for (int s0 = 8; s0 < nsplit; s0 += 8) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) ptr[u] = q0 + (long)min(s0 + u, nsplit - 1) * sstride;
-            load8_f32x4_sc1(w, ptr);
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (s0 + u < nsplit) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += w[u][e];
-                }
-        }
-    } else {
+    {
         v = *(const f32x4_t*)q0;
         // the loads of the slices are independent: eight in flight at a time (a one-load-one-add loop is a chain of up to 15 memory latencies)
         for (int s0 = 1; s0 < nsplit; s0 += 8) {
@@ -1170,34 +936,6 @@ __device__ __forceinline__ void splitk_finish_quad(const GemmParams& p, const fl
     gemm_epilogue_quad(p, m, n, v);
 }
 
-// Split-K with the reduction folded into the GEMM launch (round 4): every slice stores its fp32 partial tile as before, then signs a per-tile
-// counter; the slice that signs LAST sums the tile's partials in slice order - the same order, hence the same bits, as cvar_splitk_epilogue_kernel -
-// and applies the epilogue.  One launch instead of two for every small-M GEMM: 859 epilogue launches of 6.5 us in a B = 1 generation
-// (profiles/r04_b1_kernel_stats.txt).  ps = the slice view (C = workspace, plain fp32 stores), pf = the call's own parameters.
-template <typename T, int BM, int BN, int WM, int WN, int NSTAGE, bool FAST>
-__global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_splitk_fused_kernel(const GemmParams ps, const GemmParams pf, unsigned* __restrict__ ctr, int nsplit) {
-    cvar_gemm_tile<T, BM, BN, WM, WN, false, NSTAGE, FAST, false, false, true>(ps);       // partial tile stored with sc1 (write-through)
-    __shared__ int sk_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's partial stores are acknowledged at device scope ...
-    __syncthreads();                                       // ... every wave's are
-    if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(ctr + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sk_last = old == (unsigned)nsplit - 1u;
-        if (old == (unsigned)nsplit - 1u) __hip_atomic_store(ctr + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // ready for the slot's next user
-    }
-    __syncthreads();
-    if (!sk_last) return;
-    int m0, n0;
-    gemm_tile_origin(ps, (int)blockIdx.x, BM, BN, m0, n0);
-    const int rows = min(BM, pf.M - m0), cols4 = min(BN, pf.N - n0) / 4;
-    const float* part = (const float*)ps.C;
-    for (int i = threadIdx.x; i < rows * cols4; i += WM * WN * 64) {
-        const int m = m0 + i / cols4, n = n0 + (i % cols4) * 4;
-        splitk_finish_quad<true>(pf, part, nsplit, m, n);       // sc1 loads: the other slices' partials as the device sees them
-    }
-}
-
-
 // hipFuncAttributeMaxDynamicSharedMemorySize is sticky per (function, device): set it the first time a kernel is launched on a
 // device instead of on every launch (~1200 launches per generation)
 template <typename K>
@@ -1211,78 +949,9 @@ static void set_max_lds_once(K kfn, size_t lds) {
     }
 }
 
-// ---- persistent kernels: per-launch tile counters.  A ring of self-resetting slots in device memory (9 words used per slot: one counter per
-// XCD + the exit counter whose last incrementer zeroes the slot).  A launch takes the next slot; by the time the ring comes round
-// (CVAR_PERS_SLOTS launches later) the slot's previous user has long finished.  A captured HIP graph replays the slot baked into its node,
-// which is fine for the same reason as long as the graph does not run concurrently with itself.
-// Built, bit-identical to the one-tile kernels (tests/test_gpu_kernels.py::test_persistent_gemm_...), measured NEUTRAL on every d24 shape
-// (profiles/r04_gemm_persistent_rejected.txt: what it saves in dispatch gap and prologue it pays in a longer epilogue and its own per-tile
-// setup; the epilogue - 4.7 us of a 41 us tile at K = 1536 - is what neither form overlaps).  Compiled only with -DCVAR_GEMM_PERS=1.
-#ifndef CVAR_GEMM_PERS
-#define CVAR_GEMM_PERS 0
-#endif
-#if CVAR_GEMM_PERS
-#define CVAR_PERS_SLOTS 4096
-__device__ unsigned cvar_pers_counters[CVAR_PERS_SLOTS * 16];
-static unsigned* pers_counters(int* ncu) {
-    static unsigned* base[64] = {nullptr};
-    static int cus[64] = {0};
-    static unsigned next = 0;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64) return nullptr;
-    if (!base[dev]) {
-        void* ptr = nullptr;
-        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(cvar_pers_counters)) != hipSuccess) return nullptr;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
-        cus[dev] = prop.multiProcessorCount;
-        base[dev] = (unsigned*)ptr;
-    }
-    *ncu = cus[dev];
-    const unsigned slot = __atomic_fetch_add(&next, 1u, __ATOMIC_RELAXED) % CVAR_PERS_SLOTS;
-    return base[dev] + (size_t)slot * 16;
-}
-#else
-static unsigned* pers_counters(int*) { return nullptr; }
-#endif   // CVAR_GEMM_PERS
-
-// ---- fused split-K: per-tile arrival counters.  Same ring-of-self-resetting-slots scheme as the persistent kernels' counters: a launch takes the
-// next slot of CVAR_SK_TILES words (all zero: the last slice to sign a tile's counter clears it), the ring comes round after CVAR_SK_SLOTS launches.
-// Built, bit-identical to the two-kernel form (tests/test_gpu_kernels.py::test_fused_split_k_...), SLOWER (profiles/r04_small_batch.txt): a device-scope
-// fence per slice (buffer_wbl2 + buffer_inv of the whole L2) costs 63 us per GEMM, per-access sc1 stores / loads still 30 us - the one workgroup that
-// reduces a tile reads all its slices at memory latency, where the separate epilogue kernel spreads the same bytes over the chip.  Compiled only
-// with -DCVAR_GEMM_FUSED_SPLITK=1.
-#ifndef CVAR_GEMM_FUSED_SPLITK
-#define CVAR_GEMM_FUSED_SPLITK 0
-#endif
-#define CVAR_SK_TILES 256
-#if CVAR_GEMM_FUSED_SPLITK
-#define CVAR_SK_SLOTS 2048
-__device__ unsigned cvar_splitk_counters[CVAR_SK_SLOTS * CVAR_SK_TILES];
-static unsigned* splitk_counters() {
-    static unsigned* base[64] = {nullptr};
-    static unsigned next = 0;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64) return nullptr;
-    if (!base[dev]) {
-        void* ptr = nullptr;
-        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(cvar_splitk_counters)) != hipSuccess) return nullptr;
-        base[dev] = (unsigned*)ptr;
-    }
-    const unsigned slot = __atomic_fetch_add(&next, 1u, __ATOMIC_RELAXED) % CVAR_SK_SLOTS;
-    return base[dev] + (size_t)slot * CVAR_SK_TILES;
-}
-#else
-static unsigned* splitk_counters() { return nullptr; }
-#endif   // CVAR_GEMM_FUSED_SPLITK
-
 template <typename T, int BM, int BN, int WM, int WN, int NSTAGE = 2, bool CONVFAST = false, bool CUP = false>
 static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     GemmParams p = gp;
-    // tiles a split-K launch can land on (launch_typed): 64x128, 128x128, the 4-wave 256x256 - only these carry a fused-reduction instance
-    constexpr bool SK_TILE = (BM == 64 && BN == 128) || (BM == 128 && BN == 128) || (BM == 256 && BN == 256 && WN == 2);
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     // Group height.  Within a group the A row blocks (GM x BM x K) are re-read once per column tile and the W tile once per group;
@@ -1291,7 +960,6 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     // neutral or -1 % for the K = 1536 bf16-output GEMMs; 16 loses everywhere.
     if (p.group_m <= 0) p.group_m = (!p.conv && ((long)p.K * (long)sizeof(T) >= 8192 || p.out_dtype == CVAR_F32)) ? 4 : 8;
     if (p.conv) { const int kt_e = 128 / (int)sizeof(T); p.cv_adv = kt_e / p.Cin; p.cv_rem = kt_e % p.Cin; }
-    if (p.sk_final && !(SK_TILE && sizeof(T) == 2 && !p.conv)) return CVAR_EUNSUPPORTED;        // a fused split-K launch must reach a kernel that reduces
     const size_t lds = NSTAGE * (BM + BN) * 128;
     const int nk_all = (p.K + (128 / (int)sizeof(T)) - 1) / (128 / (int)sizeof(T));
     const int splits = p.split_tiles > 0 ? (nk_all + p.split_tiles - 1) / p.split_tiles : 1;
@@ -1318,45 +986,10 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
         return CVAR_EUNSUPPORTED;
     } else if (p.K % (128 / (int)sizeof(T)) == 0 && (long)(BM - 1) * p.lda * (long)sizeof(T) + (long)p.K * (long)sizeof(T) < (1L << 31) &&
                (long)(BN - 1) * p.ldw * (long)sizeof(T) + (long)p.K * (long)sizeof(T) < (1L << 31)) {
-        // persistent form of the 256x256 bf16 tiles: at least two rounds of tiles, no split-K / batch dimension, tile_cfg 7 / 8 select the one-tile-per-workgroup kernels (8 / 4 waves) for A/B runs
-        if constexpr (CVAR_GEMM_PERS != 0 && sizeof(T) == 2 && BM == 256 && BN == 256 && NSTAGE == 2) {
-            int ncu = 0;
-            const int ntiles = p.tiles_m * p.tiles_n;
-            if (splits == 1 && batch == 1 && p.stagger == 0 && p.tile_cfg != 7 && p.tile_cfg != 8 && nk_all >= 4) {
-                unsigned* ctr = pers_counters(&ncu);
-                const int gx = (ncu / 8) * 8;
-                if (ctr && gx >= 8 && ntiles >= 2 * gx) {
-                    p.pers_ctr = ctr;
-                    auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, false, NSTAGE, true, false, true>;
-                    set_max_lds_once(kfn, lds);
-                    hipLaunchKernelGGL(kfn, dim3((unsigned)gx), block, lds, st, p);
-                    CVAR_CHECK_LAUNCH();
-                    return CVAR_OK;
-                }
-            }
-        }
-        if constexpr (sizeof(T) == 2 && CVAR_GEMM_FUSED_SPLITK != 0 && CVAR_TU_PLAIN && !CVAR_TU_CONV && SK_TILE) {
-            if (p.sk_final) {
-                auto kfn = cvar_gemm_splitk_fused_kernel<T, BM, BN, WM, WN, NSTAGE, true>;
-                set_max_lds_once(kfn, lds);
-                hipLaunchKernelGGL(kfn, grid, block, lds, st, p, *p.sk_final, p.sk_ctr, p.sk_nsplit);
-                CVAR_CHECK_LAUNCH();
-                return CVAR_OK;
-            }
-        }
         auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, false, NSTAGE, true>;
         set_max_lds_once(kfn, lds);
         hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
     } else {
-        if constexpr (sizeof(T) == 2 && CVAR_GEMM_FUSED_SPLITK != 0 && CVAR_TU_PLAIN && !CVAR_TU_CONV && SK_TILE) {
-            if (p.sk_final) {
-                auto kfn = cvar_gemm_splitk_fused_kernel<T, BM, BN, WM, WN, NSTAGE, false>;
-                set_max_lds_once(kfn, lds);
-                hipLaunchKernelGGL(kfn, grid, block, lds, st, p, *p.sk_final, p.sk_ctr, p.sk_nsplit);
-                CVAR_CHECK_LAUNCH();
-                return CVAR_OK;
-            }
-        }
         auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, false, NSTAGE>;
         set_max_lds_once(kfn, lds);
         hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
@@ -1489,7 +1122,7 @@ int cvar_gemm_launch_conv_bf16(const GemmParams& p, int batch, hipStream_t st) {
 __global__ __launch_bounds__(256) void cvar_splitk_epilogue_kernel(const float* __restrict__ part, int nsplit, const GemmParams p) {
     const long nvec = (long)p.M * (p.N / 4);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256)
-        splitk_finish_quad<false>(p, part, nsplit, (int)(i / (p.N / 4)), (int)(i % (p.N / 4)) * 4);
+        splitk_finish_quad(p, part, nsplit, (int)(i / (p.N / 4)), (int)(i % (p.N / 4)) * 4);
 }
 
 
@@ -1541,7 +1174,6 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     make_fast_div(p.remap_l, &p.remap_magic, &p.remap_shift);
     make_fast_div(p.gate ? p.gate_rows : 1, &p.gate_magic, &p.gate_shift);
     p.split_tiles = 0; p.split_stride = 0;
-    p.pers_ctr = nullptr; p.sk_final = nullptr; p.sk_ctr = nullptr; p.sk_nsplit = 0;
     p.tile_cfg = d->tile_cfg; p.stagger = d->stagger > 0 ? d->stagger : 0; p.group_m = d->group_m > 0 ? d->group_m : 0;
     // split-K workspace: part of the call (caller-owned, any stream / device), nothing process-wide
     float* const g_splitk_ws = (d->ws && d->ws_bytes > 0 && (((uintptr_t)d->ws & 15) == 0)) ? (float*)d->ws : nullptr;
@@ -1632,18 +1264,6 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
             ps.alpha = 1.0f; ps.bias = nullptr; ps.act = CVAR_ACT_NONE; ps.gate = nullptr; ps.residual = nullptr; ps.C2 = nullptr; ps.aux = nullptr; ps.gate_scale = nullptr;
             ps.C = g_splitk_ws; ps.out_dtype = CVAR_F32; ps.ldc = d->N; ps.remap_l = 0; ps.split_n = 0; ps.Cs = nullptr; ps.strideC = 0;
             ps.split_tiles = per; ps.split_stride = (long)d->M * d->N;
-            // one launch: the last slice of every tile reduces and finishes it (bf16 operands; tile_cfg 9 keeps the two-kernel form for A/B runs)
-            if (CVAR_GEMM_FUSED_SPLITK && d->dtype == CVAR_BF16 && d->tile_cfg != 9 && d->N % 8 == 0) {      // N % 8: the partial tiles go out as 16-byte sc1 stores
-                const int t_m = d->M <= 64 ? (d->M + 63) / 64 : long_k_splits ? (d->M + 255) / 256 : (d->M + 127) / 128;
-                const int t_n = long_k_splits ? (d->N + 255) / 256 : (d->N + 127) / 128;
-                unsigned* ctr = (long)t_m * t_n <= CVAR_SK_TILES ? splitk_counters() : nullptr;
-                if (ctr) {
-                    GemmParams pfin = p;
-                    pfin.tile_cfg = 0;
-                    ps.sk_final = &pfin; ps.sk_ctr = ctr; ps.sk_nsplit = splits;
-                    return ln_after(launch_typed<bf16_t>(ps, 1, st));
-                }
-            }
             const int rc = d->dtype == CVAR_BF16 ? launch_typed<bf16_t>(ps, 1, st) : cvar_gemm_launch_f32(ps, 1, st);
             if (rc != CVAR_OK) return rc;
             return finish_slices(splits);
@@ -1657,9 +1277,10 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
         d->ldw == d->K &&      // the halo kernel addresses packed [Cout][9 Cin] weights: padded weight rows stay on the implicit-GEMM path
         (!d->bias || (((uintptr_t)d->bias & 15) == 0)) && (long)d->Hin * d->Win * d->Cin * 2 < 0x7fffffffL) {
         // wide form: Cout a multiple of 160, bf16 output, optional bf16 residual; two workgroups per CU or the implicit-GEMM tiles win (640->640 at 16x16)
-        const bool wide = d->N % 160 == 0 && d->out_dtype == CVAR_BF16 && (((uintptr_t)d->C & 7) == 0) &&
-                          (!d->residual || (d->res_dtype == CVAR_BF16 && d->ldr == d->N && (((uintptr_t)d->residual & 7) == 0))) &&
-                          true;       // round 4: at any grid size - small batches (B = 1: 36.5 -> 34.9 ms, B = 8: 71.0 -> 69.8 ms per generation, profiles/r04_small_batch.txt) gain too
+        // (16-byte alignment and < 2^31 elements per output image: the row-major epilogue moves bf16x8 vectors at 32-bit offsets inside an image)
+        const bool wide = d->N % 160 == 0 && d->out_dtype == CVAR_BF16 && (((uintptr_t)d->C & 15) == 0) &&
+                          (!d->residual || (d->res_dtype == CVAR_BF16 && d->ldr == d->N && (((uintptr_t)d->residual & 15) == 0))) &&
+                          (long)d->Hout * d->Wout * d->N < 0x7fffffffL;       // round 4: at any grid size - small batches (B = 1: 36.5 -> 34.9 ms, B = 8: 71.0 -> 69.8 ms per generation, profiles/r04_small_batch.txt) gain too
         // narrow form: Cout <= 32 (conv_out, 160 -> 3), bf16 or fp32 output, no residual - the implicit-GEMM tile spends its time re-fetching the input
         // (decided by the IMAGE size, not by the batch: the two kernels sum K in different orders, and an image's pixels must not depend on the batch it rides in)
         const bool narrow = d->N <= 32 && !d->residual && (d->out_dtype == CVAR_BF16 || d->out_dtype == CVAR_F32) && ((long)d->Hout * d->Wout >= 65536 || d->tile_cfg == 6);

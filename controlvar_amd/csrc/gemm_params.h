@@ -30,9 +30,6 @@ struct GemmParams {
     int group_m;              // row tiles per scheduling group (see launch_cfg)
     int stagger;              // > 0: the first wave of workgroups (one per CU) starts spread over this many shader cycles (see cvar_gemm_kernel)
     int tile_cfg;             // cvar_gemm_desc::tile_cfg (0 = automatic)
-    unsigned* pers_ctr;       // persistent kernels: this launch's 8 tile counters (one per XCD) + 1 exit counter, all zero at launch (self-resetting)
-    // fused split-K (host side of launch_cfg only): the call's own parameters, the launch's per-tile arrival counters, the slice count
-    const GemmParams* sk_final; unsigned* sk_ctr; int sk_nsplit;
 };
 
 

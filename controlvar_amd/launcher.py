@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import os
 import time
-from typing import Callable, Optional, Tuple
+from typing import Callable, Optional, Sequence, Tuple
 
 import torch
 
@@ -95,6 +95,42 @@ def collective_evidence(device: Optional[torch.device] = None) -> dict:
         except Exception:                                   # never lose the bench line over a version string
             ver = 'unknown'
     return {'collective_backend': 'rccl' if backend == 'nccl' else backend, 'rccl_ranks': int(round(float(one.item()))), 'rccl_version': ver}
+
+
+def channel_groups(candidates: Sequence[Optional[int]] = (None, 16, 8)):
+    """One process group per RCCL channel cap (``ncclConfig_t.maxCTAs`` through ProcessGroupNCCL.Options - a PER-COMMUNICATOR setting, unlike
+    NCCL_MAX_NCHANNELS, which RCCL reads once per process): None = the default group (RCCL's own choice).  An all-reduce kernel occupies one
+    workgroup per channel; the backward GEMMs it overlaps with are sized to exactly 256 CUs (gemm.hip tile plan), so how many CUs the exchange
+    takes is a real trade the first 8-GPU run has to settle by measurement.  Under gloo (CPU tests of the
+    selection logic) every candidate is a plain new group.  Every rank must call this with the same candidates."""
+    import torch.distributed as dist
+    out = {}
+    for c in candidates:
+        if c is None or not dist.is_initialized():
+            out[c] = None
+        elif dist.get_backend() == 'nccl':
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.config.max_ctas = int(c)
+            opts.config.min_ctas = min(int(c), 1)
+            out[c] = dist.new_group(pg_options=opts)
+        else:
+            out[c] = dist.new_group()
+    return out
+
+
+def pick_fastest(labels: Sequence, seconds_of: Callable[[object], float], device: Optional[torch.device] = None):
+    """Run ``seconds_of(label)`` for every label on every rank, agree on the MAX over ranks of each (one all-reduce, so that all ranks take
+    the same decision from the same numbers) and return (label with the smallest time - the first on ties -, {label: seconds})."""
+    import torch.distributed as dist
+    local = [float(seconds_of(lb)) for lb in labels]
+    t = torch.tensor(local, dtype=torch.float64)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == 'nccl':
+            t = t.to(device if device is not None else 'cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    agreed = [float(x) for x in t.cpu()]
+    best = min(range(len(labels)), key=lambda i: (agreed[i], i))
+    return labels[best], {labels[i]: agreed[i] for i in range(len(labels))}
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------

@@ -668,6 +668,12 @@ class Trainer:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.force_reducer = force_reducer
         self.comm = True                        # False: skip the gradient exchange (bench.py measures the exposed communication time with it)
+        self.comm_group = None                  # process group of the gradient exchange (None = default); see set_comm_group
+        self._reducer_for = None
+
+    def set_comm_group(self, group):
+        """run the gradient all-reduce in `group` from the next step on (launcher.channel_groups: one group per RCCL channel cap)"""
+        self.comm_group = group
         self._reducer_for = None
 
     @torch.no_grad()
@@ -710,7 +716,7 @@ class Trainer:
         self.engine._setup(x.shape[0])
         if (self.world > 1 or self.force_reducer) and self.comm:
             if self._reducer_for is not self.engine.buckets:
-                self._reducer = BucketReducer(self.engine.buckets, force=self.force_reducer)
+                self._reducer = BucketReducer(self.engine.buckets, group=self.comm_group, force=self.force_reducer)
                 self._reducer_for = self.engine.buckets
             self.engine.reducer = self._reducer
         else:

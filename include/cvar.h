@@ -77,8 +77,8 @@ typedef struct {
      *   tile_cfg      0 automatic; 1 only 128x128 tiles; 2 the 8-wave 256x256 tile wherever it applies; 3 the 4-wave 256x256
      *                 tile (A/B measurements - results are bit-identical across tile choices of one split-K decision); 5: 3x3 convs
      *                 stay on the implicit-GEMM tiles, 6: eligible 3x3 convs take the LDS-halo kernel at any size (conv_halo.hip sums
-     *                 K chunk-major instead of tap-major: same math, different fp32 rounding); 7 / 8: the 8- / 4-wave 256x256 tile as ONE tile per
-     *                 workgroup instead of the persistent kernel that large launches take since round 4 (same sums, bit-identical);
+     *                 K chunk-major instead of tap-major: same math, different fp32 rounding); 7 / 8: aliases of 2 / 3 (the A/B arms of the
+     *                 round-4 persistent-kernel experiment, which is no longer in the library: experiments/README.md);
      *                 12: as 0, and a small-M bf16 call (M <= 512) may take the weight-streaming kernel of gemm_skinny.hip - whole K per workgroup, no
      *                 reduction launch (long K: a few K slices finished row-wise).  Same math; the fp32 summation order then depends on the plan chosen for
      *                 (M, N, K), so callers that promise bit-identical rows across batch sizes (the VQVAE) stay on 0.  The transformer's passes use 12

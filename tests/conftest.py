@@ -70,11 +70,12 @@ def ids_parity(got, ref, margin, tol, what, strict=True):
     return n, rows_ok
 
 
-def maxabs_on(diff, rows_ok):
-    """max |diff| over the batch rows without an id flip; 0.0 when no row qualifies (a tolerated flip in every row must not turn into
-    'max of an empty tensor')"""
+def maxabs_on(diff, rows_ok, min_rows=1):
+    """max |diff| over the batch rows without an id flip.  At least ``min_rows`` rows must qualify (with none the check
+    compared nothing and passed); a caller that tolerates an all-flipped batch says so with ``min_rows=0`` and gets 0.0."""
     import torch
     ok = torch.as_tensor(np.asarray(rows_ok), dtype=torch.bool)
+    assert int(ok.sum()) >= min_rows, f'float parity check has {int(ok.sum())} flip-free rows of {ok.numel()}, needs {min_rows}'
     if not bool(ok.any()):
         return 0.0
     return float(diff[ok].abs().max())

@@ -41,3 +41,21 @@ def test_bench_under_torchrun_env_is_one_rank_of_the_world():
 def test_bench_refuses_more_gpus_than_visible():
     p = _run(['--gpus', '3'], dict(HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES=''))
     assert p.returncode != 0 and 'refusing' in (p.stderr + p.stdout)
+
+
+def test_channel_selection_picks_the_fastest_candidate_on_every_rank():
+    """the channel-cap selection of `bench.py --mode train` (launcher.channel_groups + pick_fastest) with sleeping candidates on
+    two gloo ranks: candidates (default, 16, 8) 'cost' 60 / 15 / 30 ms per step on rank 0 and twice that on rank 1 - the agreed (max over ranks)
+    table must order them 16 < 8 < default and the line must carry the choice and the table."""
+    p = _run(['--gpus', '2', '--steps', '2', '--warmup', '0', '--stub-step-ms', '5', '--stub-comm-ms', '60,15,30'])
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+    assert out['comm_channels'] == '16', out
+    tried = out['comm_channels_tried_s']
+    assert list(tried) == ['default', '16', '8'] and tried['16'] < tried['8'] < tried['default']
+    assert tried['16'] >= 0.028 and tried['default'] >= 0.115            # the slow rank (2 x) sets each candidate's clock
+    # a fixed choice runs no tuning
+    p = _run(['--gpus', '2', '--steps', '2', '--warmup', '0', '--stub-step-ms', '5', '--stub-comm-ms', '60', '--comm-channels', '8'])
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][0])
+    assert out['comm_channels'] == '8' and out['comm_channels_tried_s'] == {}

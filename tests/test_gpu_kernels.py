@@ -658,105 +658,6 @@ def test_gemm_split_alpha_scales_only_the_split_columns(gpu_device, R, l, C, K):
     assert (got != want).float().mean().item() < 0.02
 
 
-# ------------------------------------------------------------------------------------------------ round 4: persistent 256x256 GEMM
-@pytest.mark.parametrize('wv', [0, 3])
-@pytest.mark.parametrize('M,N,K', [(40000, 1024, 512), (33000, 1920, 256), (16384, 2048, 1536)])
-def test_persistent_gemm_equals_the_one_tile_per_workgroup_kernel(gpu_device, M, N, K, wv):
-    """With -DCVAR_GEMM_PERS=1 (not the default build: measured neutral, profiles/r04_gemm_persistent_rejected.txt) launches of >= 2 rounds
-    of 256x256 tiles take the persistent kernel (one workgroup per CU walks over tiles handed out by per-XCD counters; the DMA stream runs
-    on across tile boundaries); in the default build tile_cfg 0 / 3 and 7 / 8 are the same kernels and this checks run-to-run determinism
-    of every epilogue on large launches.  Same sums in the same order: every epilogue the transformer uses must come
-    out BIT-IDENTICAL to the one-tile-per-workgroup kernel (tile_cfg 7 / 8), incl. a ragged last row tile, a half-filled last column tile
-    (N = 1920), the K/V-arena row remap with the q column split, and repeated launches (the self-resetting tile counters)."""
-    from controlvar_amd import ops
-    g = torch.Generator().manual_seed(M + N + K)
-    A = (torch.randn(M, K, generator=g)).to(torch.bfloat16).to(gpu_device)
-    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(gpu_device)
-    bias = torch.randn(N, generator=g).to(gpu_device)
-    l = 250
-    R = (M + l - 1) // l
-    ada = (torch.randn(R, 2 * N, generator=g) * 0.3).to(gpu_device)
-    res0 = (torch.randn(M, N, generator=g) * 0.5).to(gpu_device)
-
-    def run(cfg, kind):
-        ops.GEMM_TILE_CFG = cfg
-        try:
-            if kind == 'plain':
-                out = torch.full((M, N), float('nan'), device=gpu_device, dtype=torch.bfloat16)
-                ops.gemm(A, W, out, M=M, N=N, K=K, bias=bias)
-                return out
-            if kind == 'gelu':
-                out = torch.full((M, N), float('nan'), device=gpu_device, dtype=torch.bfloat16)
-                ops.gemm(A, W, out, M=M, N=N, K=K, bias=bias, act=ops.ACT_GELU_TANH)
-                return out
-            if kind == 'gate_res':
-                out = res0.clone()
-                ops.gemm(A, W, out, M=M, N=N, K=K, bias=bias, gate=ada, gate_off=N, ldg=2 * N, gate_rows=l, residual=out)
-                return out
-            if kind == 'remap_split':
-                Lmax, sn = 300, (N // 3 // 8) * 8
-                arena = torch.full((R * Lmax, N - sn), float('nan'), device=gpu_device, dtype=torch.bfloat16)
-                q = torch.full((M, sn), float('nan'), device=gpu_device, dtype=torch.bfloat16)
-                ops.gemm(A, W, arena, M=M, N=N, K=K, bias=bias, ldc=N - sn, remap=(l, Lmax, 17), split=(q, sn, sn), split_alpha=0.18)
-                return torch.cat((q.float().flatten(), torch.nan_to_num(arena.float().flatten(), nan=123.0)))
-        finally:
-            ops.GEMM_TILE_CFG = 0
-    for kind in ('plain', 'gelu', 'gate_res', 'remap_split'):
-        if kind == 'remap_split' and M > R * l:
-            continue
-        ref = run(7 if wv == 0 else 8, kind)
-        for rep in range(3):
-            got = run(wv, kind)
-            assert torch.equal(torch.nan_to_num(got.float(), nan=77.0), torch.nan_to_num(ref.float(), nan=77.0)), (kind, rep)
-        if kind == 'plain':
-            want = A.float() @ W.float().t() + bias
-            assert not torch.isnan(ref.float()).any()
-            assert (ref.float() - want).abs().max() < 0.06 * max(1.0, float(want.abs().max()) / 8)
-
-
-@pytest.mark.parametrize('M,N,K', [(4, 4608, 1536), (36, 1536, 6144), (100, 6144, 1536), (256, 1536, 1536), (676, 1536, 6144), (1024, 4608, 1536)])
-def test_fused_split_k_is_bit_identical_to_the_two_kernel_form(gpu_device, M, N, K):
-    """Small-M GEMMs are split along K.  With -DCVAR_GEMM_FUSED_SPLITK=1 (not the default build: measured slower, profiles/r04_small_batch.txt)
-    the slice that signs a tile's arrival counter last sums the tile's fp32 partials in slice order and applies the epilogue inside the same
-    launch (cvar_gemm_splitk_fused_kernel) - same order, same bits as the second launch (cvar_splitk_epilogue_kernel, tile_cfg 9).  In the
-    default build both settings are the two-kernel form and this checks its run-to-run determinism over every epilogue of the transformer."""
-    from controlvar_amd import ops
-    g = torch.Generator().manual_seed(M * 7 + N + K)
-    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(gpu_device)
-    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(gpu_device)
-    bias = torch.randn(N, generator=g).to(gpu_device)
-    l = max(M // 2, 1)
-    R = (M + l - 1) // l
-    ada = (torch.randn(R, 2 * N, generator=g) * 0.3).to(gpu_device)
-    res0 = (torch.randn(M, N, generator=g) * 0.5).to(gpu_device)
-
-    def run(cfg, kind):
-        ops.GEMM_TILE_CFG = cfg
-        try:
-            if kind == 'plain':
-                out = torch.full((M, N), float('nan'), device=gpu_device, dtype=torch.bfloat16)
-                ops.gemm(A, W, out, M=M, N=N, K=K, bias=bias)
-            elif kind == 'gelu':
-                out = torch.full((M, N), float('nan'), device=gpu_device, dtype=torch.bfloat16)
-                ops.gemm(A, W, out, M=M, N=N, K=K, bias=bias, act=ops.ACT_GELU_TANH)
-            elif kind == 'gate_res':
-                out = res0.clone()
-                ops.gemm(A, W, out, M=M, N=N, K=K, bias=bias, gate=ada, gate_off=N, ldg=2 * N, gate_rows=l, residual=out)
-            else:
-                out = torch.full((M, N), float('nan'), device=gpu_device, dtype=torch.float32)
-                ops.gemm(A, W, out, M=M, N=N, K=K)
-            return out
-        finally:
-            ops.GEMM_TILE_CFG = 0
-    for kind in ('plain', 'gelu', 'gate_res', 'f32out'):
-        ref = run(9, kind)
-        assert not torch.isnan(ref.float()).any(), kind
-        for rep in range(3):
-            assert torch.equal(run(0, kind), ref), (kind, rep)
-    want = A.float() @ W.float().t() + bias
-    assert (run(0, 'plain').float() - want).abs().max() < 0.06 * max(1.0, float(want.abs().max()) / 8)
-
-
 # ---- round 4 (second half): the weight-streaming small-M kernel (gemm_skinny.hip) and the row-finishing split-K reduction with the adaLN behind it
 def _skinny_case(gpu_device, M, N, K, seed):
     g = torch.Generator().manual_seed(seed)

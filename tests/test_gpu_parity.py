@@ -499,6 +499,10 @@ def test_full_size_d24_properties(gpu_device):
     assert all(torch.equal(c, d) for c, d in zip(code, code2))                     # encode is deterministic
     fh = vae.idxBl_to_h(code)                                                      # and its teacher-forcing features are finite
     assert all(torch.isfinite(f).all() for f in fh)
+    # bounded-error round trip: the fused encode -> quantise -> decode entry point must land on the image the two-call
+    # form reconstructs (same ids, same f_hat arithmetic, same decoder), inside [-1, 1]
+    rec2 = vae.img_to_recon(img, last_one=True).clamp(-1, 1)                        # vqvae.py:80-86 does not clamp, idxBl_to_img does (:88-89)
+    assert float(rec.abs().max()) <= 1.0 and float((rec2 - rec).abs().max()) <= 2e-2
 
 
 def test_ms_encode_fast_search_equals_sequential_search_incl_ties(gpu_device):

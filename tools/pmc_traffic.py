@@ -20,5 +20,10 @@ label = sys.argv[1] if len(sys.argv) > 1 else 'one d24 generation'
 res = dict(kernel=f'cvar_gemm_kernel + conv3x3_halo_bf16_kernel (all launches of {label})', fetch_bytes_per_launch=fetch, write_bytes_per_launch=write,
            bytes_per_launch=fetch + write, launches=out.get('FETCH_SIZE', {}).get('launches'), note='FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950)',
            collected=f'separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (tools/final_measure.sh) of {label}; mean over the GEMM-family launches')
+try:      # stamp: the library the counters were collected on (digest of the kernel sources; .git does not travel to the GPU box)
+    import os
+    res['lib_digest'] = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'controlvar_amd', 'csrc', 'build', 'digest.txt')).read().strip()[:16]
+except OSError:
+    res['lib_digest'] = None
 print(json.dumps(res))
 json.dump(res, open('gpurun_out/gemm_hbm_traffic.json', 'w'))
