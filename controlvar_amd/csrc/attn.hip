@@ -1123,8 +1123,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
     }
 }
 
-template <bool HOLES> __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdParams p);
-template <bool HOLES> __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdParams p);
+template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_mfma_kernel(const AttnBwdParams p);
+template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_mfma_kernel(const AttnBwdParams p);
 
 // ws: R*H*l floats (D = rowsum(dO * O)).  impl: 0 = auto (MFMA kernels for bf16, row-wise exact kernels for fp32), 1 = row-wise
 static int cvar_attention_bwd_impl(const void* qkv, int dtype, const void* o, const void* dout, const float* lse, int R, int H, int Lmax,
@@ -1171,73 +1171,56 @@ static int cvar_attention_bwd_impl(const void* qkv, int dtype, const void* o, co
 //                       Q^T / dO^T staged transposed.
 // P is recomputed from the saved log-sum-exp; fp32 accumulation everywhere.
 // ================================================================================================
-constexpr int BW_T_STRIDE = 68;
+// Round 5: the transposed operands (K^T for dQ, Q^T / dO^T for dK / dV) are no longer built on the way INTO LDS (8 pack operations + 8 ds_write_b32
+// per thread, tile and image, on the vector pipe that bounds these kernels): every 64 x 64 tile is stored row-major twice - once with the 16-byte chunks
+// XOR-swizzled by (row >> 1) & 7 for ds_read_b128 fragment reads along a row, once with the 32-byte segments swizzled by row & 3 for
+// ds_read_b64_tr_b16 transpose reads (the layout of the forward kernel's V tile) - two ds_write_b128 per image.  Tiles whose keys every query of the tile
+// sees (all but the level-boundary ones) run a compile-time unmasked body: no per-score compare / select, no visibility tables.
 
-// row-major 64 x 64 bf16 tile -> LDS rows of 128 B, chunk index XOR-swizzled by (row>>1)&7
-__device__ __forceinline__ void bw_stage_rowmajor(char* dst, const bf16_t* src, long row_stride, int row0, int row_limit, int tid) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (tid >> 3) + 32 * i, chunk = tid & 7;
-        bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-        const bf16x8_t v = (row0 + row) < row_limit ? *(const bf16x8_t*)(src + (long)(row0 + row) * row_stride + chunk * 8) : z;
-        *(bf16x8_t*)(dst + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = v;
-    }
-}
-// 64 rows x 64 cols -> transposed LDS image T[col][row] with rows of BW_T_STRIDE elements (two rows packed per 32-bit write)
-__device__ __forceinline__ void bw_stage_transposed(bf16_t* dst, const bf16_t* src, long row_stride, int row0, int row_limit, int tid) {
-    const int w = tid >> 6, lane = tid & 63;
-    const int kp = 16 * (w >> 1) + (lane & 15), chunk = 4 * (w & 1) + (lane >> 4);
-    bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int r0 = row0 + 2 * kp;
-    const bf16x8_t a = r0 < row_limit ? *(const bf16x8_t*)(src + (long)r0 * row_stride + chunk * 8) : z;
-    const bf16x8_t b = (r0 + 1) < row_limit ? *(const bf16x8_t*)(src + (long)(r0 + 1) * row_stride + chunk * 8) : z;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const unsigned packed = (unsigned)(unsigned short)a[e] | ((unsigned)(unsigned short)b[e] << 16);
-        *(unsigned*)(dst + (chunk * 8 + e) * BW_T_STRIDE + 2 * kp) = packed;
-    }
-}
-// One global fetch feeds both images of a 64 x 64 tile: a thread owns rows 2 kp, 2 kp + 1 of one 16-byte chunk, which is exactly what the
-// transposed image packs per 32-bit write; the same registers go to the row-major image as two b128 writes (both rows share the swizzle
-// (row >> 1) & 7 = kp & 7).  The loads of tile i + 1 are issued before the MFMA work on tile i (the synchronous form exposed the load
-// latency of every tile to the two resident workgroups).
-struct BwPair { bf16x8_t a, b; };
-__device__ __forceinline__ BwPair bw_load_pair(const bf16_t* src, long row_stride, int row0, int row_limit, int tid) {
-    const int w = tid >> 6, lane = tid & 63;
-    const int kp = 16 * (w >> 1) + (lane & 15), chunk = 4 * (w & 1) + (lane >> 4);
+// staging map: thread -> rows (tid >> 3) and (tid >> 3) + 32 of a 64 x 64 bf16 tile, 16-byte chunk tid & 7 (the forward kernel's map)
+struct BwRows { bf16x8_t a, b; };
+__device__ __forceinline__ BwRows bw_load_rows(const bf16_t* src, long row_stride, int row0, int row_limit, int tid) {
+    const int row = tid >> 3, chunk = tid & 7;
     const bf16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-    const int r0 = row0 + 2 * kp;
-    BwPair v;
-    v.a = r0 < row_limit ? *(const bf16x8_t*)(src + (long)r0 * row_stride + chunk * 8) : z;
-    v.b = (r0 + 1) < row_limit ? *(const bf16x8_t*)(src + (long)(r0 + 1) * row_stride + chunk * 8) : z;
+    BwRows v;
+    v.a = (row0 + row) < row_limit ? *(const bf16x8_t*)(src + (long)(row0 + row) * row_stride + chunk * 8) : z;
+    v.b = (row0 + row + 32) < row_limit ? *(const bf16x8_t*)(src + (long)(row0 + row + 32) * row_stride + chunk * 8) : z;
     return v;
 }
-__device__ __forceinline__ void bw_store_both(char* rm, bf16_t* tr, const BwPair& v, int tid) {
-    const int w = tid >> 6, lane = tid & 63;
-    const int kp = 16 * (w >> 1) + (lane & 15), chunk = 4 * (w & 1) + (lane >> 4);
-    char* d = rm + (2 * kp) * 128 + ((chunk ^ (kp & 7)) << 4);
+// image for fragment reads along a row (ds_read_b128): chunk index XOR (row >> 1) & 7 - rows r and r + 32 share the swizzle
+__device__ __forceinline__ void bw_store_rm(char* dst, const BwRows& v, int tid) {
+    const int row = tid >> 3, chunk = tid & 7;
+    char* d = dst + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
     *(bf16x8_t*)d = v.a;
-    *(bf16x8_t*)(d + 128) = v.b;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const unsigned packed = (unsigned)(unsigned short)v.a[e] | ((unsigned)(unsigned short)v.b[e] << 16);
-        *(unsigned*)(tr + (chunk * 8 + e) * BW_T_STRIDE + 2 * kp) = packed;
-    }
+    *(bf16x8_t*)(d + 32 * 128) = v.b;
 }
-__device__ __forceinline__ bf16x8_t bw_read_tfrag(const bf16_t* T, int row, int col0) {     // 4 + 4 elements at col0 and col0 + 8
-    const bf16_t* p = T + row * BW_T_STRIDE + col0;
-    const bf16x4_t v0 = *(const bf16x4_t*)p;
-    const bf16x4_t v1 = *(const bf16x4_t*)(p + 8);
+// image for transpose reads (ds_read_b64_tr_b16): 32-byte segment index XOR row & 3
+__device__ __forceinline__ void bw_store_tr(char* dst, const BwRows& v, int tid) {
+    const int row = tid >> 3, chunk = tid & 7;
+    char* d = dst + row * 128 + ((((chunk >> 1) ^ (row & 3)) << 5) | ((chunk & 1) << 4));
+    *(bf16x8_t*)d = v.a;
+    *(bf16x8_t*)(d + 32 * 128) = v.b;
+}
+// lane address of the transposed fragments of column block db (columns 32 db .. 32 db + 31 become the fragment's rows): see the V tile of
+// attn_mfma_bf16_kernel - lane l of a 16-lane group points at tile row (l & 15) >> 2 of a [4 rows][16 columns] block, the upper half-wave 4 rows further
+__device__ __forceinline__ const char* bw_tr_lane(const char* img, int lane, int db) {
+    const int hi = lane >> 5, jrow = (lane & 15) >> 2, g = (lane >> 4) & 1;
+    return img + (4 * hi + jrow) * 128 + (((2 * db + g) ^ jrow) << 5) + (lane & 3) * 8;
+}
+// A-operand fragment T^T[32 db + (lane & 31)][row0 + {4 hi .. 4 hi + 3, 8 + 4 hi .. 8 + 4 hi + 3}]
+__device__ __forceinline__ bf16x8_t bw_tr_frag(const char* lane_base, int row0) {
+    const s16x4_t v0 = lds_tr16_b64(lane_base + row0 * 128);
+    const s16x4_t v1 = lds_tr16_b64(lane_base + (row0 + 8) * 128);
     const bf16x8_t f = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     return f;
 }
 
 template <bool HOLES>
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_mfma_kernel(const AttnBwdParams p) {
     constexpr int D = 64, KT = 64;
-    __shared__ __attribute__((aligned(16))) char Ks[KT * 128];
-    __shared__ __attribute__((aligned(16))) char Vs[KT * 128];
-    __shared__ __attribute__((aligned(16))) bf16_t Kt[D * BW_T_STRIDE];
+    __shared__ __attribute__((aligned(1024))) char Ks[KT * 128];      // K, row swizzle (S^T = K Q^T)
+    __shared__ __attribute__((aligned(1024))) char Vs[KT * 128];      // V, row swizzle (dP^T = V dO^T)
+    __shared__ __attribute__((aligned(1024))) char K2[KT * 128];      // K again, transpose-read swizzle (dQ^T += K^T dS^T)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lrow = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
     const int h = blockIdx.y;
@@ -1262,27 +1245,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdPara
     const float c2 = p.scale * 1.4426950408889634f;
     const float lse2 = p.lse[(r * p.H + h) * (long)p.l + qrow] * 1.4426950408889634f;
     const float Dq = p.dsum[(r * p.H + h) * (long)p.l + qrow];
+    const char* k2_lane[2] = {bw_tr_lane(K2, lane, 0), bw_tr_lane(K2, lane, 1)};
     f32x16_t dq[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
 
-    BwPair kv_k = bw_load_pair(kbase, C3, 0, kv_end, tid), kv_v = bw_load_pair(vbase, C3, 0, kv_end, tid);
-    for (int kt0 = 0; kt0 < kv_end; kt0 += KT) {
-        bw_store_both(Ks, Kt, kv_k, tid);
-        {
-            const int w_ = tid >> 6, lane_ = tid & 63;
-            const int kp = 16 * (w_ >> 1) + (lane_ & 15), chunk = 4 * (w_ & 1) + (lane_ >> 4);
-            char* d = Vs + (2 * kp) * 128 + ((chunk ^ (kp & 7)) << 4);
-            *(bf16x8_t*)d = kv_v.a;
-            *(bf16x8_t*)(d + 128) = kv_v.b;
-        }
-        __syncthreads();
-        if (kt0 + KT < kv_end) {            // next K / V tile travels while this one is computed
-            kv_k = bw_load_pair(kbase, C3, kt0 + KT, kv_end, tid);
-            kv_v = bw_load_pair(vbase, C3, kt0 + KT, kv_end, tid);
-        }
+    // one key tile's arithmetic; MASK compile-time (tiles below wave_min_kv are seen completely by all 32 queries of the wave)
+    auto compute = [&](int kt0, auto MASK) {
         f32x16_t s[2], dp[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -1297,7 +1268,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdPara
                 dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, of[ks], dp[kb], 0, 0, 0);
             }
         }
-        const bool need_mask = kt0 + KT > wave_min_kv;
         bf16x8_t dsf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -1308,7 +1278,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdPara
                 for (int j = 0; j < 8; ++j) {
                     const int i = 8 * t + j;
                     float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], c2, -lse2));
-                    if (need_mask) {
+                    if constexpr (decltype(MASK)::value) {
                         const int key = kt0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hi;
                         if (!vis_key_t<HOLES>(vis, key)) pr = 0.f;
                     }
@@ -1322,7 +1292,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdPara
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
-                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw_read_tfrag(Kt, 32 * db + lrow, 32 * kb + 16 * t + 4 * hi), dsf[kb][t], dq[db], 0, 0, 0);
+                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw_tr_frag(k2_lane[db], 32 * kb + 16 * t), dsf[kb][t], dq[db], 0, 0, 0);
+    };
+    typedef std::integral_constant<bool, true> Yes;
+    typedef std::integral_constant<bool, false> No;
+    BwRows kv_k = bw_load_rows(kbase, C3, 0, kv_end, tid), kv_v = bw_load_rows(vbase, C3, 0, kv_end, tid);
+    for (int kt0 = 0; kt0 < kv_end; kt0 += KT) {
+        bw_store_rm(Ks, kv_k, tid);
+        bw_store_tr(K2, kv_k, tid);
+        bw_store_rm(Vs, kv_v, tid);
+        __syncthreads();
+        if (kt0 + KT < kv_end) {            // next K / V tile travels while this one is computed
+            kv_k = bw_load_rows(kbase, C3, kt0 + KT, kv_end, tid);
+            kv_v = bw_load_rows(vbase, C3, kt0 + KT, kv_end, tid);
+        }
+        if (kt0 + KT > wave_min_kv) compute(kt0, Yes{}); else compute(kt0, No{});      // wave-uniform; no barrier inside
         __syncthreads();
     }
     if (qi < p.l) {
@@ -1340,12 +1324,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const AttnBwdPara
 }
 
 template <bool HOLES>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_mfma_kernel(const AttnBwdParams p) {
     constexpr int D = 64, QT = 64;
-    __shared__ __attribute__((aligned(16))) char Qs[QT * 128];
-    __shared__ __attribute__((aligned(16))) char Os[QT * 128];
-    __shared__ __attribute__((aligned(16))) bf16_t Qt[D * BW_T_STRIDE];
-    __shared__ __attribute__((aligned(16))) bf16_t Ot[D * BW_T_STRIDE];
+    __shared__ __attribute__((aligned(1024))) char Qs[QT * 128];      // Q / dO, row swizzle (S = Q K^T, dP = dO V^T)
+    __shared__ __attribute__((aligned(1024))) char Os[QT * 128];
+    __shared__ __attribute__((aligned(1024))) char Q2[QT * 128];      // Q / dO again, transpose-read swizzle (dK^T += Q^T dS, dV^T += dO^T P)
+    __shared__ __attribute__((aligned(1024))) char O2[QT * 128];
     __shared__ __attribute__((aligned(16))) float Ls[QT];
     __shared__ __attribute__((aligned(16))) float Dsum[QT];
     __shared__ __attribute__((aligned(16))) int Kv[QT];
@@ -1362,6 +1346,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdPar
     const int nkeys = p.q_off + p.l;
     const int kj = blockIdx.x * 128 + w * 32 + lrow;                 // key position owned by this lane
     const int krow = min(kj, nkeys - 1);
+    const int key_hi = min((int)(blockIdx.x + 1) * 128, nkeys);      // one past the workgroup's last key
     bf16x8_t kf[4], vf[4];
     {
         const bf16_t* kp = base + (long)krow * C3 + p.H * D + h * D;
@@ -1370,43 +1355,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdPar
         for (int ks = 0; ks < 4; ++ks) { kf[ks] = *(const bf16x8_t*)(kp + (2 * ks + hi) * 8); vf[ks] = *(const bf16x8_t*)(vp + (2 * ks + hi) * 8); }
     }
     const float c2 = p.scale * 1.4426950408889634f;
+    const char* q2_lane[2] = {bw_tr_lane(Q2, lane, 0), bw_tr_lane(Q2, lane, 1)};
+    const char* o2_lane[2] = {bw_tr_lane(O2, lane, 0), bw_tr_lane(O2, lane, 1)};
     f32x16_t dk[2], dv[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dk[db][i] = 0.f; dv[db][i] = 0.f; }
 
-    const int q_begin = first_query_of(p, blockIdx.x * 128);            // first query that sees the block's first key
-    const int qt_first = (q_begin / QT) * QT;
-    BwPair qv = bw_load_pair(qbase, C3, qt_first, p.l, tid), ov = bw_load_pair(obase, (long)(p.H * D), qt_first, p.l, tid);
-    float ls_v = 0.f, ds_v = 0.f;
-    auto load_rowstats = [&](int qt0) {
-        if (tid < QT) {
-            const int qi = qt0 + tid;
-            const bool ok = qi < p.l;
-            ls_v = ok ? p.lse[(r * p.H + h) * (long)p.l + qi] * 1.4426950408889634f : 0.f;
-            ds_v = ok ? p.dsum[(r * p.H + h) * (long)p.l + qi] : 0.f;
-        }
-    };
-    load_rowstats(qt_first);
-    for (int qt0 = qt_first; qt0 < p.l; qt0 += QT) {
-        bw_store_both(Qs, Qt, qv, tid);
-        bw_store_both(Os, Ot, ov, tid);
-        if (tid < QT) {
-            const int qi = qt0 + tid;
-            const bool ok = qi < p.l;
-            Ls[tid] = ls_v;
-            Dsum[tid] = ds_v;
-            const Vis vq = vis_of(p, p.q_off + (ok ? qi : 0));
-            Kv[tid] = ok ? vq.kvlen : 0;
-            if constexpr (HOLES) { Hlo[tid] = vq.hlo; Hhi[tid] = vq.hhi; }
-        }
-        __syncthreads();
-        if (qt0 + QT < p.l) {               // next tile's operands travel while this tile is computed
-            qv = bw_load_pair(qbase, C3, qt0 + QT, p.l, tid);
-            ov = bw_load_pair(obase, (long)(p.H * D), qt0 + QT, p.l, tid);
-            load_rowstats(qt0 + QT);
-        }
+    // one query tile's arithmetic.  MASK compile-time: a tile whose 64 queries all see every key of this workgroup needs no visibility test
+    auto compute = [&](auto MASK) {
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16_t s, dp;
@@ -1430,20 +1388,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdPar
                     const int qloc = 32 * qb + 8 * g + 4 * hi;
                     const f32x4_t l4 = *(const f32x4_t*)&Ls[qloc];
                     const f32x4_t d4 = *(const f32x4_t*)&Dsum[qloc];
-                    const int4 k4 = *(const int4*)&Kv[qloc];
-                    const int kvl[4] = {k4.x, k4.y, k4.z, k4.w};
-                    int hlo4[4] = {0, 0, 0, 0}, hhi4[4] = {0, 0, 0, 0};
-                    if constexpr (HOLES) {
-                        const int4 l4i = *(const int4*)&Hlo[qloc];
-                        const int4 h4i = *(const int4*)&Hhi[qloc];
-                        hlo4[0] = l4i.x; hlo4[1] = l4i.y; hlo4[2] = l4i.z; hlo4[3] = l4i.w;
-                        hhi4[0] = h4i.x; hhi4[1] = h4i.y; hhi4[2] = h4i.z; hhi4[3] = h4i.w;
+                    int kvl[4] = {0, 0, 0, 0}, hlo4[4] = {0, 0, 0, 0}, hhi4[4] = {0, 0, 0, 0};
+                    if constexpr (decltype(MASK)::value) {
+                        const int4 k4 = *(const int4*)&Kv[qloc];
+                        kvl[0] = k4.x; kvl[1] = k4.y; kvl[2] = k4.z; kvl[3] = k4.w;
+                        if constexpr (HOLES) {
+                            const int4 l4i = *(const int4*)&Hlo[qloc];
+                            const int4 h4i = *(const int4*)&Hhi[qloc];
+                            hlo4[0] = l4i.x; hlo4[1] = l4i.y; hlo4[2] = l4i.z; hlo4[3] = l4i.w;
+                            hhi4[0] = h4i.x; hhi4[1] = h4i.y; hhi4[2] = h4i.z; hhi4[3] = h4i.w;
+                        }
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int i = 4 * g + e;
                         float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c2, -l4[e]));
-                        if (krow >= kvl[e] || (HOLES && krow >= hlo4[e] && krow < hhi4[e])) pr = 0.f;
+                        if constexpr (decltype(MASK)::value) {
+                            if (krow >= kvl[e] || (HOLES && krow >= hlo4[e] && krow < hhi4[e])) pr = 0.f;
+                        }
                         pv[4 * g2 + e] = pr;
                         dsv[4 * g2 + e] = pr * (dp[i] - d4[e]);
                     }
@@ -1455,13 +1417,63 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const AttnBwdPar
             for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const int col0 = 32 * qb + 16 * t + 4 * hi;
-                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw_read_tfrag(Ot, 32 * db + lrow, col0), pf[t], dv[db], 0, 0, 0);
-                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw_read_tfrag(Qt, 32 * db + lrow, col0), df[t], dk[db], 0, 0, 0);
+                    const int row0 = 32 * qb + 16 * t;
+                    dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw_tr_frag(o2_lane[db], row0), pf[t], dv[db], 0, 0, 0);
+                    dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw_tr_frag(q2_lane[db], row0), df[t], dk[db], 0, 0, 0);
                 }
         }
+    };
+    typedef std::integral_constant<bool, true> Yes;
+    typedef std::integral_constant<bool, false> No;
+
+    const int q_begin = first_query_of(p, blockIdx.x * 128);            // first query that sees the block's first key
+    const int qt_first = (q_begin / QT) * QT;
+    BwRows qv = bw_load_rows(qbase, C3, qt_first, p.l, tid), ov = bw_load_rows(obase, (long)(p.H * D), qt_first, p.l, tid);
+    float ls_v = 0.f, ds_v = 0.f;
+    auto load_rowstats = [&](int qt0) {
+        if (tid < QT) {
+            const int qi = qt0 + tid;
+            const bool ok = qi < p.l;
+            ls_v = ok ? p.lse[(r * p.H + h) * (long)p.l + qi] * 1.4426950408889634f : 0.f;
+            ds_v = ok ? p.dsum[(r * p.H + h) * (long)p.l + qi] : 0.f;
+        }
+    };
+    load_rowstats(qt_first);
+    // workgroup-uniform: all 64 queries of the tile exist and each sees every key of this workgroup
+    auto is_full = [&](int qt0) { return qt0 + QT <= p.l && range_full_prefix(p, p.q_off + qt0, p.q_off + qt0 + QT - 1) >= key_hi; };
+    auto tile = [&](int qt0, auto MASK) {
+        bw_store_rm(Qs, qv, tid);
+        bw_store_tr(Q2, qv, tid);
+        bw_store_rm(Os, ov, tid);
+        bw_store_tr(O2, ov, tid);
+        if (tid < QT) {
+            const int qi = qt0 + tid;
+            const bool ok = qi < p.l;
+            Ls[tid] = ls_v;
+            Dsum[tid] = ds_v;
+            if constexpr (decltype(MASK)::value) {
+                const Vis vq = vis_of(p, p.q_off + (ok ? qi : 0));
+                Kv[tid] = ok ? vq.kvlen : 0;
+                if constexpr (HOLES) { Hlo[tid] = vq.hlo; Hhi[tid] = vq.hhi; }
+            }
+        }
         __syncthreads();
+        if (qt0 + QT < p.l) {               // next tile's operands travel while this tile is computed
+            qv = bw_load_rows(qbase, C3, qt0 + QT, p.l, tid);
+            ov = bw_load_rows(obase, (long)(p.H * D), qt0 + QT, p.l, tid);
+            load_rowstats(qt0 + QT);
+        }
+        compute(MASK);
+        __syncthreads();
+    };
+    // three loops, one instantiation of the tile body each (both bodies inside ONE loop made the compiler spill 46-95 registers): the masked level-boundary
+    // tiles, the run of completely visible tiles behind them (the visible prefix only grows with the query position when no level has a hole), the tail
+    int qt0 = qt_first;
+    if constexpr (!HOLES) {
+        for (; qt0 < p.l && !is_full(qt0); qt0 += QT) tile(qt0, Yes{});
+        for (; qt0 < p.l && is_full(qt0); qt0 += QT) tile(qt0, No{});
     }
+    for (; qt0 < p.l; qt0 += QT) tile(qt0, Yes{});
     if (kj < nkeys) {
         bf16_t* kp = (bf16_t*)p.dqkv + (r * p.Lmax + kj) * (long)C3 + p.H * D + h * D;
         bf16_t* vp = kp + p.H * D;

@@ -733,6 +733,59 @@ def case_generate_d24():
     save('gen_d24_cmask', c_ids=torch.cat(c_ids, dim=1).to(torch.int16), **r)
 
 
+def case_d24_bf16ref():
+    """the bf16 yardstick for the model the metric is quoted on.  (a) gen_d24_bf16ref: the reference d24 + full VQVAE
+    walked under torch.autocast('cpu', bfloat16) ALONG the greedy ids of its own fp32 run (gen_d24_b2.npz, committed; control_var.py:356-565 with the
+    sampler's result replaced by the recorded ids): per-stage CFG-combined logits, sampled exactly like gen_d24_b2's `logit_samples`
+    ([rows 0..1, every third position, vocabulary ::128]), the full-tensor max / RMS distance to the fp32 logits per scale, and the autocast run's own
+    argmax ids + margins.  (b) forward_d24_bf16ref: teacher-forced logits (control_var.py:568-651) of the same model in fp32, under autocast and from the
+    oracle's bf16 emulation on one input, as forward_d12_bf16ref."""
+    from oracle import var_ref
+    from oracle.vqvae_ref import Prec
+    g = np.load(os.path.join(HERE, 'gen_d24_b2.npz'))
+    vae = make_vae(160)
+    cfg = VarConfig(depth=24)
+    m = make_cvar(vae, cfg)
+    ids_all = torch.from_numpy(g['ids'].astype(np.int64))
+    ids, o = [], 0
+    for p_ in PN:
+        ids.append(ids_all[:, o:o + 2 * p_ * p_].clone()); o += 2 * p_ * p_
+    kw = dict(B=2, label_B=torch.tensor([3, 7]), g_seed=0, cfg=4.0, top_k=1, top_p=0.0, cond_type=torch.tensor([0, 1]))
+    t0 = time.time()
+    with ReplayIdx(ref_cv, ids) as r32, torch.no_grad():
+        m.autoregressive_infer_cfg(**kw)
+    print(f'  reference d24 fp32 along its own trace {time.time() - t0:.1f}s')
+    t0 = time.time()
+    with ReplayIdx(ref_cv, ids) as rac, torch.no_grad(), torch.autocast('cpu', dtype=torch.bfloat16):
+        m.autoregressive_infer_cfg(**kw)
+    print(f'  reference d24 autocast(bf16) along the fp32 trace {time.time() - t0:.1f}s')
+    l32, lac = r32.logit_samples, rac.logit_samples
+    samp = lambda L: torch.cat([t_[:2, :, ::128] for t_ in L], dim=1)[:, ::3].contiguous()
+    assert float((samp(l32) - torch.from_numpy(g['logit_samples'])).abs().max()) < 1e-4          # the replay reproduces the committed fp32 recording
+    d = [_dist(a, b) for a, b in zip(lac, l32)]
+    amax = torch.stack([t_.abs().amax() for t_ in l32])
+    arg_ac = torch.cat([t_.argmax(-1) for t_ in lac], dim=1)
+    print('  autocast vs fp32 per scale (max / RMS, relative to max|logit|):', ' '.join(f'{d[i][0] / float(amax[i]):.2e}/{d[i][1] / float(amax[i]):.2e}' for i in range(len(PN))))
+    print(f'  overall: max {max(x[0] for x in d) / float(amax.max()):.3e}; autocast argmax != fp32 ids: {int((arg_ac != ids_all).sum())} of {ids_all.numel()}')
+    save('gen_d24_bf16ref', ref_autocast=samp(lac), ref_fp32=samp(l32), absmax_per_scale=amax, d_autocast_fp32=d, absmax=amax.max(),
+         d_autocast_fp32_sampled=_dist(samp(lac), samp(l32)), argmax_autocast=arg_ac.to(torch.int16), margin_autocast=torch.cat(rac.margins, dim=1),
+         flips_autocast_vs_fp32=np.array(int((arg_ac != ids_all).sum())))
+    # (b) teacher-forced forward, B = 1
+    gen = torch.Generator().manual_seed(41)
+    x = torch.randn(1, cfg.pyramid.L - cfg.pyramid.first_l, 32, generator=gen)
+    labels, types = torch.tensor([77]), torch.tensor([2])
+    t0 = time.time()
+    with torch.no_grad():
+        f32 = m(labels, x, types, True).float()
+        with torch.autocast('cpu', dtype=torch.bfloat16):
+            fac = m(labels, x, types, True).float()
+        femu = var_ref.forward_logits(synth_var_state(cfg), cfg, labels, x, types, prec=Prec(True))
+    print(f'  d24 forward fp32 / autocast / emulation {time.time() - t0:.1f}s; max|logit| {float(f32.abs().max()):.3f}; autocast-fp32 {_dist(fac, f32)}, emu-fp32 {_dist(femu, f32)}, emu-autocast {_dist(femu, fac)}')
+    S = (slice(None), slice(None, None, 9), slice(None, None, 31))
+    save('forward_d24_bf16ref', labels=labels, types=types, absmax=f32.abs().amax(), ref_fp32=f32[S].contiguous(), ref_autocast=fac[S].contiguous(),
+         emu=femu[S].contiguous(), d_autocast_fp32=_dist(fac, f32), d_emu_fp32=_dist(femu, f32), d_emu_autocast=_dist(femu, fac))
+
+
 def case_train_step_d24():
     """BASELINE config 3 anchor: one reference training step at d24 width (C=1536, 24 blocks), B=2, tiny VQVAE for the tokens."""
     case_train_step(VarConfig(depth=24), 'd24', 0)
@@ -878,6 +931,7 @@ CASES = {
     'gen_d30': case_generate_d30,
     'gen_d24': case_generate_d24,
     'train_d24': case_train_step_d24,
+    'd24_bf16ref': case_d24_bf16ref,
 }
 
 if __name__ == '__main__':

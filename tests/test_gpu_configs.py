@@ -258,32 +258,48 @@ def test_d24_conditional_infer_fp32_matches_reference(gpu_device):
     _gen_check(m, g, 2, torch.tensor([5, 6]), (4.0, 4.0, 4.0), torch.tensor([2, 3]), 'd24 conditional_infer_cfg (headline model)', four=True, c_mask=c_ids)
 
 
-# measured on MI355X (round 4) for the d24 model along the reference's fp32 greedy trace: max / RMS of |HIP bf16 - reference fp32| over the sampled
-# CFG-combined logits, relative to max|logit|
-D24_BF16_MAX_MEASURED, D24_BF16_RMS_MEASURED = 7.3e-3, 1.6e-3        # measured: 7.23e-3 / 1.54e-3 (max|logit| 66.3); 38 of 2 720 greedy ids move, margins <= 0.32
-
-
 def test_d24_bf16_logits_along_the_reference_fp32_trace(gpu_device):
-    """north_star's "within 1e-3 on bf16 logits" for the model the metric is quoted on: the HIP bf16 d24 model is forced along the greedy ids the
-    REFERENCE produced in fp32 (gen_d24_b2.npz) and its CFG-combined logits are compared with the reference's recorded ones ([rows 0..1, every third
-    position, vocabulary ::128]).  Recorded: max and RMS distance relative to max|logit| (no bf16 pipeline reaches 1e-3 in the max norm - DESIGN.md
-    section 2); asserted: within 1.5 x the values measured in round 4, and greedy ids equal to the reference's wherever its top-1 margin exceeds twice
-    the measured max distance."""
-    g = golden('gen_d24_b2')
+    """north_star's "within 1e-3 on bf16 logits" for the model the metric is quoted on, measured against the REFERENCE'S OWN bf16:
+    gen_d24_bf16ref.npz holds the reference d24 walked under torch.autocast('cpu', bfloat16) along the greedy ids of its fp32 run (gen_d24_b2.npz) - its
+    CFG-combined logits sit 1.12e-2 (max) / 2.1e-3 (RMS) of max|logit| from its fp32 ones and 70 of its 2 720 argmax ids move.  The HIP bf16 model is forced
+    along the same ids; asserted: it is NO FARTHER from the reference's fp32 logits than the reference's autocast is (max and RMS over the same sampled
+    logits, x 1.0), it flips no more greedy ids than the autocast does, and every flip happens at a reference margin below twice the autocast's own max
+    distance (a bound that comes from the recording, not from this implementation)."""
+    g, gb = golden('gen_d24_b2'), golden('gen_d24_bf16ref')
     vae, m = build(24, BF16, gpu_device)
     ids = split(t(g['ids']).long())
     m.autoregressive_infer_cfg(2, torch.tensor([3, 7]), g_seed=0, cfg=4.0, top_k=1, cond_type=torch.tensor([0, 1]), _force_idx=ids, _trace=True)
     tr = m.last_trace
     hip = torch.cat([x.float() for x in tr['logits']], dim=1)[:2, ::3, ::128].cpu()
-    ref = t(g['logit_samples'])
-    assert hip.shape == ref.shape, (hip.shape, ref.shape)
+    ref, rac = t(g['logit_samples']), t(gb['ref_autocast'])
+    assert hip.shape == ref.shape == rac.shape, (hip.shape, ref.shape, rac.shape)
+    assert float((t(gb['ref_fp32']) - ref).abs().max()) < 1e-4            # the autocast recording belongs to this fp32 trace
     amax = float(ref.abs().max())
     dmax, drms = [v / amax for v in _d(hip, ref)]
-    print(f'[bf16] d24 along the reference fp32 trace: max {dmax:.2e} / RMS {drms:.2e} of max|logit| = {amax:.2f} (sampled logits)')
-    record('gen_d24 bf16 vs reference fp32 (forced along the reference trace)', kind='bf16_logits', absmax=amax, hip_vs_ref_fp32=[dmax, drms])
-    assert dmax <= 1.5 * D24_BF16_MAX_MEASURED and drms <= 1.5 * D24_BF16_RMS_MEASURED
+    amax_ac, arms_ac = [v / amax for v in _d(rac, ref)]
+    print(f'[bf16] d24 along the reference fp32 trace: HIP max {dmax:.2e} / RMS {drms:.2e}; reference autocast {amax_ac:.2e} / {arms_ac:.2e} of max|logit| = {amax:.2f} (sampled logits)')
+    record('gen_d24 bf16 vs reference fp32 (forced along the reference trace)', kind='bf16_logits', absmax=amax, hip_vs_ref_fp32=[dmax, drms],
+           ref_autocast_vs_ref_fp32=[amax_ac, arms_ac], ref_autocast_flips=int(gb['flips_autocast_vs_fp32']))
+    assert dmax <= amax_ac and drms <= arms_ac
     own = torch.cat(tr['idx'], dim=1).cpu()
-    check_ids(own, g['ids'], g['margin'], 2 * D24_BF16_MAX_MEASURED * amax, 'gen_d24 bf16 greedy ids vs the reference fp32 trace', strict=False)
+    n, _ = check_ids(own, g['ids'], g['margin'], 2 * amax_ac * amax, 'gen_d24 bf16 greedy ids vs the reference fp32 trace', strict=False)
+    assert n <= int(gb['flips_autocast_vs_fp32']), (n, int(gb['flips_autocast_vs_fp32']))
+
+
+def test_forward_d24_bf16_among_the_references_bf16(gpu_device):
+    """the d24 counterpart of test_forward_d12_bf16_among_the_references_bf16: forward_d24_bf16ref.npz holds the teacher-forced logits of the reference
+    d24 (control_var.py:568-651) in fp32, under CPU bf16 autocast and from the oracle's bf16 emulation on one input (B = 1).  The HIP bf16 path must be no
+    farther from the reference's fp32 logits than the reference's own autocast (max and RMS), and within 1e-3 RMS (north_star) of the emulation."""
+    g = golden('forward_d24_bf16ref')
+    vae, m = build(24, BF16, gpu_device)
+    gen = torch.Generator().manual_seed(41)
+    x = torch.randn(1, 1358, 32, generator=gen).to(gpu_device)
+    with torch.no_grad():
+        hip = m(t(g['labels']), x, t(g['types']), True).float().cpu()[:, ::9, ::31]
+    r = _fourway('forward_d24 bf16', hip, t(g['ref_fp32']), t(g['ref_autocast']), t(g['emu']), float(g['absmax']))
+    assert r['hip_vs_ref_fp32'][0] <= r['ref_autocast_vs_ref_fp32'][0]
+    assert r['hip_vs_ref_fp32'][1] <= r['ref_autocast_vs_ref_fp32'][1]
+    assert r['hip_vs_emulation'][1] <= 1e-3
 
 
 def test_d30_full_width_bf16_properties(gpu_device):
