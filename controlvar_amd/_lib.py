@@ -11,7 +11,7 @@ import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CVAR_LIB') or os.path.join(HERE, 'libcvar_hip.so')      # CVAR_LIB: A/B runs against another build
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 CVAR_F32, CVAR_BF16 = 0, 1
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_GRAD = 0, 1, 2
@@ -39,6 +39,7 @@ class GemmDesc(C.Structure):
         ('ws', c_p), ('ws_bytes', c_l), ('tile_cfg', c_i), ('stagger', c_i), ('group_m', c_i),
         ('C_split', c_p), ('split_n', c_i), ('ld_split', c_l), ('split_alpha', c_f),
         ('ln_out', c_p), ('ln_out_dtype', c_i), ('ln_scale', c_p), ('ln_shift', c_p), ('ld_ln', c_l), ('ln_rows', c_i), ('ln_eps', c_f),
+        ('gn_part', c_p),
     ]
 
 
@@ -70,6 +71,8 @@ SIGNATURES = {
     'cvar_first_tokens': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     'cvar_groupnorm_ws_bytes': (c_l, [c_i, c_i, c_i]),
     'cvar_groupnorm_silu': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p]),
+    'cvar_groupnorm_silu_partials': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_i, c_i, c_p, c_p]),
+    'cvar_conv3x3_gn_partials': (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.POINTER(c_i), C.POINTER(c_i)]),
     'cvar_softmax_rows': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     'cvar_gemm_tn': (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_p, c_p]),
     'cvar_embed_rows': (c_i, [c_p, c_p, c_i, c_p, c_l, c_i, c_p]),

@@ -23,6 +23,7 @@ struct ConvHaloParams {
     const bf16_t* X; const bf16_t* Wt; const float* bias; const bf16_t* res; void* out;
     int B, H, W, Cin, Cout, tiles_x, tiles_y, nchunk;
     int up, Hin, Win;          // up = 1: the conv reads its input through a nearest x2 upsample (Hin = H / 2), vae_modules.py:28
+    float* gn_part;            // optional (wide form): GroupNorm partial sums of the OUTPUT, [B][tiles][Cout][3] = (sum (y - piv), sum (y - piv)^2, piv) per tile and channel
 };
 
 // Tile width TW = 16 (4 waves, two workgroups per CU).  Halo row stride TW + 4 pixels (TW + 2 used): a multiple of 4, so that the bank slot depends on the column only.
@@ -188,6 +189,7 @@ __global__ __launch_bounds__(TW * 16, 2) void conv3x3_halo_bf16_kernel(const Con
     // All residual loads of a row block are issued before its first store: vmcnt retires in order and counts stores, so a load queued
     // behind stores would wait for their latency as well (+13 % on the residual convs).  The bias comes straight from global memory (L2
     // hits): a second static LDS array for it cost 6 % on every shape.
+    float gs[8], gq[8], gpiv[8];                 // GroupNorm partials of this lane's (column chunk, pixel residue): wide form with p.gn_part only
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int yy = py0 + RPI * i, xx = px;
@@ -214,7 +216,9 @@ __global__ __launch_bounds__(TW * 16, 2) void conv3x3_halo_bf16_kernel(const Con
             // pipeline LDS as [pixel][cout] rows of 336 B: residual in by 16-byte row-contiguous loads, summed in the accumulator layout in fp32 exactly as
             // before (acc + bias + residual, one rounding), out by 16-byte row-contiguous stores - 160 full-line requests per wave and tile.
             constexpr int PS = 336;
-            char* stg = smem + wave * ((2 * CH_HALO_BYTES + 3 * CH_W_BYTES) / NW / 64 * 64);
+            constexpr int SLICE = (2 * CH_HALO_BYTES + 3 * CH_W_BYTES) / NW / 64 * 64;      // LDS of one wave; rows take 32 PS = 10 752 B of it
+            static_assert(32 * PS + 512 + 3 * 20 * 64 <= SLICE, "GroupNorm partials need the slack behind the staged rows");
+            char* stg = smem + wave * SLICE;
             const float* bp = p.bias ? p.bias + cout0 + 4 * hi : nullptr;
             // chunk q = 64 k + lane of the row block: pixel q / 20, 16-byte part q % 20; offsets relative to the image (32-bit)
             const long img = (long)b * p.H * p.W * p.Cout;
@@ -255,6 +259,36 @@ __global__ __launch_bounds__(TW * 16, 2) void conv3x3_halo_bf16_kernel(const Con
                 }
 #pragma unroll
             for (int k = 0; k < 10; ++k) { int go, lo; chunk(k, go, lo); *(bf16x8_t*)((bf16_t*)p.out + img + go) = *(const bf16x8_t*)(stg + lo); }
+            // ---- GroupNorm statistics of the tile (round 5; replaces the gn_stats pass of the GroupNorm that reads this conv's output, vae_modules.py:12-13).
+            // The staged rows hold the values as STORED (bf16): lane (cc, pg) = (16-byte column chunk, pixel residue mod 3) walks its pixels and accumulates
+            // sum (y - piv), sum (y - piv)^2 per channel in fp32 around a pivot common to the whole tile (the channel's value at the tile's first staged pixel:
+            // no cancellation when |mean| >> std, as in gn_stats_kernel); the tiles are combined in double by gn_finalize_tiles_kernel.  Fixed order, no atomics.
+            if (p.gn_part) {
+                char* pv = smem + 32 * PS;                                  // 160 bf16 pivots, behind wave 0's rows
+                if (i == 0) {
+                    __builtin_amdgcn_wave_barrier();
+                    if (wave == 0 && lane < 20) *(bf16x8_t*)(pv + lane * 16) = *(const bf16x8_t*)(stg + lane * 16);       // row 0 of wave 0 (in-order LDS: written above)
+                    __syncthreads();
+                    if (lane < 60) {
+                        const bf16x8_t pq8 = *(const bf16x8_t*)(pv + (lane % 20) * 16);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { gpiv[e] = bf16_to_f32((bf16_t)pq8[e]); gs[e] = 0.f; gq[e] = 0.f; }
+                    }
+                }
+                if (lane < 60) {
+                    const int cc = lane % 20, pg = lane / 20;
+#pragma unroll
+                    for (int it = 0; it < 11; ++it) {
+                        const int pp = pg + 3 * it;
+                        if (pp < 32) {
+                            const bf16x8_t y8 = *(const bf16x8_t*)(stg + pp * PS + cc * 16);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { const float f = bf16_to_f32((bf16_t)y8[e]) - gpiv[e]; gs[e] += f; gq[e] = __builtin_fmaf(f, f, gq[e]); }
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();      // the next row block's residual / output rows overwrite the staged rows: reads first
+            }
         } else {
             bf16_t* op = (bf16_t*)p.out + gpix * p.Cout + cout0 + 4 * hi;
             const bf16_t* rp = p.res ? p.res + gpix * p.Cout + cout0 + 4 * hi : nullptr;
@@ -284,16 +318,47 @@ __global__ __launch_bounds__(TW * 16, 2) void conv3x3_halo_bf16_kernel(const Con
                 }
         }
     }
+    if constexpr (CH_NB == 5 && CH_EPI_LDS != 0) {
+        if (p.gn_part) {
+            // per-lane partials -> the wave's slack -> 160 threads sum (wave, pixel residue) in a fixed order and write (S, Q, piv) of their channel
+            constexpr int PS = 336, SLICE = (2 * CH_HALO_BYTES + 3 * CH_W_BYTES) / NW / 64 * 64, RED = 32 * PS + 512;
+            if (lane < 60) {
+                float* rd = (float*)(smem + wave * SLICE + RED) + lane * 16;
+#pragma unroll
+                for (int e = 0; e < 8; e += 4) {
+                    *(f32x4_t*)(rd + e) = f32x4_t{gs[e], gs[e + 1], gs[e + 2], gs[e + 3]};
+                    *(f32x4_t*)(rd + 8 + e) = f32x4_t{gq[e], gq[e + 1], gq[e + 2], gq[e + 3]};
+                }
+            }
+            __syncthreads();
+            if (tid < 160) {
+                const int cc = tid >> 3, e = tid & 7;
+                float S = 0.f, Q = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+#pragma unroll
+                    for (int pg = 0; pg < 3; ++pg) {
+                        const float* rd = (const float*)(smem + w * SLICE + RED) + (pg * 20 + cc) * 16;
+                        S += rd[e]; Q += rd[8 + e];
+                    }
+                const float piv = bf16_to_f32(*(const bf16_t*)(smem + 32 * PS + tid * 2));
+                float* gp = p.gn_part + ((((long)b * p.tiles_y + ty) * p.tiles_x + tx) * p.Cout + cout0 + tid) * 3;
+                gp[0] = S; gp[1] = Q; gp[2] = piv;
+            }
+        }
+    }
 }
 
 // (H, W: the OUTPUT grid) eligibility is checked by the caller (cvar_gemm): bf16 operands, stride 1, Cin % 32 == 0, H % 16 == 0, W % 16 == 0 and
 // either Cout % 160 == 0 with a bf16 output (optional bf16 residual) or Cout <= 32 without residual (bf16 or fp32 output: conv_out)
 int cvar_conv3x3_halo_bf16(const void* X, const void* Wt, const float* bias, const void* residual, void* out, int out_f32, int B, int H, int W, int Cin,
-                           int Cout, int up, hipStream_t st) {
+                           int Cout, int up, float* gn_part, hipStream_t st) {
     ConvHaloParams p;
     p.X = (const bf16_t*)X; p.Wt = (const bf16_t*)Wt; p.bias = bias; p.res = (const bf16_t*)residual; p.out = out;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.tiles_x = W / 16; p.tiles_y = H / 16; p.nchunk = Cin / 32;
     p.up = up ? 1 : 0; p.Hin = up ? H / 2 : H; p.Win = up ? W / 2 : W;
+    p.gn_part = gn_part;
+    if (gn_part && !(Cout % 160 == 0 && !out_f32)) return CVAR_EUNSUPPORTED;      // only the wide form emits GroupNorm partials
     const long tiles = (long)B * p.tiles_x * p.tiles_y;
     if (tiles <= 0 || tiles > 0x7fffffffL) return CVAR_EINVAL;
     if (Cout % 160 == 0 && !out_f32) {

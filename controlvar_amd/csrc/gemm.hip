@@ -1126,6 +1126,17 @@ __global__ __launch_bounds__(256) void cvar_splitk_epilogue_kernel(const float* 
 }
 
 
+// Does a stride-1 3x3 bf16 conv of this shape emit GroupNorm partials of its output when cvar_gemm_desc.gn_part is set (the wide LDS-halo kernel, chosen
+// by shape alone; operands must be 16-byte aligned and dense: ldc == N, ldw == 9 Cin, ldr == N)?  Returns 1 and the partial geometry, else 0.
+extern "C" int cvar_conv3x3_gn_partials(int dtype, int stride, int Cin, int Cout, int Hin, int Win, int Hout, int Wout, int* tiles_per_image, int* pixels_per_tile) {
+    const bool ok = dtype == CVAR_BF16 && stride == 1 && Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 160 == 0 && Hout > 0 && Wout > 0 && Hout % 16 == 0 && Wout % 16 == 0 &&
+                    (long)Hin * Win * Cin * 2 < 0x7fffffffL && (long)Hout * Wout * Cout < 0x7fffffffL;
+    if (!ok) return 0;
+    if (tiles_per_image) *tiles_per_image = (Hout / 16) * (Wout / 16);
+    if (pixels_per_tile) *pixels_per_tile = 256;
+    return 1;
+}
+
 extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     if (!d || !d->A || !d->W || !d->C) return CVAR_EINVAL;
     if (d->M <= 0 || d->N <= 0 || d->K <= 0 || d->batch < 1) return CVAR_EINVAL;
@@ -1144,6 +1155,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     } else if (d->lda % kch) {
         return CVAR_EUNSUPPORTED;
     }
+    if (d->gn_part && !d->conv) return CVAR_EINVAL;               // GroupNorm partials are a conv epilogue (ABI 18)
     if (d->gate && d->gate_rows <= 0) return CVAR_EINVAL;
     if (d->act == CVAR_ACT_GELU_GRAD && !d->aux) return CVAR_EINVAL;
     if (d->pre_act && d->act == CVAR_ACT_GELU_GRAD) return CVAR_EINVAL;
@@ -1284,10 +1296,12 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
         // narrow form: Cout <= 32 (conv_out, 160 -> 3), bf16 or fp32 output, no residual - the implicit-GEMM tile spends its time re-fetching the input
         // (decided by the IMAGE size, not by the batch: the two kernels sum K in different orders, and an image's pixels must not depend on the batch it rides in)
         const bool narrow = d->N <= 32 && !d->residual && (d->out_dtype == CVAR_BF16 || d->out_dtype == CVAR_F32) && ((long)d->Hout * d->Wout >= 65536 || d->tile_cfg == 6);
+        if (d->gn_part && !wide) return CVAR_EUNSUPPORTED;       // GroupNorm partials come out of the wide halo kernel only (cvar_conv3x3_gn_partials says which calls)
         if (wide || narrow)
             return cvar_conv3x3_halo_bf16(d->A, d->W, d->bias, d->residual, d->C, d->out_dtype == CVAR_F32, d->M / (d->Hout * d->Wout), d->Hout, d->Wout, d->Cin,
-                                          d->N, d->up, st);
+                                          d->N, d->up, d->gn_part, st);
     }
+    if (d->gn_part) return CVAR_EUNSUPPORTED;
     if (d->dtype == CVAR_BF16) return d->conv ? cvar_gemm_launch_conv_bf16(p, d->batch, st) : ln_after(launch_typed<bf16_t>(p, d->batch, st));
     return ln_after(cvar_gemm_launch_f32(p, d->batch, st));
 }

@@ -446,6 +446,43 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     }
 }
 
+// per (b, group): the conv epilogue's per-tile partials (sum (y - piv_t), sum (y - piv_t)^2, piv_t) combined in double - every tile has its own pivot:
+//   sum y = sum_t (n piv_t + S_t),   sum (y - mean)^2 = sum_t [ Q_t + 2 S_t d_t + n d_t^2 ],  d_t = piv_t - mean   (exact identities, every term small)
+__global__ __launch_bounds__(64) void gn_finalize_tiles_kernel(const float* __restrict__ part, int ntile, int npix, const float* __restrict__ weight,
+                                                              const float* __restrict__ bias, float* __restrict__ coef, int HW, int C, int groups, float eps) {
+    const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+    const int cpg = C / groups;
+    const int items = cpg * ntile;
+    const double n = (double)npix;
+    double s = 0.0;
+    for (int it = lane; it < items; it += 64) {
+        const int k = it / cpg, cc = g * cpg + it % cpg;
+        const float* q = part + (((long)b * ntile + k) * C + cc) * 3;
+        s += n * (double)q[2] + (double)q[0];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const double cnt = (double)HW * cpg;
+    const double mean = s / cnt;
+    double v = 0.0;
+    for (int it = lane; it < items; it += 64) {
+        const int k = it / cpg, cc = g * cpg + it % cpg;
+        const float* q = part + (((long)b * ntile + k) * C + cc) * 3;
+        const double d = (double)q[2] - mean;
+        v += (double)q[1] + 2.0 * d * (double)q[0] + n * d * d;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    double var = v / cnt;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int cc = g * cpg + lane; cc < (g + 1) * cpg; cc += 64) {
+        const float a = rstd * weight[cc];
+        coef[((long)b * C + cc) * 2] = a;
+        coef[((long)b * C + cc) * 2 + 1] = bias[cc] - (float)mean * a;
+    }
+}
+
 static inline int gn_pix_per_block(int HW) { return HW >= 16384 ? 512 : (HW >= 1024 ? 128 : 32); }
 
 extern "C" int64_t cvar_groupnorm_ws_bytes(int B, int HW, int C) {
@@ -466,6 +503,23 @@ static int groupnorm_typed(const T* x, const float* weight, const float* bias, T
     hipLaunchKernelGGL(gn_stats_kernel<T>, dim3(nchunk, B), dim3(256), (size_t)PL * C * 2 * sizeof(float), st, x, partial, HW, C, ppb);
     hipLaunchKernelGGL(gn_finalize_kernel<T>, dim3(groups, B), dim3(64), 0, st, partial, nchunk, x, weight, bias, coef, HW, C, groups, eps);
     hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(nchunk, B), dim3(256), 0, st, x, coef, out, HW, C, ppb, silu);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+extern "C" int cvar_groupnorm_silu_partials(const void* x, int dtype, const float* weight, const float* bias, void* out, int B, int HW, int C, int groups, float eps,
+                                            int silu, const float* gn_part, int tiles_per_image, int pixels_per_tile, void* ws, void* stream) {
+    if (!x || !weight || !bias || !out || !ws || !gn_part || B <= 0 || HW <= 0 || C <= 0 || groups <= 0 || tiles_per_image <= 0 || pixels_per_tile <= 0) return CVAR_EINVAL;
+    if ((long)tiles_per_image * pixels_per_tile != HW) return CVAR_EINVAL;                 // the partials must cover the image exactly
+    if (dtype != CVAR_BF16) return CVAR_EUNSUPPORTED;                                       // only the bf16 halo conv emits partials
+    constexpr int VEC = 8;
+    if (C % VEC || C % groups || C / VEC > 256) return CVAR_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const int ppb = gn_pix_per_block(HW);
+    const int nchunk = cdiv(HW, ppb);
+    float* coef = (float*)ws + (size_t)B * nchunk * C * 2;                                  // same place as in cvar_groupnorm_silu's workspace
+    hipLaunchKernelGGL(gn_finalize_tiles_kernel, dim3(groups, B), dim3(64), 0, st, gn_part, tiles_per_image, pixels_per_tile, weight, bias, coef, HW, C, groups, eps);
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(nchunk, B), dim3(256), 0, st, (const bf16_t*)x, coef, (bf16_t*)out, HW, C, ppb, silu);
     CVAR_CHECK_LAUNCH();
     return CVAR_OK;
 }
@@ -656,7 +710,7 @@ extern "C" int cvar_nhwc_to_nchw(const void* in, int dtype, int64_t ld_in, float
     return CVAR_OK;
 }
 
-extern "C" int cvar_abi_version(void) { return 17; }
+extern "C" int cvar_abi_version(void) { return 18; }
 extern "C" const char* cvar_status_str(int status) {
     switch (status) {
         case CVAR_OK: return "ok";

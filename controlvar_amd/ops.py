@@ -94,8 +94,11 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
          remap: Optional[Sequence[int]] = None, batch: int = 1, strideA: int = 0, strideW: int = 0, strideC: int = 0, strideR: int = 0,
          conv: Optional[dict] = None, a_off: int = 0, w_off: int = 0, c_off: int = 0,
          pre_act: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None, gate_scale: Optional[torch.Tensor] = None,
-         split: Optional[tuple] = None, split_alpha: float = 1.0, ln: Optional[tuple] = None, small_m: bool = False, split_k: bool = True):
+         split: Optional[tuple] = None, split_alpha: float = 1.0, ln: Optional[tuple] = None, small_m: bool = False, split_k: bool = True,
+         gn_part: Optional[torch.Tensor] = None):
     """C = epilogue(A @ W^T).  Offsets (*_off) are in elements of the respective tensor.
+    gn_part (fp32 [B][tiles][N][3], conv only): GroupNorm partials of the output from the conv's epilogue (cvar_gemm_desc.gn_part, ABI 18; ask
+    conv_gn_partials() whether the call can emit them - it fails loudly otherwise).
     ln = (out, ada, scale_off, shift_off, ld_ada, rows_per, eps): also write cast(LN(C[m]) * (1 + scale) + shift) of the finished rows to ``out`` -
     the ln_modulate of the op that follows (cvar_gemm_desc.ln_out, ABI 17; fused into the split-K reduction of small-M calls).
     split = (tensor, split_n, ld_split): result columns [0, split_n) go to ``tensor`` (rows not remapped), the rest to ``out`` at
@@ -136,6 +139,7 @@ def gemm(A: torch.Tensor, W: torch.Tensor, out: torch.Tensor, *, M: int, N: int,
         d.ln_out, d.ln_out_dtype = _ptr(lo), dt(lo)
         d.ln_scale, d.ln_shift = _ptr(ada) + 4 * sc_off, _ptr(ada) + 4 * sh_off
         d.ld_ln, d.ln_rows, d.ln_eps = ld_ada, rows_per, eps
+    d.gn_part = _ptr(gn_part)
     ws = _SPLITK_WS.get((A.device.index, _stream()))
     if ws is None:
         ws = ensure_splitk_workspace(A.device)
@@ -278,6 +282,23 @@ def groupnorm_ws_bytes(B, HW, Cdim) -> int:
 def groupnorm_silu(x, weight, bias, out, B, HW, Cdim, groups, eps, silu, ws):
     check(_lib.load().cvar_groupnorm_silu(_ptr(x), dt(x), _ptr(weight), _ptr(bias), _ptr(out), B, HW, Cdim, groups, eps, int(silu),
                                           _ptr(ws), _stream()), 'cvar_groupnorm_silu')
+    return out
+
+
+def conv_gn_partials(dtype: torch.dtype, stride: int, Cin: int, Cout: int, Hin: int, Win: int, Hout: int, Wout: int):
+    """(tiles_per_image, pixels_per_tile) when a 3x3 conv of this shape emits GroupNorm partials of its output (gemm(..., gn_part=...)), else None"""
+    if GEMM_TILE_CFG not in (0, 6):
+        return None
+    nt, pp = C.c_int(0), C.c_int(0)
+    if dtype not in _DT:
+        return None
+    ok = _lib.load().cvar_conv3x3_gn_partials(_DT[dtype], stride, Cin, Cout, Hin, Win, Hout, Wout, C.byref(nt), C.byref(pp))
+    return (nt.value, pp.value) if ok else None
+
+
+def groupnorm_silu_partials(x, weight, bias, out, B, HW, Cdim, groups, eps, silu, gn_part, tiles, tile_pixels, ws):
+    check(_lib.load().cvar_groupnorm_silu_partials(_ptr(x), dt(x), _ptr(weight), _ptr(bias), _ptr(out), B, HW, Cdim, groups, eps, int(silu),
+                                                   _ptr(gn_part), tiles, tile_pixels, _ptr(ws), _stream()), 'cvar_groupnorm_silu_partials')
     return out
 
 

@@ -108,8 +108,16 @@ typedef struct {
      * reduction launch plus cvar_ln_modulate; every other call gets a cvar_ln_modulate launch behind it.  Same bits either way. */
     void* ln_out; int ln_out_dtype;
     const float* ln_scale; const float* ln_shift; int64_t ld_ln; int ln_rows; float ln_eps;
+    /* ABI 18: GroupNorm statistics of the OUTPUT from the conv's own epilogue (gn_part != NULL; stride-1 3x3 bf16 convs that cvar_conv3x3_gn_partials accepts):
+     * gn_part[((b * tiles + t) * N + c) * 3 + {0, 1, 2}] = (sum (y - piv), sum (y - piv)^2, piv) over the 256 pixels of output tile t of image b for channel c,
+     * y = the values as stored (bf16), piv = the channel's value at one pixel of the tile.  cvar_groupnorm_silu_partials finishes them - the GroupNorm that
+     * follows a ResnetBlock conv (vae_modules.py:40-66) then needs no pass over the tensor for its statistics.  A call that cannot emit them returns
+     * CVAR_EUNSUPPORTED (never silently skips). */
+    float* gn_part;
 } cvar_gemm_desc;
 int cvar_gemm(const cvar_gemm_desc* d, void* stream);
+/* 1 (and the partial geometry) when a conv of this shape honours cvar_gemm_desc.gn_part, else 0 */
+int cvar_conv3x3_gn_partials(int dtype, int stride, int Cin, int Cout, int Hin, int Win, int Hout, int Wout, int* tiles_per_image, int* pixels_per_tile);
 
 /* Weight-gradient GEMM on token-major operands (ABI 13): C[n][k] = sum_t A[t][n] * B[t][k], A = [T][lda], B = [T][ldb] bf16, C fp32 [Nn][ldc]
  * (dW = dY^T X, the parameter gradients of every nn.Linear under autograd, train_control_var_hpu.py:231).  No transposed copies: the fragments
@@ -237,6 +245,10 @@ int cvar_first_tokens(const float* class_emb, const float* cond_embed, const int
 int64_t cvar_groupnorm_ws_bytes(int B, int HW, int C);
 int cvar_groupnorm_silu(const void* x, int dtype, const float* weight, const float* bias, void* out,
                         int B, int HW, int C, int groups, float eps, int silu, void* ws, void* stream);
+/* The same GroupNorm with its statistics taken from per-tile partials (cvar_gemm_desc.gn_part of the conv that produced x; ABI 18): tiles are combined in
+ * double precision in a fixed order, then out = silu?(x * a_c + d_c) as above.  ws: cvar_groupnorm_ws_bytes(B, HW, C) bytes (only the coefficient part is used). */
+int cvar_groupnorm_silu_partials(const void* x, int dtype, const float* weight, const float* bias, void* out, int B, int HW, int C, int groups, float eps,
+                                 int silu, const float* gn_part, int tiles_per_image, int pixels_per_tile, void* ws, void* stream);
 /* row softmax of fp32 scores -> dtype probabilities (AttnBlock, vae_modules.py:84). */
 int cvar_softmax_rows(const float* s, void* p, int out_dtype, int rows, int cols, void* stream);
 /* [B][n][c] -> [B][c][n] transpose of `dtype` (V operand of AttnBlock's second bmm, vae_modules.py:87-89). */

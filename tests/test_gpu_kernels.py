@@ -576,6 +576,86 @@ def test_conv3x3_halo_kernel_against_torch_and_the_implicit_gemm(gpu_device, B, 
     assert ((outs[6] - outs[5]).abs() <= (1e-4 if out_f32 else 2.0 ** -7) * (ref.abs() + 1)).all()
 
 
+# ------------------------------------------------------------------------------------------------ round 5: GroupNorm statistics from the conv's epilogue (ABI 18)
+@pytest.mark.parametrize('B,H,W,cin,cout,res,up,big_mean', [(2, 32, 32, 160, 160, False, 0, False),
+                                                              (3, 16, 48, 320, 320, True, 0, False),      # two 160-channel workgroup columns, residual in the sum
+                                                              (1, 64, 32, 160, 160, True, 1, False),      # behind the nearest x2 upsample
+                                                              (2, 16, 16, 64, 160, False, 0, True)])      # |mean| >> std: the per-tile pivots carry the precision
+def test_groupnorm_from_the_conv_epilogue_partials(gpu_device, B, H, W, cin, cout, res, up, big_mean):
+    """cvar_gemm_desc.gn_part (ABI 18): the halo conv writes (sum (y - piv), sum (y - piv)^2, piv) per tile and channel of the output it stores;
+    cvar_groupnorm_silu_partials must then give the GroupNorm of that stored tensor - checked against a float64 group_norm of the SAME bf16 values
+    (the yardstick of test_groupnorm_large_mean_small_spread) and against the stand-alone statistics pass (<= one bf16 step apart, almost everywhere equal).
+    The partials themselves are checked per tile against float64 sums."""
+    T = torch.bfloat16
+    hin, win = (H // 2, W // 2) if up else (H, W)
+    g = torch.Generator().manual_seed(7 * B + H + cin)
+    x = torch.randn(B * hin * win, cin, generator=g).to(T).to(gpu_device)
+    w = (torch.randn(cout, 9 * cin, generator=g) / (9 * cin) ** 0.5 * (0.02 if big_mean else 1.0)).to(T).to(gpu_device)
+    bias = (torch.randn(cout, generator=g) * (40.0 if big_mean else 1.0)).to(gpu_device)
+    r = torch.randn(B * H * W, cout, generator=g).to(T).to(gpu_device) if res else None
+    geo = ops.conv_gn_partials(T, 1, cin, cout, hin, win, H, W)
+    assert geo == ((H // 16) * (W // 16), 256)
+    out = torch.empty(B * H * W, cout, device=gpu_device, dtype=T)
+    part = torch.full((B, geo[0], cout, 3), float('nan'), device=gpu_device)
+    ops.gemm(x, w, out, M=B * H * W, N=cout, K=9 * cin, bias=bias, residual=r, conv=dict(Hin=hin, Win=win, Cin=cin, Hout=H, Wout=W, up=up), gn_part=part)
+    plain = torch.empty_like(out)
+    ops.gemm(x, w, plain, M=B * H * W, N=cout, K=9 * cin, bias=bias, residual=r, conv=dict(Hin=hin, Win=win, Cin=cin, Hout=H, Wout=W, up=up))
+    assert torch.equal(out, plain)                                       # asking for the partials does not change the conv's output
+    assert torch.isfinite(part).all()
+    # partials per tile: tiles are 16 x 16 pixel blocks in row-major tile order
+    y = out.double().cpu().view(B, H // 16, 16, W // 16, 16, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, geo[0], 256, cout)
+    pc = part.double().cpu()
+    piv = pc[..., 2].unsqueeze(2)
+    assert ((y - piv).abs().amin(dim=2) == 0).all()                      # the pivot is one of the tile's own stored values
+    S, Q = (y - piv).sum(2), ((y - piv) ** 2).sum(2)
+    assert (pc[..., 0] - S).abs().max() <= 1e-4 * (S.abs().max() + 1) and (pc[..., 1] - Q).abs().max() <= 1e-4 * (Q.abs().max() + 1)
+    # the GroupNorm from them
+    G = 32
+    gw, gb = (1 + 0.1 * torch.randn(cout, generator=g)).to(gpu_device), (0.1 * torch.randn(cout, generator=g)).to(gpu_device)
+    ws = torch.empty(ops.groupnorm_ws_bytes(B, H * W, cout), device=gpu_device, dtype=torch.uint8)
+    for silu in (False, True):
+        a = ops.groupnorm_silu_partials(out, gw, gb, torch.empty_like(out), B, H * W, cout, G, 1e-6, silu, part, geo[0], geo[1], ws)
+        b_ = ops.groupnorm_silu(out, gw, gb, torch.empty_like(out), B, H * W, cout, G, 1e-6, silu, ws)
+        ref = F.group_norm(out.double().cpu().view(B, H * W, cout).permute(0, 2, 1), G, gw.double().cpu(), gb.double().cpu(), 1e-6).permute(0, 2, 1).reshape(B * H * W, cout)
+        if silu:
+            ref = F.silu(ref)
+        assert (a.double().cpu() - ref).abs().max().item() < 3e-2
+        d = (a.float() - b_.float()).abs()
+        assert (d <= 2.0 ** -7 * (b_.float().abs() + 1)).all() and (d > 0).float().mean().item() < 0.02
+    from controlvar_amd._lib import CvarError
+    with pytest.raises(CvarError):      # a conv that cannot emit them refuses instead of skipping silently (stride 2)
+        ops.gemm(x, w, torch.empty(B * (hin // 2) * (win // 2), cout, device=gpu_device, dtype=T), M=B * (hin // 2) * (win // 2), N=cout, K=9 * cin,
+                 conv=dict(Hin=hin, Win=win, Cin=cin, Hout=hin // 2, Wout=win // 2, stride=2), gn_part=part)
+    assert ops.conv_gn_partials(T, 2, cin, cout, hin, win, hin // 2, win // 2) is None and ops.conv_gn_partials(torch.float32, 1, cin, cout, hin, win, H, W) is None
+
+
+def test_vqvae_with_conv_epilogue_statistics_is_as_close_to_fp32_as_without(gpu_device):
+    """whole bf16 decoder / encoder with GN_FROM_CONV on and off.  The two differ only by the fp32 summation order of the GroupNorm statistics, but 60 bf16
+    layers amplify any one-ulp flip to the mode's own noise level (mean |err| ~ 1e-2 on [-1, 1] pixels) - so the yardstick is the fp32
+    parity mode of the same weights: the image with the epilogue statistics must be no farther from it than the image with the stand-alone pass (x 1.25),
+    and the two bf16 images no farther from each other than from fp32.  The fp32 mode never takes the halo conv and is untouched."""
+    from test_gpu_parity import make_vae as _mk
+    from controlvar_amd import models
+    vae, vae32 = _mk(160, torch.bfloat16, gpu_device), _mk(160, torch.float32, gpu_device)
+    f = torch.randn(2, 32, 16, 16, generator=torch.Generator().manual_seed(3)).to(gpu_device)
+    img = (torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(4)) * 2 - 1).to(gpu_device)
+    c, fc = vae32.fhat_to_img(f).float(), vae32._encode_f(img)
+    try:
+        models.VQVAE.GN_FROM_CONV = True
+        a, fa = vae.fhat_to_img(f).float(), vae._encode_f(img)
+        a2 = vae.fhat_to_img(f).float()
+        models.VQVAE.GN_FROM_CONV = False
+        b, fb = vae.fhat_to_img(f).float(), vae._encode_f(img)
+    finally:
+        models.VQVAE.GN_FROM_CONV = True
+    assert torch.equal(a, a2)                                            # fixed summation order: bit-reproducible
+    e_on, e_off, e_ab = [(u - v).abs().mean().item() for u, v in ((a, c), (b, c), (a, b))]
+    print(f'[gn-from-conv] decoder mean |err| vs fp32: with {e_on:.3e}, without {e_off:.3e}; between the two bf16 images {e_ab:.3e}')
+    assert e_on <= 1.25 * e_off + 1e-3 and e_ab <= 1.5 * max(e_on, e_off) and e_on < 3e-2
+    g_on, g_off = [(u - fc).abs().mean().item() for u in (fa, fb)]
+    assert g_on <= 1.25 * g_off + 1e-3 * fc.abs().mean().item()
+
+
 # ------------------------------------------------------------------------------------------------ round 3: prescaled queries (ABI 14)
 @pytest.mark.parametrize('H,Lmax,q_off,l,levels,holes', [
     (2, 1360, 848, 512, None, None),                       # last scale of the pyramid: 4 query blocks, 22 KV tiles

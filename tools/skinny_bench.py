@@ -10,7 +10,7 @@ from controlvar_amd._lib import ACT_GELU_TANH
 
 ops.GEMM_TILE_CFG = int(os.environ.get('ISO_CFG', '0'))          # tile_cfg of the LDS-tiled arm (13 / 14: three / four LDS stages on the 128x128 tile)
 dev = torch.device('cuda:0')
-C, depth, Lmax = 1536, 24, 1360
+C, depth, Lmax = 1536, int(os.environ.get('SK_DEPTH', '24')), 1360       # SK_DEPTH=2: 113 MB of weights - they stay in the 256 MB Infinity Cache between replays
 Ms = [int(a) for a in sys.argv[1:]] or [4, 16, 36, 64, 100, 144, 256, 400, 676, 1024]
 g = torch.Generator(device='cpu').manual_seed(0)
 Wqkv = (torch.randn(depth, 3 * C, C, generator=g) * 0.02).to(torch.bfloat16).to(dev)

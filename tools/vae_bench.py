@@ -7,6 +7,7 @@ from controlvar_amd import models
 from controlvar_amd.synth import synth_images
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 dev = torch.device('cuda:0')
+models.VQVAE.GN_FROM_CONV = os.environ.get('GN_FROM_CONV', '1') != '0'          # A/B: GroupNorm statistics from the conv epilogue (round 5) or the stand-alone pass
 vae = models.build_vae(ch=160, decode_chunk=64).to(dev)
 img = synth_images(B, 256, seed=3).to(dev)
 def step():
@@ -20,5 +21,5 @@ step(); torch.cuda.synchronize()
 t0 = time.perf_counter(); n = 3
 for _ in range(n): out = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-print(json.dumps({'metric': 'VQVAE encode+quant+decode images/s (256^2)', 'value': round(B / dt, 1), 'batch': B, 'ms_per_pass': round(dt * 1e3, 1),
+print(json.dumps({'gn_from_conv': models.VQVAE.GN_FROM_CONV, 'metric': 'VQVAE encode+quant+decode images/s (256^2)', 'value': round(B / dt, 1), 'batch': B, 'ms_per_pass': round(dt * 1e3, 1),
                   'algorithmic_tflops': round(609e9 * B / dt / 1e12, 1), 'mem_GB': round(torch.cuda.max_memory_allocated() / 2**30, 1)}))
