@@ -1123,7 +1123,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
     }
 }
 
-template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_mfma_kernel(const AttnBwdParams p);
+template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_dq_mfma_kernel(const AttnBwdParams p);
 template <bool HOLES> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_mfma_kernel(const AttnBwdParams p);
 
 // ws: R*H*l floats (D = rowsum(dO * O)).  impl: 0 = auto (MFMA kernels for bf16, row-wise exact kernels for fp32), 1 = row-wise
@@ -1216,7 +1216,7 @@ __device__ __forceinline__ bf16x8_t bw_tr_frag(const char* lane_base, int row0) 
 }
 
 template <bool HOLES>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dq_mfma_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_dq_mfma_kernel(const AttnBwdParams p) {
     constexpr int D = 64, KT = 64;
     __shared__ __attribute__((aligned(1024))) char Ks[KT * 128];      // K, row swizzle (S^T = K Q^T)
     __shared__ __attribute__((aligned(1024))) char Vs[KT * 128];      // V, row swizzle (dP^T = V dO^T)
@@ -1252,47 +1252,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int i = 0; i < 16; ++i) dq[db][i] = 0.f;
 
-    // one key tile's arithmetic; MASK compile-time (tiles below wave_min_kv are seen completely by all 32 queries of the wave)
+    // one key tile's arithmetic, one 32-key half at a time (scores, dP, dS and the dQ update of a half are finished before the next half starts: 32
+    // accumulator registers live instead of 64 - three waves per SIMD); MASK compile-time (tiles below wave_min_kv are seen completely by all 32 queries of the wave)
     auto compute = [&](int kt0, auto MASK) {
-        f32x16_t s[2], dp[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            f32x16_t s, dp;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { s[kb][i] = 0.f; dp[kb][i] = 0.f; }
+            for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int off = (32 * kb + lrow) * 128 + (((2 * ks + hi) ^ sw) << 4);
                 const bf16x8_t kf = *(const bf16x8_t*)(Ks + off);
                 const bf16x8_t vf = *(const bf16x8_t*)(Vs + off);
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
-                dp[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, of[ks], dp[kb], 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, of[ks], dp, 0, 0, 0);
             }
-        }
-        bf16x8_t dsf[2][2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            bf16x8_t dsf[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 float ds[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int i = 8 * t + j;
-                    float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][i], c2, -lse2));
+                    float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c2, -lse2));
                     if constexpr (decltype(MASK)::value) {
                         const int key = kt0 + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * hi;
                         if (!vis_key_t<HOLES>(vis, key)) pr = 0.f;
                     }
-                    ds[j] = pr * (dp[kb][i] - Dq);
+                    ds[j] = pr * (dp[i] - Dq);
                 }
-                dsf[kb][t] = pack_bf16x8(ds);
+                dsf[t] = pack_bf16x8(ds);
             }
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
-                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw_tr_frag(k2_lane[db], 32 * kb + 16 * t), dsf[kb][t], dq[db], 0, 0, 0);
+                    dq[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw_tr_frag(k2_lane[db], 32 * kb + 16 * t), dsf[t], dq[db], 0, 0, 0);
+        }
     };
     typedef std::integral_constant<bool, true> Yes;
     typedef std::integral_constant<bool, false> No;

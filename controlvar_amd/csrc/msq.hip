@@ -156,9 +156,10 @@ struct MsEncodeParams {
     int Ltot;
 };
 
-// NTH = 256: one wave per SIMD (the pyramid fills the LDS), both search forms.  NTH = 512 (round 4): 8 waves - the lane-owns-a-code search with two waves
-// per SIMD to hide its loads (1024 threads would cap the kernel at 128 registers: 1.2 KB of scratch per lane), the phi conv split over two blocks of output channels; fast search form only (cvar_ms_encode picks the instance).  Every
-// distance / conv output is the same fma chain in both, and the merges keep the first minimum: identical ids.
+// NTH = 256: one wave per SIMD (the pyramid fills the LDS), both search forms (matrix-pipe search; sequential search when the margins are asked for).
+// NTH = 512: 8 waves, two per SIMD - one wave's compare / select / code-row loads run beside the other's MFMAs -, the phi conv split over two blocks of output
+// channels; matrix-pipe search only (cvar_ms_encode picks the instance).  Every distance / conv output is the same fma chain in both, and the merges keep the
+// first minimum: identical ids.  (Round 4's lane-owns-a-code VALU search - 2.62 ms per call against 1.93 ms - is gone: experiments/README.md.)
 template <int NTH>
 __global__ __launch_bounds__(NTH) void ms_encode_kernel(const MsEncodeParams p) {
     constexpr int NW = NTH / 64;
@@ -182,15 +183,15 @@ __global__ __launch_bounds__(NTH) void ms_encode_kernel(const MsEncodeParams p) 
         const int pn = p.pn[si], n = pn * pn;
         // z[t][c] = area(f_rest) -> bufA (token-major)
         ms_area_tokens<NTH>(fr, p.down + p.down_off[si], tmp, bufA, pn, false);
-        if (NTH != 256 || (!p.margin_out && (p.V & 255) == 0)) {
-            // ---- nearest code, fast form (no margin requested).  The pyramid fills the LDS, so a workgroup is one wave per SIMD
-            // and nothing hides a load: the token-per-thread search below walks the 512 KB codebook row by row at ~1000 cycles a
-            // code (86 % of the kernel).  Here a LANE owns a code: wave w searches codes [w V/4, (w+1) V/4) in groups of 64 (one
-            // coalesced 8 KB load per group, the next group's rows prefetched), tokens come from LDS as broadcast reads, and a
-            // lane keeps the first minimum over ITS codes for a block of 8 tokens; one lexicographic (distance, index) wave
-            // reduction per token block and a merge of the four waves in code order give exactly the first-minimum index of the
-            // sequential search - every distance is the same fmaf chain as before.
-            const int lane = tid & 63, w = tid >> 6;
+        if (!p.margin_out && (p.V % (32 * NW)) == 0) {
+            // ---- nearest code on the matrix pipe (round 5).  dot[t][v] = sum_c z[t][c] E[v][c] is a GEMM: v_mfma_f32_32x32x2_f32 is exact fp32 and bitwise an
+            // fmaf chain over k (MI355X_MICROARCH.md; the fp32 parity mode of gemm.hip rests on the same property), so with channels 2 s, 2 s + 1 in step s
+            // every distance is the SAME ascending-c chain the sequential search computes - at the matrix pipe's 64 flop per clock and SIMD, without a
+            // broadcast LDS read per fma.  Wave w owns codes [w V/4, (w+1) V/4) as before; per block of 32 tokens it walks its codes 32 at a time:
+            // lane j (both half-waves) holds code j's row (B operand: channel 2 s + hi of code j), the accumulator column j holds the block's 32 dots;
+            // a lane keeps the first minimum of ITS column per token row (codes come in increasing order), then one lexicographic (distance, index)
+            // reduction over the 32 columns per row and the merge of the four waves in code order: exactly the first-minimum index of the sequential search.
+            const int lane = tid & 63, w = tid >> 6, col = lane & 31, hi = lane >> 5;
             if (tid < n) {
                 float zz = 0.f;
 #pragma unroll
@@ -198,26 +199,42 @@ __global__ __launch_bounds__(NTH) void ms_encode_kernel(const MsEncodeParams p) 
                 zzs[tid] = zz;
             }
             __syncthreads();
-            const int per_wave = p.V / NW, groups = per_wave / 64;
-            constexpr int TB = NTH == 256 ? 8 : 4;           // tokens per pass over a wave's codes (512 threads: half the register budget per lane)
-            for (int t0 = 0; t0 < n; t0 += TB) {
-                float bd8[TB]; int bi8[TB];
+            const int per_wave = p.V / NW, cblocks = per_wave / 32;
+            for (int t0 = 0; t0 < n; t0 += 32) {
+                // A operand of step s: z[t0 + col][2 s + hi] (tail tokens repeat the last one: results ignored); the row's |z|^2 per accumulator register
+                float za[MS_C / 2], zr[16];
+                {
+                    const float* zt = bufA + min(t0 + col, n - 1) * MS_C + hi;
 #pragma unroll
-                for (int u = 0; u < TB; ++u) { bd8[u] = INFINITY; bi8[u] = 0; }
+                    for (int s_ = 0; s_ < MS_C / 2; ++s_) za[s_] = zt[2 * s_];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zr[r] = zzs[min(t0 + (r & 3) + 8 * (r >> 2) + 4 * hi, n - 1)];
+                }
+                float bd[16]; int bi[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { bd[r] = INFINITY; bi[r] = 0; }
                 f32x4_t e4[MS_C / 4], nx[MS_C / 4];
                 {
-                    const float* er = p.E + (long)(w * per_wave + lane) * MS_C;
+                    const float* er = p.E + (long)(w * per_wave + col) * MS_C;
 #pragma unroll
                     for (int q = 0; q < MS_C / 4; ++q) nx[q] = *(const f32x4_t*)(er + 4 * q);
                 }
-                for (int g = 0; g < groups; ++g) {
-                    const int v = w * per_wave + g * 64 + lane;
+                for (int cb = 0; cb < cblocks; ++cb) {
+                    const int v = w * per_wave + cb * 32 + col;
 #pragma unroll
                     for (int q = 0; q < MS_C / 4; ++q) e4[q] = nx[q];
-                    if (g + 1 < groups) {
-                        const float* er = p.E + (long)(v + 64) * MS_C;
+                    if (cb + 1 < cblocks) {
+                        const float* er = p.E + (long)(v + 32) * MS_C;
 #pragma unroll
                         for (int q = 0; q < MS_C / 4; ++q) nx[q] = *(const f32x4_t*)(er + 4 * q);
+                    }
+                    f32x16_t acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                    for (int s_ = 0; s_ < MS_C / 2; ++s_) {
+                        const float eb = hi ? e4[s_ >> 1][2 * (s_ & 1) + 1] : e4[s_ >> 1][2 * (s_ & 1)];       // E[v][2 s + hi]
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(za[s_], eb, acc, 0, 0, 0);
                     }
                     float ee = 0.f;
 #pragma unroll
@@ -226,40 +243,32 @@ __global__ __launch_bounds__(NTH) void ms_encode_kernel(const MsEncodeParams p) 
                         ee = fmaf(e4[q][2], e4[q][2], ee); ee = fmaf(e4[q][3], e4[q][3], ee);
                     }
 #pragma unroll
-                    for (int u = 0; u < TB; ++u) {
-                        const int t = min(t0 + u, n - 1);                  // tail tokens repeat the last one (results ignored)
-                        const float* zt = bufA + t * MS_C;
-                        float dot = 0.f;
-#pragma unroll
-                        for (int q = 0; q < MS_C / 4; ++q) {
-                            const f32x4_t z4 = *(const f32x4_t*)(zt + 4 * q);
-                            dot = fmaf(z4[0], e4[q][0], dot); dot = fmaf(z4[1], e4[q][1], dot);
-                            dot = fmaf(z4[2], e4[q][2], dot); dot = fmaf(z4[3], e4[q][3], dot);
-                        }
-                        const float d = __fadd_rn(__fadd_rn(zzs[t], ee), __fmul_rn(-2.0f, dot));
-                        if (d < bd8[u]) { bd8[u] = d; bi8[u] = v; }           // codes of a lane come in increasing order: first minimum
+                    for (int r = 0; r < 16; ++r) {
+                        const float d = __fadd_rn(__fadd_rn(zr[r], ee), __fmul_rn(-2.0f, acc[r]));
+                        if (d < bd[r]) { bd[r] = d; bi[r] = v; }                  // a column's codes come in increasing order: first minimum
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < TB; ++u) {
-                    float d = bd8[u]; int i = bi8[u];
+                for (int r = 0; r < 16; ++r) {
+                    float d = bd[r]; int i = bi[r];
 #pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
+                    for (int o = 16; o > 0; o >>= 1) {                            // over the 32 columns of this half-wave
                         const float d2 = __shfl_xor(d, o, 64);
                         const int i2 = __shfl_xor(i, o, 64);
                         if (d2 < d || (d2 == d && i2 < i)) { d = d2; i = i2; }
                     }
-                    if (lane == 0 && t0 + u < n) { wave_bd[w][t0 + u] = d; wave_bi[w][t0 + u] = i; }
+                    const int t = t0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (col == 0 && t < n) { wave_bd[w][t] = d; wave_bi[w][t] = i; }
                 }
             }
             __syncthreads();
             if (tid < n) {
-                float bd = wave_bd[0][tid]; int bi = wave_bi[0][tid];
+                float bdm = wave_bd[0][tid]; int bim = wave_bi[0][tid];
 #pragma unroll
                 for (int q = 1; q < NW; ++q)                                     // waves hold increasing code ranges: strict '<'
-                    if (wave_bd[q][tid] < bd) { bd = wave_bd[q][tid]; bi = wave_bi[q][tid]; }
-                sidx[tid] = bi;
-                p.idx_out[b * p.Ltot + p.idx_off[si] + tid] = bi;
+                    if (wave_bd[q][tid] < bdm) { bdm = wave_bd[q][tid]; bim = wave_bi[q][tid]; }
+                sidx[tid] = bim;
+                p.idx_out[b * p.Ltot + p.idx_off[si] + tid] = bim;
             }
             __syncthreads();
         } else if constexpr (NTH == 256) {
@@ -334,8 +343,16 @@ extern "C" int cvar_ms_encode(const float* f, const float* codebook, int V, cons
     }
     p.Ltot = io;
     const size_t lds = 4 * MS_MAP * sizeof(float);
-    // (round 4, measured and not used: the <512> instance - 8 waves, token blocks of 4 to fit 256 registers - runs 3.27 ms per call against 2.67 ms: the
-    //  halved token block doubles the passes over the codebook, and that costs more than the second wave per SIMD hides.)
+#ifndef MS_ENCODE_W8
+#define MS_ENCODE_W8 1
+#endif
+    if (MS_ENCODE_W8 && !margin_out && V % 256 == 0) {
+        // eight waves (two per SIMD): one wave's compare / select / code-row loads run beside the other's MFMAs; 512 codes per wave
+        (void)hipFuncSetAttribute((const void*)ms_encode_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(ms_encode_kernel<512>, dim3(B), dim3(512), lds, as_stream(stream), p);
+        CVAR_CHECK_LAUNCH();
+        return CVAR_OK;
+    }
     (void)hipFuncSetAttribute((const void*)ms_encode_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(ms_encode_kernel<256>, dim3(B), dim3(256), lds, as_stream(stream), p);
     CVAR_CHECK_LAUNCH();
