@@ -304,7 +304,10 @@ def _tune_channels(a, world, device, run_two_steps):
     Returns the keys for the JSON line; the chosen group is in the returned dict under '_group' (popped by the caller)."""
     from controlvar_amd.launcher import channel_groups, pick_fastest
     cands = _channel_candidates(a)
-    groups = channel_groups(cands)
+    try:
+        groups = channel_groups(cands)
+    except Exception as e:                   # a library that rejects the per-communicator cap must not cost the run its line: default group, reason on the line
+        return {'comm_channels': 'default', 'comm_channels_tried_s': {}, 'comm_channels_error': f'{type(e).__name__}: {e}'[:300], '_group': None}
 
     def seconds_of(label):
         run_two_steps(label, groups[label])                     # communicator set-up / first-use cost stays outside the clock

@@ -1172,10 +1172,9 @@ static int cvar_attention_bwd_impl(const void* qkv, int dtype, const void* o, co
 // P is recomputed from the saved log-sum-exp; fp32 accumulation everywhere.
 // ================================================================================================
 // Round 5: the transposed operands (K^T for dQ, Q^T / dO^T for dK / dV) are no longer built on the way INTO LDS (8 pack operations + 8 ds_write_b32
-// per thread, tile and image, on the vector pipe that bounds these kernels): every 64 x 64 tile is stored row-major twice - once with the 16-byte chunks
-// XOR-swizzled by (row >> 1) & 7 for ds_read_b128 fragment reads along a row, once with the 32-byte segments swizzled by row & 3 for
-// ds_read_b64_tr_b16 transpose reads (the layout of the forward kernel's V tile) - two ds_write_b128 per image.  Tiles whose keys every query of the tile
-// sees (all but the level-boundary ones) run a compile-time unmasked body: no per-score compare / select, no visibility tables.
+// per thread, tile and image, on the vector pipe that bounds these kernels): every 64 x 64 tile is stored row-major ONCE (two ds_write_b128 per thread) under a
+// swizzle that both ds_read_b128 fragment reads along a row and ds_read_b64_tr_b16 transpose reads take without bank conflicts (bw_swz below).  Tiles whose keys
+// every query of the tile sees (all but the level-boundary ones) run a compile-time unmasked body: no per-score compare / select, no visibility tables.
 
 // staging map: thread -> rows (tid >> 3) and (tid >> 3) + 32 of a 64 x 64 bf16 tile, 16-byte chunk tid & 7 (the forward kernel's map)
 struct BwRows { bf16x8_t a, b; };
@@ -1187,30 +1186,39 @@ __device__ __forceinline__ BwRows bw_load_rows(const bf16_t* src, long row_strid
     v.b = (row0 + row + 32) < row_limit ? *(const bf16x8_t*)(src + (long)(row0 + row + 32) * row_stride + chunk * 8) : z;
     return v;
 }
-// image for fragment reads along a row (ds_read_b128): chunk index XOR (row >> 1) & 7 - rows r and r + 32 share the swizzle
-__device__ __forceinline__ void bw_store_rm(char* dst, const BwRows& v, int tid) {
+// ONE image serves both read patterns (round 5, second step: the stores of a second, transpose-read image cost 21 % of the dK/dV kernel - tools ablation,
+// profiles/r05_attn_bwd.txt).  Row r keeps its eight 16-byte chunks at chunk ^ bw_swz(r), bw_swz(r) = ((r >> 1) & 1) << 2 | ((r >> 2) & 3):
+//   * ds_read_b128 fragment reads along a row (lane = row, one chunk): the hardware's 16-lane groups hold rows {0-3, 12-15, 20-27} / {4-11, 16-19, 28-31};
+//     rows of one parity inside a group get eight DIFFERENT swizzles ({0,4,3,7,1,5,2,6} / {1,5,2,6,0,4,3,7}) - with the 128-byte row pitch all 64 banks once;
+//   * ds_read_b64_tr_b16 transpose reads (a half-wave covers rows r0 .. r0 + 3 x four adjacent chunks): rows r0 and r0 + 2 share a bank half, and their swizzles
+//     differ in bit 2, i.e. they land in different 64-byte halves of the row - conflict-free as well.
+// Rows r and r + 32 share the swizzle (the two rows a thread stages).
+__device__ __forceinline__ int bw_swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ void bw_store(char* dst, const BwRows& v, int tid) {
     const int row = tid >> 3, chunk = tid & 7;
-    char* d = dst + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+    char* d = dst + row * 128 + ((chunk ^ bw_swz(row)) << 4);
     *(bf16x8_t*)d = v.a;
     *(bf16x8_t*)(d + 32 * 128) = v.b;
 }
-// image for transpose reads (ds_read_b64_tr_b16): 32-byte segment index XOR row & 3
-__device__ __forceinline__ void bw_store_tr(char* dst, const BwRows& v, int tid) {
-    const int row = tid >> 3, chunk = tid & 7;
-    char* d = dst + row * 128 + ((((chunk >> 1) ^ (row & 3)) << 5) | ((chunk & 1) << 4));
-    *(bf16x8_t*)d = v.a;
-    *(bf16x8_t*)(d + 32 * 128) = v.b;
+// lane address of the row fragment (MFMA operand: lane & 31 = row inside a 32-row block, chunk 2 ks + hi): add (32 * block) * 128
+__device__ __forceinline__ int bw_row_off(int lrow, int chunk) { return lrow * 128 + ((chunk ^ bw_swz(lrow)) << 4); }
+// lane addresses of the transposed fragments of column block db (columns 32 db .. 32 db + 31 become the fragment's rows): lane l of a 16-lane group points at tile
+// row (l & 15) >> 2 of a [4 rows][16 columns] block, 8 bytes = columns 4 (l & 3) .. + 3; the upper half-wave 4 rows further.  Two bases: rows r0 + 4 hi + j and the
+// same + 8 (their swizzles differ: (row >> 2) & 3 = hi resp. hi + 2 for r0 a multiple of 16).
+struct BwTrLane { const char* lo; const char* up; };
+__device__ __forceinline__ BwTrLane bw_tr_lane(const char* img, int lane, int db) {
+    const int hi = lane >> 5, jrow = (lane & 15) >> 2, g = (lane >> 4) & 1, x = lane & 3;
+    const int c = 4 * db + 2 * g + (x >> 1);
+    const int f_lo = ((jrow >> 1) << 2) | hi, f_up = ((jrow >> 1) << 2) | (hi + 2);
+    BwTrLane r;
+    r.lo = img + (4 * hi + jrow) * 128 + ((c ^ f_lo) << 4) + (x & 1) * 8;
+    r.up = img + (8 + 4 * hi + jrow) * 128 + ((c ^ f_up) << 4) + (x & 1) * 8;
+    return r;
 }
-// lane address of the transposed fragments of column block db (columns 32 db .. 32 db + 31 become the fragment's rows): see the V tile of
-// attn_mfma_bf16_kernel - lane l of a 16-lane group points at tile row (l & 15) >> 2 of a [4 rows][16 columns] block, the upper half-wave 4 rows further
-__device__ __forceinline__ const char* bw_tr_lane(const char* img, int lane, int db) {
-    const int hi = lane >> 5, jrow = (lane & 15) >> 2, g = (lane >> 4) & 1;
-    return img + (4 * hi + jrow) * 128 + (((2 * db + g) ^ jrow) << 5) + (lane & 3) * 8;
-}
-// A-operand fragment T^T[32 db + (lane & 31)][row0 + {4 hi .. 4 hi + 3, 8 + 4 hi .. 8 + 4 hi + 3}]
-__device__ __forceinline__ bf16x8_t bw_tr_frag(const char* lane_base, int row0) {
-    const s16x4_t v0 = lds_tr16_b64(lane_base + row0 * 128);
-    const s16x4_t v1 = lds_tr16_b64(lane_base + (row0 + 8) * 128);
+// A-operand fragment T^T[32 db + (lane & 31)][row0 + {4 hi .. 4 hi + 3, 8 + 4 hi .. 8 + 4 hi + 3}], row0 a multiple of 16
+__device__ __forceinline__ bf16x8_t bw_tr_frag(const BwTrLane& b, int row0) {
+    const s16x4_t v0 = lds_tr16_b64(b.lo + row0 * 128);
+    const s16x4_t v1 = lds_tr16_b64(b.up + row0 * 128);
     const bf16x8_t f = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
     return f;
 }
@@ -1218,11 +1226,10 @@ __device__ __forceinline__ bf16x8_t bw_tr_frag(const char* lane_base, int row0) 
 template <bool HOLES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_bwd_dq_mfma_kernel(const AttnBwdParams p) {
     constexpr int D = 64, KT = 64;
-    __shared__ __attribute__((aligned(1024))) char Ks[KT * 128];      // K, row swizzle (S^T = K Q^T)
-    __shared__ __attribute__((aligned(1024))) char Vs[KT * 128];      // V, row swizzle (dP^T = V dO^T)
-    __shared__ __attribute__((aligned(1024))) char K2[KT * 128];      // K again, transpose-read swizzle (dQ^T += K^T dS^T)
+    __shared__ __attribute__((aligned(1024))) char Ks[KT * 128];      // K: row fragments (S^T = K Q^T) and transposed fragments (dQ^T += K^T dS^T) out of one image
+    __shared__ __attribute__((aligned(1024))) char Vs[KT * 128];      // V: row fragments (dP^T = V dO^T)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int lrow = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
+    const int lrow = lane & 31, hi = lane >> 5;
     const int h = blockIdx.y;
     const long r = blockIdx.z;
     const int C3 = 3 * p.H * D;
@@ -1245,7 +1252,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const float c2 = p.scale * 1.4426950408889634f;
     const float lse2 = p.lse[(r * p.H + h) * (long)p.l + qrow] * 1.4426950408889634f;
     const float Dq = p.dsum[(r * p.H + h) * (long)p.l + qrow];
-    const char* k2_lane[2] = {bw_tr_lane(K2, lane, 0), bw_tr_lane(K2, lane, 1)};
+    const BwTrLane k2_lane[2] = {bw_tr_lane(Ks, lane, 0), bw_tr_lane(Ks, lane, 1)};
+    int row_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) row_off[ks] = bw_row_off(lrow, 2 * ks + hi);
     f32x16_t dq[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -1262,7 +1272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int off = (32 * kb + lrow) * 128 + (((2 * ks + hi) ^ sw) << 4);
+                const int off = 32 * kb * 128 + row_off[ks];
                 const bf16x8_t kf = *(const bf16x8_t*)(Ks + off);
                 const bf16x8_t vf = *(const bf16x8_t*)(Vs + off);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
@@ -1295,9 +1305,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     typedef std::integral_constant<bool, false> No;
     BwRows kv_k = bw_load_rows(kbase, C3, 0, kv_end, tid), kv_v = bw_load_rows(vbase, C3, 0, kv_end, tid);
     for (int kt0 = 0; kt0 < kv_end; kt0 += KT) {
-        bw_store_rm(Ks, kv_k, tid);
-        bw_store_tr(K2, kv_k, tid);
-        bw_store_rm(Vs, kv_v, tid);
+        bw_store(Ks, kv_k, tid);
+        bw_store(Vs, kv_v, tid);
         __syncthreads();
         if (kt0 + KT < kv_end) {            // next K / V tile travels while this one is computed
             kv_k = bw_load_rows(kbase, C3, kt0 + KT, kv_end, tid);
@@ -1323,17 +1332,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 template <bool HOLES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_bwd_dkv_mfma_kernel(const AttnBwdParams p) {
     constexpr int D = 64, QT = 64;
-    __shared__ __attribute__((aligned(1024))) char Qs[QT * 128];      // Q / dO, row swizzle (S = Q K^T, dP = dO V^T)
-    __shared__ __attribute__((aligned(1024))) char Os[QT * 128];
-    __shared__ __attribute__((aligned(1024))) char Q2[QT * 128];      // Q / dO again, transpose-read swizzle (dK^T += Q^T dS, dV^T += dO^T P)
-    __shared__ __attribute__((aligned(1024))) char O2[QT * 128];
+    __shared__ __attribute__((aligned(1024))) char Qs[QT * 128];      // Q / dO tiles: row fragments (S = Q K^T, dP = dO V^T) and transposed fragments
+    __shared__ __attribute__((aligned(1024))) char Os[QT * 128];      // (dK^T += Q^T dS, dV^T += dO^T P) out of one image each
     __shared__ __attribute__((aligned(16))) float Ls[QT];
     __shared__ __attribute__((aligned(16))) float Dsum[QT];
     __shared__ __attribute__((aligned(16))) int Kv[QT];
     __shared__ __attribute__((aligned(16))) int Hlo[QT];
     __shared__ __attribute__((aligned(16))) int Hhi[QT];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int lrow = lane & 31, hi = lane >> 5, sw = (lane >> 1) & 7;
+    const int lrow = lane & 31, hi = lane >> 5;
     const int h = blockIdx.y;
     const long r = blockIdx.z;
     const int C3 = 3 * p.H * D;
@@ -1352,8 +1359,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int ks = 0; ks < 4; ++ks) { kf[ks] = *(const bf16x8_t*)(kp + (2 * ks + hi) * 8); vf[ks] = *(const bf16x8_t*)(vp + (2 * ks + hi) * 8); }
     }
     const float c2 = p.scale * 1.4426950408889634f;
-    const char* q2_lane[2] = {bw_tr_lane(Q2, lane, 0), bw_tr_lane(Q2, lane, 1)};
-    const char* o2_lane[2] = {bw_tr_lane(O2, lane, 0), bw_tr_lane(O2, lane, 1)};
+    const BwTrLane q2_lane[2] = {bw_tr_lane(Qs, lane, 0), bw_tr_lane(Qs, lane, 1)};
+    const BwTrLane o2_lane[2] = {bw_tr_lane(Os, lane, 0), bw_tr_lane(Os, lane, 1)};
+    int row_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) row_off[ks] = bw_row_off(lrow, 2 * ks + hi);
     f32x16_t dk[2], dv[2];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -1369,7 +1379,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int off = (32 * qb + lrow) * 128 + (((2 * ks + hi) ^ sw) << 4);
+                const int off = 32 * qb * 128 + row_off[ks];
                 const bf16x8_t qa = *(const bf16x8_t*)(Qs + off);
                 const bf16x8_t oa = *(const bf16x8_t*)(Os + off);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[ks], s, 0, 0, 0);       // S[q][key]: lane = key, regs = queries
@@ -1439,10 +1449,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // workgroup-uniform: all 64 queries of the tile exist and each sees every key of this workgroup
     auto is_full = [&](int qt0) { return qt0 + QT <= p.l && range_full_prefix(p, p.q_off + qt0, p.q_off + qt0 + QT - 1) >= key_hi; };
     auto tile = [&](int qt0, auto MASK) {
-        bw_store_rm(Qs, qv, tid);
-        bw_store_tr(Q2, qv, tid);
-        bw_store_rm(Os, ov, tid);
-        bw_store_tr(O2, ov, tid);
+        bw_store(Qs, qv, tid);
+        bw_store(Os, ov, tid);
         if (tid < QT) {
             const int qi = qt0 + tid;
             const bool ok = qi < p.l;

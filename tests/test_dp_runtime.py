@@ -135,6 +135,51 @@ def test_real_slabs_through_rccl_one_rank_group(gpu_device):
 
 
 @pytest.mark.gpu
+def test_channel_capped_communicators_on_rccl(gpu_device):
+    """launcher.channel_groups on the real backend (a one-rank RCCL group is all a single-GPU box offers): every candidate of bench.py's channel-cap
+    selection (RCCL's own choice, 16, 8) must yield a communicator that all-reduces correctly, the Trainer must run its bucket exchange through a capped
+    group bit-identically to the default one, and pick_fastest must return one of the candidates with a time for each."""
+    import torch.distributed as dist
+    from controlvar_amd import models, train as T
+    from controlvar_amd.launcher import channel_groups, pick_fastest
+    from controlvar_amd.synth import synth_images
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(29200 + os.getpid() % 90))
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=gpu_device)
+        created = True
+    try:
+        groups = channel_groups((None, 16, 8))
+        assert list(groups) == [None, 16, 8] and groups[None] is None and groups[16] is not None and groups[8] is not None
+        for c, g in groups.items():
+            x = torch.arange(1 << 20, device=gpu_device, dtype=torch.float32)
+            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=g)
+            torch.cuda.synchronize()
+            assert torch.equal(x, torch.arange(1 << 20, device=gpu_device, dtype=torch.float32)), c
+        images, masks = synth_images(2, 256, seed=6).to(gpu_device), synth_images(2, 256, seed=7).to(gpu_device)
+        cls, types = torch.tensor([17, 403]), torch.tensor([2, 0])
+        kw = dict(peak_lr=2e-3, weight_decay=0.05, sche='lin0', warmup_it=2, max_it=50, clip=2.0, drop_path=False, force_reducer=True)
+        states = []
+        for c in (None, 8):
+            vae = models.build_vae(ch=32, compute_dtype=torch.bfloat16).to(gpu_device)
+            m = models.build_control_var(vae, depth=2, mask_type='interleave_append', multi_cond=True, compute_dtype=torch.bfloat16, cond_drop_rate=0.0).to(gpu_device).eval()
+            tr = T.Trainer(m, vae, **kw)
+            tr.set_comm_group(groups[c])
+            tr.step(images, masks, cls, types); tr.step(images, masks, cls, types)
+            torch.cuda.synchronize()
+            assert tr.engine.reducer.group is groups[c]
+            states.append({k: v.clone() for k, v in m.state_dict().items()})
+        for k in states[0]:
+            assert torch.equal(states[0][k], states[1][k]), k
+        best, table = pick_fastest([None, 16, 8], lambda c: {None: 0.3, 16: 0.1, 8: 0.2}[c], gpu_device)
+        assert best == 16 and list(table) == [None, 16, 8]
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+@pytest.mark.gpu
 def test_optimizer_world_folding_on_device(gpu_device):
     """FusedAdamW.step(world=2) on SUM gradients (= 2x the single-rank gradients, what two identical ranks would all-reduce) must land on
     exactly the parameters of world=1 on the single-rank gradients: the 1/world mean and the clip coefficient are folded in-kernel."""
