@@ -275,6 +275,26 @@ def side_configs(a, dev, box):
 
 
 # ------------------------------------------------------------------------------------------------------------------------- workers
+def sustained_mfma(dev, launches=6, iters=30000):
+    """What the matrix pipes of THIS device sustain in THIS run on a register-fed stream of the product GEMM's MFMA (cvar_probe_mfma_bf16: no memory traffic, two waves
+    per SIMD on every CU): on operands of the bench's kind (randn bf16) and on zeros.  MI355X clocks to its power budget, so the first is the ceiling a GEMM kernel can
+    approach by scheduling alone on this box; the second shows the 2.4 GHz peak is there when nothing toggles.  Runs after the timed region; ~0.3 s."""
+    from controlvar_amd import _lib
+    lib = _lib.load()
+    res = {}
+    for name, ops in (('randn', torch.randn(1 << 17, device=dev).to(torch.bfloat16)), ('zeros', torch.zeros(1 << 17, device=dev, dtype=torch.bfloat16))):
+        st = torch.cuda.current_stream().cuda_stream
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
+        ev[0].record()
+        for i in range(launches):
+            _lib.check(lib.cvar_probe_mfma_bf16(ops.data_ptr(), ops.numel() * 2, iters, None, st), 'cvar_probe_mfma_bf16')
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(launches // 2, launches))       # the later launches: the clock has settled
+        res[name] = lib.cvar_probe_mfma_flops(iters) / (ms[len(ms) // 2] * 1e-3) / 1e12
+    return res
+
+
 def _finish(world):
     if world > 1:
         import torch.distributed as dist
@@ -488,6 +508,16 @@ def main_infer(a):
             flops = sum(r[2] for r in prof)
             ach = flops / (ms * 1e-3) / 1e12
             peak = 2500.0 if a.dtype == 'bf16' else 157.3
+            sustained = {}
+            if a.dtype == 'bf16':
+                try:
+                    sm = sustained_mfma(dev)
+                    sustained = {'sustained_peak': round(sm['randn'], 1), 'frac_of_sustained': round(ach / sm['randn'], 4), 'peak_on_zero_operands': round(sm['zeros'], 1),
+                                 'sustained_note': 'cvar_probe_mfma_bf16 in this run on this device: a register-fed stream of the GEMM\'s MFMA (v_mfma_f32_16x16x32_bf16, two waves '
+                                                   'per SIMD on every CU, no memory traffic) on randn bf16 operands / on zeros - the part clocks to its power budget, so '
+                                                   'sustained_peak is the ceiling a GEMM kernel can approach by scheduling alone; frac stays against the 2.4 GHz peak'}
+                except Exception as e:
+                    sustained = {'sustained_peak': None, 'sustained_note': f'probe failed: {type(e).__name__}: {e}'}
             traffic, tsrc = None, None
             tpath = os.path.join(ROOT, 'profiles', 'gemm_hbm_traffic.json')
             if os.path.exists(tpath):
@@ -508,7 +538,7 @@ def main_infer(a):
             out['roofline'] = {'bound': 'mfma', 'kernel': 'cvar_gemm_kernel + conv3x3_halo_bf16_kernel (every cvar_gemm launch: GEMMs and 3x3 convs)',
                                'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                                'traffic': traffic, 'traffic_source': tsrc, 'launches': len(prof), 'avg_launch_ms': round(ms / len(prof), 4),
-                               'gemm_share_of_step': round(ms * 1e-3 / dt, 3),
+                               'gemm_share_of_step': round(ms * 1e-3 / dt, 3), **sustained,
                                'peak_note': 'dense bf16 MFMA peak at 2.4 GHz; this kernel is power-limited on random operands (the same instruction stream runs '
                                             '~30 % faster on constant operands: profiles/r03_gemm_power.txt), so the clock under load is ~1.85 GHz'}
         prof = None

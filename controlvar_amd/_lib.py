@@ -11,7 +11,7 @@ import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CVAR_LIB') or os.path.join(HERE, 'libcvar_hip.so')      # CVAR_LIB: A/B runs against another build
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 CVAR_F32, CVAR_BF16 = 0, 1
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_GRAD = 0, 1, 2
@@ -97,6 +97,9 @@ SIGNATURES = {
     'cvar_adamw': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_i, c_p, c_f, c_p]),
     'cvar_sumsq': (c_i, [c_p, c_l, c_p, c_p]),
     'cvar_clip_coef': (c_i, [c_p, c_l, c_f, c_f, c_p, c_p]),
+    # measurement aid (bench.py roofline.sustained_*)
+    'cvar_probe_mfma_bf16': (c_i, [c_p, c_l, c_i, c_p, c_p]),
+    'cvar_probe_mfma_flops': (C.c_double, [c_i]),
 }
 
 _lib = None

@@ -710,7 +710,7 @@ extern "C" int cvar_nhwc_to_nchw(const void* in, int dtype, int64_t ld_in, float
     return CVAR_OK;
 }
 
-extern "C" int cvar_abi_version(void) { return 18; }
+extern "C" int cvar_abi_version(void) { return 19; }
 extern "C" const char* cvar_status_str(int status) {
     switch (status) {
         case CVAR_OK: return "ok";

@@ -354,6 +354,15 @@ int cvar_ignore_mask(const float* cond, int B, int H, int W, const int* patch_nu
                      int image_first, float* out, int L, void* stream);
 int cvar_rle_paint(const int* run_ends, const int* ann_offsets, const void* colours, int n_ann, int H, int W, void* out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Measurement aid (ABI 19; bench.py's roofline.sustained_*; replaces nothing in the reference): a register-fed stream of the product GEMM's MFMA
+ * (v_mfma_f32_16x16x32_bf16, 16 independent accumulators per wave, two waves per SIMD on every CU, no memory traffic in the loop) on the caller's
+ * operand values - >= 256 KB of bf16, 16-byte aligned.  MI355X clocks to its power budget, so what this launch reaches on operands of the bench's
+ * kind is the ceiling a GEMM kernel can approach by scheduling alone on that device; on zeros it reaches the 2.4 GHz peak.
+ * cvar_probe_mfma_flops(iters) = flop of one launch. */
+int cvar_probe_mfma_bf16(const void* operands, int64_t operand_bytes, int iters, float* sink, void* stream);
+double cvar_probe_mfma_flops(int iters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -892,3 +892,21 @@ def test_attention_64_queries_per_wave_kernel_equals_the_128_query_kernel_bit_fo
     pr = torch.softmax(s2.masked_fill(~vis, float('-inf')) * math.log(2.0), dim=-1)
     ref = (pr @ vf).permute(0, 2, 1, 3).reshape(2 * l, C)
     assert (out_small.double().cpu() - ref).abs().max().item() < 1.2e-2 * ref.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------ round 5: measurement aid of bench.py (ABI 19)
+def test_mfma_probe_runs_and_validates_its_arguments(gpu_device):
+    """cvar_probe_mfma_bf16 (bench.py's roofline.sustained_peak): refuses short / misaligned operand buffers, and a launch on zeros is not slower than one on
+    random operands (the part clocks to its power budget) while both stay below the 2.5 PFLOP/s peak"""
+    import bench
+    from controlvar_amd import _lib
+    lib = _lib.load()
+    ops_t = torch.zeros(1 << 17, device=gpu_device, dtype=torch.bfloat16)
+    assert lib.cvar_probe_mfma_bf16(None, ops_t.numel() * 2, 10, None, None) == -1
+    assert lib.cvar_probe_mfma_bf16(ops_t.data_ptr(), 1024, 10, None, None) == -1
+    assert lib.cvar_probe_mfma_bf16(ops_t.data_ptr() + 2, ops_t.numel() * 2 - 2, 10, None, None) == -1
+    assert lib.cvar_probe_mfma_bf16(ops_t.data_ptr(), ops_t.numel() * 2, 0, None, None) == -1
+    with torch.cuda.device(gpu_device):
+        r = bench.sustained_mfma(gpu_device, launches=4, iters=8000)
+    assert 300.0 < r['randn'] < 2600.0 and 300.0 < r['zeros'] < 2600.0, r
+    assert r['zeros'] > 0.97 * r['randn'], r
