@@ -284,14 +284,16 @@ def sustained_mfma(dev, launches=6, iters=30000):
     res = {}
     for name, ops in (('randn', torch.randn(1 << 17, device=dev).to(torch.bfloat16)), ('zeros', torch.zeros(1 << 17, device=dev, dtype=torch.bfloat16))):
         st = torch.cuda.current_stream().cuda_stream
+        sink = torch.zeros(2, device=dev)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
         ev[0].record()
         for i in range(launches):
-            _lib.check(lib.cvar_probe_mfma_bf16(ops.data_ptr(), ops.numel() * 2, iters, None, st), 'cvar_probe_mfma_bf16')
+            _lib.check(lib.cvar_probe_mfma_bf16(ops.data_ptr(), ops.numel() * 2, iters, sink.data_ptr(), st), 'cvar_probe_mfma_bf16')
             ev[i + 1].record()
         torch.cuda.synchronize()
         ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(launches // 2, launches))       # the later launches: the clock has settled
         res[name] = lib.cvar_probe_mfma_flops(iters) / (ms[len(ms) // 2] * 1e-3) / 1e12
+        res[name + '_ghz'] = float(sink[1]) / (ms[len(ms) // 2] * 1e-3) / 1e9          # shader cycles of a wave's loop / wall time of the launch
     return res
 
 
@@ -513,6 +515,7 @@ def main_infer(a):
                 try:
                     sm = sustained_mfma(dev)
                     sustained = {'sustained_peak': round(sm['randn'], 1), 'frac_of_sustained': round(ach / sm['randn'], 4), 'peak_on_zero_operands': round(sm['zeros'], 1),
+                                 'clock_ghz_randn_zeros': [round(sm['randn_ghz'], 2), round(sm['zeros_ghz'], 2)],
                                  'sustained_note': 'cvar_probe_mfma_bf16 in this run on this device: a register-fed stream of the GEMM\'s MFMA (v_mfma_f32_16x16x32_bf16, two waves '
                                                    'per SIMD on every CU, no memory traffic) on randn bf16 operands / on zeros - the part clocks to its power budget, so '
                                                    'sustained_peak is the ceiling a GEMM kernel can approach by scheduling alone; frac stays against the 2.4 GHz peak'}

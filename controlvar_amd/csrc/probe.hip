@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void probe_mfma_bf16_kernel(const pb_bf16x8_t*
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = pb_f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int k = 0; k < 2; ++k)
@@ -37,16 +38,18 @@ __global__ __launch_bounds__(256) void probe_mfma_bf16_kernel(const pb_bf16x8_t*
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[k][i], b[k][j], acc[i][j], 0, 0, 0);
     }
+    const long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     if (s == 12345.678f && sink) sink[0] = s;                            // keeps the accumulators alive; practically never true
+    if (sink && blockIdx.x == 0 && threadIdx.x == 0) sink[1] = (float)(t1 - t0);     // shader cycles of one wave's loop: cycles / wall time = the clock the launch ran at
 }
 
 // operands: >= 16 * 16 * 64 * 16 B = 256 KB of bf16 values (the caller chooses them: the bench's randn, zeros, ...).  Launches 256 CUs x 2 workgroups of 4 waves
-// (two waves per SIMD, as the product GEMM runs).  flop of the launch = cvar_probe_mfma_flops(iters).
+// (two waves per SIMD, as the product GEMM runs).  flop of the launch = cvar_probe_mfma_flops(iters).  sink (optional, 2 floats): [1] = shader cycles of one wave's loop.
 extern "C" int cvar_probe_mfma_bf16(const void* operands, int64_t operand_bytes, int iters, float* sink, void* stream) {
     if (!operands || operand_bytes < 16 * 16 * 64 * 16 || iters <= 0) return CVAR_EINVAL;
     if ((uintptr_t)operands & 15) return CVAR_EINVAL;
