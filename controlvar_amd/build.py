@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'csrc', 'build')
 LIB = os.path.join(HERE, 'libcvar_hip.so')
-SOURCES = ['gemm.hip', 'gemm_conv.hip', 'gemm_f32.hip', 'gemm_skinny.hip', 'conv_halo.hip', 'gemm_tn.hip', 'ops.hip', 'attn.hip', 'sample.hip', 'msq.hip', 'train.hip', 'preproc.hip', 'probe.hip']
+SOURCES = ['gemm.hip', 'gemm_conv.hip', 'gemm_f32.hip', 'gemm_skinny.hip', 'conv_halo.hip', 'conv_c8.hip', 'gemm_tn.hip', 'ops.hip', 'attn.hip', 'sample.hip', 'msq.hip', 'train.hip', 'preproc.hip', 'probe.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wno-unused-result']
 # per-source extras.  attn.hip: keep MFMA results in VGPRs - the softmax consumes every score with vector ALU ops, and the AGPR form
 # costs one v_accvgpr_read per score and tile (plus writes for the rescale)

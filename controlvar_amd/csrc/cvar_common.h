@@ -103,3 +103,5 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // conv_halo.hip: 3x3 stride-1 NHWC bf16 conv with the input tile + halo resident in LDS (dispatched from cvar_gemm; not part of the C ABI)
 int cvar_conv3x3_halo_bf16(const void* X, const void* Wt, const float* bias, const void* residual, void* out, int out_f32, int B, int H, int W, int Cin,
                            int Cout, int up, float* gn_part, hipStream_t st);
+// conv_c8.hip: the same for an image of <= 8 (padded) input channels into 160-multiples of couts - the VQVAE encoder's conv_in (dispatched from cvar_gemm)
+int cvar_conv3x3_c8_bf16(const void* X, const void* Wt, const float* bias, void* out, int B, int H, int W, int Cout, float* gn_part, hipStream_t st);

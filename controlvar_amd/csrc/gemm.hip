@@ -1129,7 +1129,13 @@ __global__ __launch_bounds__(256) void cvar_splitk_epilogue_kernel(const float* 
 // Does a stride-1 3x3 bf16 conv of this shape emit GroupNorm partials of its output when cvar_gemm_desc.gn_part is set (the wide LDS-halo kernel, chosen
 // by shape alone; operands must be 16-byte aligned and dense: ldc == N, ldw == 9 Cin, ldr == N)?  Returns 1 and the partial geometry, else 0.
 extern "C" int cvar_conv3x3_gn_partials(int dtype, int stride, int Cin, int Cout, int Hin, int Win, int Hout, int Wout, int* tiles_per_image, int* pixels_per_tile) {
-    const bool ok = dtype == CVAR_BF16 && stride == 1 && Cin > 0 && Cin % 32 == 0 && Cout > 0 && Cout % 160 == 0 && Hout > 0 && Wout > 0 && Hout % 16 == 0 && Wout % 16 == 0 &&
+    // (Cin == 8: the image conv of conv_c8.hip - same tile geometry and partial format; it has no upsampled form)
+#ifndef CVAR_NO_CONV_C8
+    const bool c8 = Cin == 8 && Hin == Hout && Win == Wout;
+#else
+    const bool c8 = false;
+#endif
+    const bool ok = dtype == CVAR_BF16 && stride == 1 && Cin > 0 && (Cin % 32 == 0 || c8) && Cout > 0 && Cout % 160 == 0 && Hout > 0 && Wout > 0 && Hout % 16 == 0 && Wout % 16 == 0 &&
                     (long)Hin * Win * Cin * 2 < 0x7fffffffL && (long)Hout * Wout * Cout < 0x7fffffffL;
     if (!ok) return 0;
     if (tiles_per_image) *tiles_per_image = (Hout / 16) * (Wout / 16);
@@ -1281,6 +1287,15 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
             return finish_slices(splits);
         }
     }
+    // the image conv (Cin = 3 padded to 8, 160-multiples of couts: the encoder's conv_in): conv_c8.hip - K = 72 is two half-empty K tiles of gathered 16-byte pieces on the
+    // implicit-GEMM tiles (1.9 TB/s of output), and only the LDS-tile kernels emit GroupNorm partials.  Chosen by shape alone (an image's bits do not depend on its batch).
+#ifndef CVAR_NO_CONV_C8          // (A/B builds: tools/build_variant.py gemm.hip noc8 -DCVAR_NO_CONV_C8 keeps conv_in on the implicit-GEMM tiles)
+    if (d->conv && d->dtype == CVAR_BF16 && d->stride == 1 && !d->up && d->batch == 1 && (d->tile_cfg == 0 || d->tile_cfg == 6) && d->Cin == 8 && d->N % 160 == 0 &&
+        d->Hout % 16 == 0 && d->Wout % 16 == 0 && d->act == CVAR_ACT_NONE && !d->gate && d->alpha == 1.0f && !d->residual && !d->pre_act && !d->aux && !d->gate_scale &&
+        d->remap_l == 0 && d->split_n == 0 && d->strideC == 0 && d->ldc == d->N && d->ldw == d->K && d->out_dtype == CVAR_BF16 &&
+        ((((uintptr_t)d->C | (uintptr_t)d->bias) & 15) == 0) && (long)d->Hout * d->Wout * d->N < 0x7fffffffL)
+        return cvar_conv3x3_c8_bf16(d->A, d->W, d->bias, d->C, d->M / (d->Hout * d->Wout), d->Hout, d->Wout, d->N, d->gn_part, st);
+#endif
     // stride-1 3x3 convs (plain or behind the nearest x2 upsample) over 32-channel multiples with 160-multiple outputs on 16-multiple images (every ResnetBlock conv of the VQVAE
     // decoder from 16x16 up): the LDS-halo kernel (conv_halo.hip).  tile_cfg 5 keeps them on the implicit-GEMM tiles, 6 forces the halo kernel at any grid size (A/B runs, tests).
     if (d->conv && d->dtype == CVAR_BF16 && d->stride == 1 && d->batch == 1 && (d->tile_cfg == 0 || d->tile_cfg == 6 || d->tile_cfg == 9 || d->tile_cfg == 10) &&

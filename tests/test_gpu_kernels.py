@@ -656,6 +656,59 @@ def test_vqvae_with_conv_epilogue_statistics_is_as_close_to_fp32_as_without(gpu_
     assert g_on <= 1.25 * g_off + 1e-3 * fc.abs().mean().item()
 
 
+# ------------------------------------------------------------------------------------------------ round 5: the image conv (conv_c8.hip: 3 channels padded to 8 -> 160-multiples)
+@pytest.mark.parametrize('B,H,W,cout,big_mean', [(3, 32, 48, 160, False), (2, 16, 16, 320, False), (1, 64, 32, 160, True)])
+def test_conv3x3_image_kernel_against_torch_the_implicit_gemm_and_its_groupnorm_partials(gpu_device, B, H, W, cout, big_mean):
+    """conv_c8.hip (what cvar_gemm picks for Cin = 8, Cout % 160 == 0) against torch's fp32 conv2d of the bf16-rounded operands and against the implicit-GEMM tiles
+    (tile_cfg 5); NaN images in front of and behind the batch (a tap that leaves its image must read zeros), nothing written behind the output; its GroupNorm partials
+    per tile against float64 sums of the values it stored, and the GroupNorm from them against the stand-alone statistics pass."""
+    T = torch.bfloat16
+    g = torch.Generator().manual_seed(B * 100 + H + cout)
+    xs = torch.zeros(B + 2, H, W, 8)
+    xs[..., :3] = torch.randn(B + 2, H, W, 3, generator=g)
+    xs[0] = float('nan'); xs[-1] = float('nan')
+    buf = xs.to(T).to(gpu_device)
+    x = buf[1:B + 1].reshape(-1, 8)
+    w = torch.zeros(cout, 3, 3, 8)
+    w[..., :3] = torch.randn(cout, 3, 3, 3, generator=g) / 27 ** 0.5 * (0.02 if big_mean else 1.0)
+    w = w.to(T)
+    bias = torch.randn(cout, generator=g) * (40.0 if big_mean else 1.0)
+    ref = F.conv2d(x.float().cpu().view(B, H, W, 8).permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1).reshape(B * H * W, cout)
+    geo = ops.conv_gn_partials(T, 1, 8, cout, H, W, H, W)
+    assert geo == ((H // 16) * (W // 16), 256)
+    outs = {}
+    for cfg in (0, 5):
+        out = torch.full((B * H * W + 64, cout), float('nan'), device=gpu_device, dtype=T)
+        part = torch.full((B, geo[0], cout, 3), float('nan'), device=gpu_device) if cfg == 0 else None
+        part0 = part if cfg == 0 else part0
+        ops.GEMM_TILE_CFG = cfg
+        try:
+            ops.gemm(x, w.reshape(cout, 72).to(gpu_device), out, M=B * H * W, N=cout, K=72, bias=bias.to(gpu_device),
+                     conv=dict(Hin=H, Win=W, Cin=8, Hout=H, Wout=W), gn_part=part)
+        finally:
+            ops.GEMM_TILE_CFG = 0
+        assert torch.isnan(out[B * H * W:].float()).all()
+        outs[cfg] = out[:B * H * W]
+        assert torch.isfinite(outs[cfg].float()).all()
+        assert close(outs[cfg], ref, T, bf16_rel=1e-2), (cfg, (outs[cfg].float().cpu() - ref).abs().max().item())
+        if cfg == 0:
+            pc = part.double().cpu()
+            assert torch.isfinite(pc).all()
+    assert ((outs[0].float() - outs[5].float()).abs().cpu() <= 2.0 ** -7 * (ref.abs() + 1)).all()
+    out = outs[0].contiguous()
+    y = out.double().cpu().view(B, H // 16, 16, W // 16, 16, cout).permute(0, 1, 3, 2, 4, 5).reshape(B, geo[0], 256, cout)
+    piv = pc[..., 2].unsqueeze(2)
+    assert ((y - piv).abs().amin(dim=2) == 0).all()
+    S, Q = (y - piv).sum(2), ((y - piv) ** 2).sum(2)
+    assert (pc[..., 0] - S).abs().max() <= 1e-4 * (S.abs().max() + 1) and (pc[..., 1] - Q).abs().max() <= 1e-4 * (Q.abs().max() + 1)
+    gw, gb = (1 + 0.1 * torch.randn(cout, generator=g)).to(gpu_device), (0.1 * torch.randn(cout, generator=g)).to(gpu_device)
+    ws = torch.empty(ops.groupnorm_ws_bytes(B, H * W, cout), device=gpu_device, dtype=torch.uint8)
+    a = ops.groupnorm_silu_partials(out, gw, gb, torch.empty_like(out), B, H * W, cout, 32, 1e-6, True, part0, geo[0], geo[1], ws)
+    b_ = ops.groupnorm_silu(out, gw, gb, torch.empty_like(out), B, H * W, cout, 32, 1e-6, True, ws)
+    d = (a.float() - b_.float()).abs()
+    assert (d <= 2.0 ** -7 * (b_.float().abs() + 1)).all() and (d > 0).float().mean().item() < 0.02
+
+
 # ------------------------------------------------------------------------------------------------ round 3: prescaled queries (ABI 14)
 @pytest.mark.parametrize('H,Lmax,q_off,l,levels,holes', [
     (2, 1360, 848, 512, None, None),                       # last scale of the pyramid: 4 query blocks, 22 KV tiles
