@@ -275,10 +275,10 @@ def side_configs(a, dev, box):
 
 
 # ------------------------------------------------------------------------------------------------------------------------- workers
-def sustained_mfma(dev, launches=6, iters=30000):
+def sustained_mfma(dev, launches=8, iters=6000):
     """What the matrix pipes of THIS device sustain in THIS run on a register-fed stream of the product GEMM's MFMA (cvar_probe_mfma_bf16: no memory traffic, two waves
     per SIMD on every CU): on operands of the bench's kind (randn bf16) and on zeros.  MI355X clocks to its power budget, so the first is the ceiling a GEMM kernel can
-    approach by scheduling alone on this box; the second shows the 2.4 GHz peak is there when nothing toggles.  Runs after the timed region; ~0.3 s."""
+    approach by scheduling alone on this box; the second shows the 2.4 GHz peak is there when nothing toggles.  Runs after the timed region: 2 x 8 launches of ~4 ms (the clock settles within the first), the median of the last four counts."""
     from controlvar_amd import _lib
     lib = _lib.load()
     res = {}
