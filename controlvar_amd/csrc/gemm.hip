@@ -335,6 +335,13 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
 #ifndef CVAR_GEMM_C128
 #define CVAR_GEMM_C128 0.61
 #endif
+// the 256x192 tile in the partial-round rule (launch_typed): on / off, and the cost of one of its rounds against a 256x256 round
+#ifndef CVAR_GEMM_T192
+#define CVAR_GEMM_T192 1
+#endif
+#ifndef CVAR_GEMM_C192
+#define CVAR_GEMM_C192 0.88
+#endif
     // M16: the K loop runs on v_mfma_f32_16x16x32_bf16 (two per 32x32x16's worth of flops, 16 cycles each).  Same fragment bytes out of LDS,
     // but an accumulator register is read and written once per 32 k instead of once per 16: the chip is POWER-limited under this kernel
     // (all-zero operands run the identical instruction stream 30 % faster, profiles/r03_gemm_power.txt) and the narrower tile moves less
@@ -460,7 +467,13 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
                             else if (s32 == 0) rd_a(1, in - MI16);
                             else if (XB) rd_a_next(in - MI16);               // fragments 0, 1 of the next tile (m >= XB_PM: behind the barrier)
                         }
-                        if (s32 == 0 && j == 2 && i >= MI16 - NJ16) rd_b(1, i - (MI16 - NJ16));     // next k-step's W fragments, one per A fragment
+                        if constexpr (NJ16 <= MI16) {
+                            if (s32 == 0 && j == 2 && i >= MI16 - NJ16) rd_b(1, i - (MI16 - NJ16));     // next k-step's W fragments, one per A fragment
+                        } else {                                                                        // more W than A fragments (64x96 wave tile): up to two per A fragment
+                            static_assert(NJ16 <= 2 * MI16 && NJ16 >= 5, "W fragment schedule");
+                            if (s32 == 0 && j == 2) rd_b(1, i);
+                            if (s32 == 0 && j == 4 && MI16 + i < NJ16) rd_b(1, MI16 + i);
+                        }
                         if constexpr (XB) {
                             // W fragments of the next tile's first k-step: one per MFMA behind the barrier (bw[0] is dead since k-step 0 ended)
                             if (m >= XB_PM && j != 0) {
@@ -700,6 +713,10 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
                 const int i = ih >> 1, half = ih & 1, bsel = ih & 1;
                 if constexpr (gate || res != 0 || act == CVAR_ACT_GELU_GRAD) { if (ih + 1 < 2 * MI) fetch_operands(ih + 1); }
                 stage_block(i, half);
+                // 16x16-block staging with idle lanes in the row-major phase (LPR does not divide 64, e.g. the 64x96 wave tile): an idle lane never reads the staging
+                // region itself, so from ITS point of view every staging store but the last is dead and the compiler predicates them on lane_on - but the
+                // other lanes of the wave read those bytes.  A compiler-level memory clobber keeps the stores (no instruction; only these instantiations).
+                if constexpr (M16 && (64 % LPR) != 0) asm volatile("" ::: "memory");
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) {
                     const int roff = i * 32 + 16 * half + ps * RPP;          // wave-uniform, known at compile time
@@ -795,6 +812,7 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
         const unsigned long long te0 = __builtin_amdgcn_s_memtime();
 #endif
         stage_block(i, half);
+        if constexpr (M16 && (64 % LPR) != 0) asm volatile("" ::: "memory");          // see the specialised loop above
 #ifdef CVAR_GEMM_TIMING
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned long long te1 = __builtin_amdgcn_s_memtime();
@@ -1053,6 +1071,11 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
         }
         return launch_cfg<T, 128, 160, 4, 1>(p, batch, st);
     }
+#if CVAR_TU_PLAIN && !CVAR_TU_CONV
+    if constexpr (sizeof(T) == 2) {
+        if (p.tile_cfg == 27 && !p.conv && p.split_tiles == 0) return launch_cfg<T, 256, 192, 4, 2>(p, batch, st);
+    }
+#endif
     // large streaming GEMMs: 256x256 tile - halves the operand bytes per flop and doubles the MFMA work per barrier; measured
     // +10..15 % over 128x128 on the d24 shapes.  tile_cfg 1 forces the 128x128 tile, 2 the 8-wave tile everywhere (A/B runs).
     const int ov = gemm_cfg_override(p);
@@ -1076,6 +1099,21 @@ static int launch_typed(const GemmParams& p, int batch, hipStream_t st) {
     if (ov == -1 && sizeof(T) == 2 && p.split_tiles == 0 && batch == 1 && n_ok && p.M >= 2048) {
         const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256), t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
         const double c256 = (double)((t256 + 255) / 256), c128 = CVAR_GEMM_C128 * (double)((t128 + 511) / 512);
+#if CVAR_TU_PLAIN && !CVAR_TU_CONV
+        // Round 5: a 256x192 tile (8 waves as 4 x 2, 64x96 per wave) for the launches whose 256x256 tiles fill their last round badly - the mid batches (B = 8 ... 32:
+        // M = 2 048 ... 12 800 rows per scale).  Per flop it is 9-26 % slower than the 256x256 tile (M = 21 632: 1 172 / 1 148 / 1 022 / 1 038 against 1 285 / 1 313 /
+        // 1 384 / 1 269 TFLOP/s for qkv / fc1 / fc2 / proj), i.e. a round of it costs ~0.88 of a 256x256 round instead of 0.75; it wins where it saves a round or fills
+        // one that was half empty: M = 8 192 qkv 108 -> 101 us, M = 5 408 fc1 110 -> 98, fc2 113 -> 98, M = 12 800 fc2 247 -> 204 us (tools/tile_probe.py,
+        // profiles/r05_gemm_tile_192.txt).  Same K order per output: bit-identical to the other tiles.  tile_cfg 27 forces it (A/B runs, tests).
+        if constexpr (sizeof(T) == 2) {
+            if (CVAR_GEMM_T192 && !p.conv && p.N % 192 == 0) {
+                const long t192 = (long)((p.M + 255) / 256) * (p.N / 192);
+                const double c192 = CVAR_GEMM_C192 * (double)((t192 + 255) / 256);
+                // (5 % margin against the 256x256 plan only: the 0.61 per round of 128x128 tiles is optimistic where they need a third round - M = 3 200 fc1: 73 us against 61)
+                if (c192 < 0.95 * c256 && c192 < c128) return launch_cfg<T, 256, 192, 4, 2>(p, batch, st);
+            }
+        }
+#endif
         if (c128 < 0.97 * c256) {
 #if CVAR_TU_PLAIN && !CVAR_TU_CONV
             // one round of at most 256 workgroups in a transformer pass: three LDS stages (see cvar_gemm: a workgroup of this regime is latency-bound)

@@ -963,3 +963,53 @@ def test_mfma_probe_runs_and_validates_its_arguments(gpu_device):
         r = bench.sustained_mfma(gpu_device, launches=4, iters=8000)
     assert 300.0 < r['randn'] < 2600.0 and 300.0 < r['zeros'] < 2600.0, r
     assert r['zeros'] > 0.97 * r['randn'], r
+
+
+# ------------------------------------------------------------------------------------------------ round 5: the 256x192 tile of the partial-round rule
+@pytest.mark.parametrize('M,N,K', [(2048, 4608, 1536), (777, 384, 128), (5408, 1536, 6144), (3000, 1920, 1536)])
+def test_gemm_256x192_tile_every_hot_epilogue_bit_identical_to_the_256x256_tile(gpu_device, M, N, K):
+    """cvar_gemm's 256x192 tile (tile_cfg 27 forces it; the automatic plan takes it where 256x256 tiles fill their last round badly): plain bf16, bias + GELU,
+    fp32 gate + residual in place, K/V-arena row remap with the q split - against torch fp32 of the bf16 operands and bit for bit against the forced 256x256 tile
+    (same K order per output).  Its wave tile is 64x96: 12 lanes per output row, so four lanes of every wave idle in the row-major epilogue - the case that needs the
+    staging stores kept alive (gemm.hip)."""
+    T = torch.bfloat16
+    A, W, b = rnd(M, K, seed=M), rnd(N, K, seed=N) / K ** 0.5, rnd(N, seed=3)
+    Ad, Wd, bd = to_dev(A, T, gpu_device), to_dev(W, T, gpu_device), b.to(gpu_device)
+    ref = Ad.float().cpu() @ Wd.float().cpu().t() + b
+    gate = rnd((M + 255) // 256, N, seed=5).to(gpu_device)
+    res0 = rnd(M, N, seed=6)
+    l = 64
+    R, L, off = (M + l - 1) // l, 200, 17
+
+    def run(cfg, kind):
+        ops.GEMM_TILE_CFG = cfg
+        try:
+            if kind == 'plain':
+                out = torch.full((M + 8, N), float('nan'), device=gpu_device, dtype=T)
+                ops.gemm(Ad, Wd, out, M=M, N=N, K=K, bias=bd)
+                assert torch.isnan(out[M:].float()).all()
+                return out[:M]
+            if kind == 'gelu':
+                out = torch.empty(M, N, device=gpu_device, dtype=T)
+                ops.gemm(Ad, Wd, out, M=M, N=N, K=K, bias=bd, act=ACT_GELU_TANH)
+                return out
+            if kind == 'gate':
+                out = res0.to(gpu_device).clone()
+                ops.gemm(Ad, Wd, out, M=M, N=N, K=K, bias=bd, gate=gate, ldg=N, gate_rows=256, residual=out)
+                return out
+            out = torch.zeros(R * L, N, device=gpu_device, dtype=T)
+            ops.gemm(Ad, Wd, out, M=M, N=N, K=K, bias=bd, remap=(l, L, off))
+            return out
+        finally:
+            ops.GEMM_TILE_CFG = 0
+
+    for kind in ('plain', 'gelu', 'gate', 'remap'):
+        a, b2 = run(27, kind), run(2, kind)
+        assert torch.equal(a, b2), kind
+        if kind == 'plain':
+            assert close(a, ref, T)
+        elif kind == 'gelu':
+            assert close(a, F.gelu(ref, approximate='tanh'), T)
+        elif kind == 'gate':
+            want = res0 + gate.cpu().repeat_interleave(256, 0)[:M] * ref
+            assert ((a.cpu() - want).abs() <= 1e-2 * (want.abs() + 1)).all()
