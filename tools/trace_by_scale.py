@@ -5,7 +5,7 @@ usage: trace_by_scale.py <kernel_trace.csv> [generation index, default last]"""
 import csv, sys, collections
 
 FAM = [('gemm128', 'cvar_gemm_kernel<unsigned short, 128, 128'), ('gemm64', 'cvar_gemm_kernel<unsigned short, 64, 128'),
-       ('gemm256', 'cvar_gemm_kernel<unsigned short, 256, 256'), ('gemmskinny', 'skinny'), ('splitk_epi', 'cvar_splitk_epilogue'), ('rowfin', 'rowfin'),
+       ('gemm256', 'cvar_gemm_kernel<unsigned short, 256, 256'), ('gemm192', 'cvar_gemm_kernel<unsigned short, 256, 192'), ('gemmskinny', 'skinny'), ('splitk_epi', 'cvar_splitk_epilogue'), ('rowfin', 'rowfin'),
        ('attn', 'attn_'), ('ln_mod', 'ln_modulate'), ('conv_halo', 'conv3x3_halo'), ('gemm_conv', 'cvar_gemm_kernel'), ('gn', 'gn_'),
        ('sampler', 'cfg_sample'), ('msq', 'ms_'), ('word_embed', 'word_embed')]
 
