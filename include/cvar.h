@@ -85,6 +85,8 @@ typedef struct {
      *                 (which also gives mid-size calls - 64 < M <= 1024, or one round of 128x128 tiles - the three-LDS-stage tile instance);
      *                 13 / 14: the 128x128 tile with three / four LDS stages wherever that tile is chosen (A/B measurements); 26: the 128x128 tile on four
      *                 waves instead of eight (the form before the second half of round 4; A/B measurements, bit-identical);
+     *                 27: the 256x192 tile (round 5) on every unsliced plain bf16 call - automatic plans (0 / 12) take it for launches whose 256x256 tiles would
+     *                 fill their last round of the chip badly (N % 192 == 0, M >= 2048); bit-identical to the other tiles;
      *   stagger       > 0: the first workgroup of every CU starts delayed by up to this many shader cycles (by its index), which
      *                 de-phases the output bursts of equally long tiles; 0: off.  Never changes results. */
     void* ws; int64_t ws_bytes;
