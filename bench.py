@@ -48,6 +48,7 @@ def parse(argv=None):
     ap.add_argument('--top_k', type=int, default=900)      # the reference's sampling defaults (train_control_var_hpu.py:338)
     ap.add_argument('--top_p', type=float, default=0.96)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--decode-chunk', type=int, default=0, help='images per VQVAE decoder pass (0 = the model default); A/B knob')
     ap.add_argument('--cpu-depth', type=int, default=0, help='depth of the CPU baseline model (0 = same as --depth)')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
@@ -459,6 +460,8 @@ def main_infer(a):
     T = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
     t_build = time.time()
     vae = models.build_vae(ch=160, compute_dtype=T).to(dev)
+    if a.decode_chunk > 0:
+        vae.decode_chunk = a.decode_chunk
     var = models.build_control_var(vae, depth=a.depth, mask_type='interleave_append', multi_cond=True, compute_dtype=T).to(dev).eval()
     B = a.batch or (512 if a.depth <= 24 else 128)       # round 4: 384 -> 512 (+1.0 % on one box: 195.4 -> 197.3 images/s; 576: 198.1 at 254 GB - not taken)
     g = torch.Generator().manual_seed(1234 + rank)

@@ -80,7 +80,7 @@ class VQVAE(nn.Module):
 
     def __init__(self, vocab_size=4096, z_channels=32, ch=128, dropout=0.0, beta=0.25, using_znorm=False, quant_conv_ks=3,
                  quant_resi=0.5, share_quant_resi=4, default_qresi_counts=0, v_patch_nums=DEFAULT_PATCH_NUMS, test_mode=True,
-                 compute_dtype=torch.bfloat16, init_seed: int = 0, decode_chunk: int = 64):
+                 compute_dtype=torch.bfloat16, init_seed: int = 0, decode_chunk: int = 128):
         super().__init__()
         if using_znorm or quant_conv_ks != 3 or abs(quant_resi - 0.5) > 1e-9 or share_quant_resi != 4 or dropout != 0.0:
             raise NotImplementedError('only the shipped VQVAE configuration (vqvae.py:18-27 defaults, share_quant_resi=4) is built')
@@ -91,6 +91,8 @@ class VQVAE(nn.Module):
         self.Cvae = z_channels
         self.downsample = 2 ** (len(self.cfg.ch_mult) - 1)
         self.compute_dtype = _compute_dtype(compute_dtype)
+        # images per decoder pass (an image's bits do not depend on it).  128 since round 5: VQVAE round trip 1 355 -> 1 373-1 379 images/s, headline +0.4 % at the
+        # same 226 GB peak (64 / 128 / 256: 201.5 / 202.3 / 202.0 images/s on one box)
         self.decode_chunk = decode_chunk
         _register_tree(self, vae_state_shapes(self.cfg), synth_vae_state(self.cfg, init_seed), requires_grad=not test_mode)
         self._packed = None

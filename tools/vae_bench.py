@@ -8,7 +8,7 @@ from controlvar_amd.synth import synth_images
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 dev = torch.device('cuda:0')
 models.VQVAE.GN_FROM_CONV = os.environ.get('GN_FROM_CONV', '1') != '0'          # A/B: GroupNorm statistics from the conv epilogue (round 5) or the stand-alone pass
-vae = models.build_vae(ch=160, decode_chunk=64).to(dev)
+vae = models.build_vae(ch=160, decode_chunk=int(os.environ.get('DECODE_CHUNK', '128'))).to(dev)          # images per decoder pass
 img = synth_images(B, 256, seed=3).to(dev)
 def step():
     CH = int(os.environ.get('VAE_CHUNK', '128'))          # images per encode + quantise call (round 4: 128, was 64; the decoder chunks by itself)
