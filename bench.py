@@ -51,6 +51,7 @@ def parse(argv=None):
     ap.add_argument('--decode-chunk', type=int, default=0, help='images per VQVAE decoder pass (0 = the model default); A/B knob')
     ap.add_argument('--cpu-depth', type=int, default=0, help='depth of the CPU baseline model (0 = same as --depth)')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-telemetry', action='store_true', help='do not sample socket power / gfx clock (AMD SMI) beside the timed region and the MFMA probe')
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                     help="infer (default, the BASELINE headline metric) | train: BASELINE config 3 - the d24 data-parallel training step, gradient "
                          "all-reduce over RCCL overlapped with the backward; reports samples/s and the exposed communication share")
@@ -61,6 +62,9 @@ def parse(argv=None):
                                                             'repetitions each, median) instead of the bounded default (B=1, short warm-up, up to 3 repetitions in ~35 s)')
     ap.add_argument('--comm-channels', default='auto', help="--mode train, N > 1: RCCL channel cap of the gradient all-reduce - 'auto' (default): try RCCL's own "
                                                             "choice, 16 and 8 for two steps each during warm-up and keep the fastest; or one value ('default', 16, 8, ...)")
+    ap.add_argument('--share-gpu', action='store_true', help='--mode train, N > 1 on a box with fewer GPUs than ranks: the ranks share the visible device(s) round-robin and exchange their gradient '
+                                                             'slabs over gloo (RCCL refuses two ranks on one device).  Not a scaling number - it is the real two-rank step (hand-written backward + BucketReducer + '
+                                                             '1/world folding) on the only hardware a one-GPU lease offers; the line says so in config.parallelism')
     ap.add_argument('--stub-comm-ms', default='', help=argparse.SUPPRESS)                    # stub only: comma list of the fake step time of each channel candidate
     ap.add_argument('--stub-step-ms', type=float, default=0.0, help=argparse.SUPPRESS)      # tests/test_bench_launch.py: the launch / timing / JSON logic on
     return ap.parse_args(argv)                                                               # CPU ranks (gloo) with a sleeping step instead of the model
@@ -276,7 +280,7 @@ def side_configs(a, dev, box):
 
 
 # ------------------------------------------------------------------------------------------------------------------------- workers
-def sustained_mfma(dev, launches=8, iters=6000):
+def sustained_mfma(dev, launches=8, iters=6000, telemetry_s=1.5):
     """What the matrix pipes of THIS device sustain in THIS run on a register-fed stream of the product GEMM's MFMA (cvar_probe_mfma_bf16: no memory traffic, two waves
     per SIMD on every CU): on operands of the bench's kind (randn bf16) and on zeros.  MI355X clocks to its power budget, so the first is the ceiling a GEMM kernel can
     approach by scheduling alone on this box; the second shows the 2.4 GHz peak is there when nothing toggles.  Runs after the timed region: 2 x 8 launches of ~4 ms (the clock settles within the first), the median of the last four counts."""
@@ -295,7 +299,34 @@ def sustained_mfma(dev, launches=8, iters=6000):
         ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(launches // 2, launches))       # the later launches: the clock has settled
         res[name] = lib.cvar_probe_mfma_flops(iters) / (ms[len(ms) // 2] * 1e-3) / 1e12
         res[name + '_ghz'] = float(sink[1]) / (ms[len(ms) // 2] * 1e-3) / 1e9          # shader cycles of a wave's loop / wall time of the launch
+        if telemetry_s > 0:
+            # the same stream for ~telemetry_s seconds under the board sampler: socket power and gfx clock the firmware grants THIS instruction stream on THESE operands
+            from controlvar_amd.telemetry import BoardSampler
+            n = max(8, int(telemetry_s / (ms[len(ms) // 2] * 1e-3)))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            with BoardSampler(dev.index or 0) as bs:
+                e0.record()
+                for i in range(n):
+                    _lib.check(lib.cvar_probe_mfma_bf16(ops.data_ptr(), ops.numel() * 2, iters, sink.data_ptr(), st), 'cvar_probe_mfma_bf16')
+                e1.record()
+                torch.cuda.synchronize()
+            tel = bs.summary(skip_first_s=0.3)
+            tel['tflops'] = round(n * lib.cvar_probe_mfma_flops(iters) / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+            res[name + '_telemetry'] = tel
     return res
+
+
+def _board_keys(board, probe):
+    """roofline.power_w / power_cap_w / sclk_mhz (+ the same for the MFMA probe): the board's own account of the timed region (controlvar_amd/telemetry.py)"""
+    if board is None:
+        return {}
+    t = board.summary(skip_first_s=0.3)
+    out = {'power_w': t.get('power_w'), 'power_cap_w': t.get('power_cap_w'), 'sclk_mhz': t.get('sclk_mhz'), 'telemetry': t}
+    if probe:
+        out['telemetry_probe'] = probe
+        out['telemetry_note'] = ('AMD SMI gpu_metrics sampled every 20 ms by a thread of this process over the timed region (telemetry) and over ~1.5 s of the MFMA probe on randn / zero '
+                                 'operands (telemetry_probe): socket power against the cap, mean gfx clock over the XCDs, and the firmware power-limit residency over the region')
+    return out
 
 
 def _finish(world):
@@ -323,23 +354,31 @@ def _channel_candidates(a):
 def _tune_channels(a, world, device, run_two_steps):
     """the first 8-GPU contact tunes itself.  For every candidate channel cap (launcher.channel_groups: a process group
     whose communicator is capped at that many channels = workgroups = CUs taken from the backward GEMMs) run `run_two_steps(label, group)`
-    - one untimed step that also builds the communicator, then two timed ones -, agree on the max over ranks and keep the fastest.
+    - an untimed pair `run_two_steps(label, group, True)` that selects the group and builds the communicator, then a timed pair (`..., False`) -,
+    agree on the max over ranks and keep the fastest.
     Returns the keys for the JSON line; the chosen group is in the returned dict under '_group' (popped by the caller)."""
     from controlvar_amd.launcher import channel_groups, pick_fastest
     cands = _channel_candidates(a)
+    import torch.distributed as dist
+    err = None
     try:
         groups = channel_groups(cands)
     except Exception as e:                   # a library that rejects the per-communicator cap must not cost the run its line: default group, reason on the line
-        return {'comm_channels': 'default', 'comm_channels_tried_s': {}, 'comm_channels_error': f'{type(e).__name__}: {e}'[:300], '_group': None}
+        groups, err = None, f'{type(e).__name__}: {e}'[:300]
+    # every rank must take the same branch (ADVICE r5): a cap that failed on ONE rank would leave the others in pick_fastest's collectives
+    ok = torch.tensor([0.0 if groups is None else 1.0], device=device if (device is not None and dist.is_initialized() and dist.get_backend() == 'nccl') else 'cpu')
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok.item()) < 1.0:
+        return {'comm_channels': 'default', 'comm_channels_tried_s': {}, 'comm_channels_error': err or 'channel_groups failed on another rank', '_group': None}
 
     def seconds_of(label):
-        run_two_steps(label, groups[label])                     # communicator set-up / first-use cost stays outside the clock
-        import torch.distributed as dist
+        run_two_steps(label, groups[label], True)               # selects the group (reducer construction) + communicator first use: outside the clock
         if device is not None:
             torch.cuda.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
-        run_two_steps(label, groups[label])
+        run_two_steps(label, groups[label], False)
         if device is not None:
             torch.cuda.synchronize()
         return time.perf_counter() - t0
@@ -364,7 +403,7 @@ def main_stub(a):
         # the channel selection of main_train with sleeping candidates: rank r sleeps (1 + r) x the candidate's milliseconds, so the agreed
         # time of a candidate is the SLOWEST rank's and every rank must land on the same choice
         fake = dict(zip(_channel_candidates(a), [float(x) for x in a.stub_comm_ms.split(',')]))
-        tuned = _tune_channels(a, world, None, lambda label, group: time.sleep(fake[label] * 1e-3 * (1 + rank)))
+        tuned = _tune_channels(a, world, None, lambda label, group, select: time.sleep(fake[label] * 1e-3 * (1 + rank)))
     _, dt = sharded_timed_run(lambda i: time.sleep(a.stub_step_ms * 1e-3 * (1 + rank)), a.steps, a.warmup, B)
     tuned.pop('_group', None)
     ev = {**_rank_evidence(B, a.steps, None), **tuned}
@@ -383,9 +422,13 @@ def main_train(a):
     EXPOSED communication time (what the overlap did not hide)."""
     from controlvar_amd.launcher import dist_env, init_dist, sharded_timed_run, synthetic_rank_batch
     rank, local, world = dist_env()
+    if a.share_gpu:
+        local = local % max(1, torch.cuda.device_count())
+        if a.comm_channels == 'auto':
+            a.comm_channels = 'default'                         # channel caps are an RCCL setting
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    init_dist('nccl', dev)
+    init_dist('gloo' if a.share_gpu else 'nccl', None if a.share_gpu else dev)
     from controlvar_amd import models, ops, train as T, _lib
     from controlvar_amd.spec import VarConfig, algorithmic_gflop_per_row
     _lib.load()
@@ -402,8 +445,9 @@ def main_train(a):
 
     tuned = {}
     if world > 1:
-        def two_steps(label, group):
-            tr.set_comm_group(group)
+        def two_steps(label, group, select):
+            if select:                          # once per candidate, before the untimed pair: the reducer is rebuilt outside the clock
+                tr.set_comm_group(group)
             step(0); step(1)
         tuned = _tune_channels(a, world, dev, two_steps)
         tr.set_comm_group(tuned.pop('_group'))
@@ -436,7 +480,8 @@ def main_train(a):
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
                'config': {'workload': f'ControlVAR d{a.depth} training step (tokenise image+control, forward, CE, backward, clip 2.0, AdamW), '
                                       f'synthetic ImageNetC-shaped batch', 'batch_per_gpu': B, 'global_batch': B * world, 'seq_len': 1360,
-                          'parallelism': f'dp{world} (per-layer gradient slabs, RCCL all-reduce on a side stream)'},
+                          'parallelism': (f'dp{world} SHARING {torch.cuda.device_count()} GPU(s), per-layer gradient slabs all-reduced over gloo on a side stream - the real two-rank step, not a scaling number'
+                                          if a.share_gpu else f'dp{world} (per-layer gradient slabs, RCCL all-reduce on a side stream)')},
                'algorithmic_tflop_per_sample': round(per_sample_tf, 3), 'end_to_end_tflops_per_gpu': round(per_sample_tf * B * a.steps / dt, 1),
                'loss': round(float(last['out']['loss']), 4), 'exposed_comm_frac': None if exposed is None else round(exposed, 4),
                'allreduce_ms_per_step': None if allreduce_ms is None else round(allreduce_ms, 2), **ev,
@@ -478,12 +523,21 @@ def main_infer(a):
     prof = None if a.no_kernel_timing else []
     last = {}
 
+    board = None
+    if rank == 0 and not a.no_telemetry:
+        from controlvar_amd.telemetry import BoardSampler
+        board = BoardSampler(local)
+
     def timed_step(i):
         if i == a.warmup:
             ops.GEMM_PROFILE = prof                     # kernel events only inside the timed region
+            if board is not None:
+                board.start()                           # socket power / gfx clock of the timed region (a thread polling AMD SMI every 20 ms)
         last['img'] = step(100 + i)
 
     _, dt = sharded_timed_run(timed_step, a.steps, a.warmup, B, sync=torch.cuda.synchronize)
+    if board is not None:
+        board.stop()
     ops.GEMM_PROFILE = None
     ev = _rank_evidence(B, a.steps, dev)
     if ev['rccl_ranks'] != world:
@@ -514,9 +568,12 @@ def main_infer(a):
             ach = flops / (ms * 1e-3) / 1e12
             peak = 2500.0 if a.dtype == 'bf16' else 157.3
             sustained = {}
+            telemetry_probe = None
             if a.dtype == 'bf16':
                 try:
-                    sm = sustained_mfma(dev)
+                    sm = sustained_mfma(dev, telemetry_s=0.0 if a.no_telemetry else 1.5)
+                    if 'randn_telemetry' in sm:
+                        telemetry_probe = {'randn_operands': sm['randn_telemetry'], 'zero_operands': sm['zeros_telemetry']}
                     sustained = {'sustained_peak': round(sm['randn'], 1), 'frac_of_sustained': round(ach / sm['randn'], 4), 'peak_on_zero_operands': round(sm['zeros'], 1),
                                  'clock_ghz_randn_zeros': [round(sm['randn_ghz'], 2), round(sm['zeros_ghz'], 2)],
                                  'sustained_note': 'cvar_probe_mfma_bf16 in this run on this device: a register-fed stream of the GEMM\'s MFMA (v_mfma_f32_16x16x32_bf16, two waves '
@@ -544,7 +601,7 @@ def main_infer(a):
             out['roofline'] = {'bound': 'mfma', 'kernel': 'cvar_gemm_kernel + conv3x3_halo_bf16_kernel (every cvar_gemm launch: GEMMs and 3x3 convs)',
                                'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
                                'traffic': traffic, 'traffic_source': tsrc, 'launches': len(prof), 'avg_launch_ms': round(ms / len(prof), 4),
-                               'gemm_share_of_step': round(ms * 1e-3 / dt, 3), **sustained,
+                               'gemm_share_of_step': round(ms * 1e-3 / dt, 3), **sustained, **_board_keys(board, telemetry_probe),
                                'peak_note': 'dense bf16 MFMA peak at 2.4 GHz; this kernel is power-limited on random operands (the same instruction stream runs '
                                             '~30 % faster on constant operands: profiles/r03_gemm_power.txt), so the clock under load is ~1.85 GHz'}
         prof = None
@@ -580,10 +637,10 @@ def main(argv=None):
         stub = a.stub_step_ms > 0
         if not stub:
             have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-            if have < a.gpus:
+            if have < a.gpus and not (a.share_gpu and a.mode == 'train' and have >= 1):
                 sys.exit(f'[bench] --gpus {a.gpus} but only {have} GPU(s) are visible to this process - refusing to run a smaller job under the same name')
         from controlvar_amd.launcher import spawn
-        spawn(_spawned, nprocs=a.gpus, args=(argv,), backend='gloo' if stub else 'nccl')
+        spawn(_spawned, nprocs=a.gpus, args=(argv,), backend='gloo' if (stub or a.share_gpu) else 'nccl')
         return
     run(a)
 

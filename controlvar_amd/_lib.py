@@ -11,7 +11,7 @@ import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('CVAR_LIB') or os.path.join(HERE, 'libcvar_hip.so')      # CVAR_LIB: A/B runs against another build
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 CVAR_F32, CVAR_BF16 = 0, 1
 ACT_NONE, ACT_GELU_TANH, ACT_GELU_GRAD = 0, 1, 2
@@ -72,6 +72,8 @@ SIGNATURES = {
     'cvar_groupnorm_ws_bytes': (c_l, [c_i, c_i, c_i]),
     'cvar_groupnorm_silu': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p]),
     'cvar_groupnorm_silu_partials': (c_i, [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_i, c_i, c_p, c_p]),
+    'cvar_split3': (c_i, [c_p, c_l, c_p, c_l, c_i, c_i, c_p]),
+    'cvar_groupnorm_silu_split3': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p, c_p]),
     'cvar_conv3x3_gn_partials': (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, C.POINTER(c_i), C.POINTER(c_i)]),
     'cvar_softmax_rows': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     'cvar_gemm_tn': (c_i, [c_p, c_l, c_p, c_l, c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_p, c_p]),

@@ -48,6 +48,7 @@ extern "C" int cvar_gemm_dbg_read(unsigned long long* host) { return (int)hipMem
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef int v4i_t __attribute__((ext_vector_type(4)));
 
 template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2, bool FAST = false, bool CUP = false>
 __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
@@ -604,6 +605,14 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
     constexpr bool FULL32 = TRANS && !M16;                // 16x16 blocks (M16) are staged one block row = 16 output rows at a time
     constexpr int SROWS = FULL32 ? 32 : 16;
     static_assert(NW * SROWS * EROW * 4 <= NSTAGE * STAGE, "epilogue staging must fit the pipeline LDS");
+#ifndef CVAR_GEMM_RPF
+#define CVAR_GEMM_RPF 1
+#endif
+    // RPF tile: the eight-wave 256x256 bf16 GEMM (16-row staging, 64 columns per wave = 8 lanes per row, two 8-row passes per half-pass); its launch allocates 32 KB
+    // behind the pipeline stages (launch_cfg) - see the RPF epilogue below
+    constexpr bool RPF_TILE = (CVAR_GEMM_RPF != 0) && M16 && !CONV && FAST && ES == 2 && BM == 256 && BN == 256 && NW == 8 && SUB_N == 64 && SUB_M == 128 && NSTAGE == 2;
+    constexpr int RPF_RING_BASE = (NW * SROWS * EROW * 4 + 1023) / 1024 * 1024;
+    static_assert(!RPF_TILE || RPF_RING_BASE + NW * 8192 <= NSTAGE * STAGE, "RPF ring slots 1-2 must fit the released pipeline stages");
     float* stg = (float*)smem + wave * (SROWS * EROW);
     // rows of block i land in the staging region: the whole transposed block at once (4 x b128 per 32 columns), or - tiles whose
     // pipeline LDS is too small for 32 staged rows per wave keep the plain MFMA layout (lane = column) - 16 rows as b32 stores
@@ -663,6 +672,88 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
             constexpr bool out_bf = decltype(OUTBF)::value, gate = decltype(GATE)::value, remap = decltype(REMAP)::value;
             constexpr int act = decltype(ACT)::value, res = decltype(RES)::value;          // res: 0 none, 1 fp32, 2 bf16
             constexpr int OES = out_bf ? 2 : 4, RES_ES = res == 2 ? 2 : 4;
+#if CVAR_GEMM_RPF
+            // ---- RPF (round 6): the fp32 gate + residual read-modify-write of a FULL 256x256 tile (proj / fc2: x += gate * f, basic_var.py:208-209) with the residual
+            // rows prefetched THREE half-passes ahead by LDS DMA.  The register form keeps one half-pass (32 KB per CU) of residual reads in flight - a CU then moves
+            // its 512 KB at ~25 B/clk, latency-bound (28 % of proj, 9-10 % of fc2: profiles/r05_gemm_insitu_b512.txt), and deeper register prefetch spills
+            // (256 VGPRs, profiles/r03_gemm_rejected_ab.txt).  Here a wave owns a ring of three 4 KB slots (16 rows x 64 fp32 columns each: slot 0 in the 32 KB behind
+            // the pipeline stages, slots 1-2 in the released stages behind the staging rows): `buffer_load ... lds` costs no registers, the pieces of half-pass h + 3
+            // are issued when half-pass h has consumed its slot, and one counted vmcnt in front of a half-pass (loads, stores and DMA retire in issue order on gfx9;
+            // every count below is static because nothing in this path is predicated) waits for exactly its own four pieces.  Stores and gate loads go through
+            // buffer instructions on scalar bases + 32-bit offsets.  Same arithmetic in the same order as the register form: bit-identical results.
+            if constexpr (RPF_TILE && gate && res == 1 && !out_bf && !remap && act == CVAR_ACT_NONE) {
+                const bool rpf_ok = vec_ok && m0 + BM <= p.M && n0 + BN <= p.N && !p.C2 && !p.gate_scale && p.tile_cfg != 28 &&
+                                    ((long)(p.M / max(p.gate_rows, 1) + 1) * p.ldg * 4 < 0x7fffffffL) && (long)SUB_M * p.ldr * 4 < 0x7fffffffL && (long)SUB_M * p.ldc * 4 < 0x7fffffffL;
+                if (rpf_ok) {
+                    const int mw = m0 + wm * SUB_M, nw = n0 + wn * SUB_N;
+                    const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const float*)p.residual + rz + (long)mw * p.ldr + nw), 0, 0x7fffffff, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t c_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((float*)p.C + cz + (long)mw * p.ldc + nw), 0, 0x7fffffff, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.gate + nw), 0, 0x7fffffff, 0x00020000);
+                    const int ldr4 = (int)p.ldr * 4, ldc4 = (int)p.ldc * 4, ldg4 = (int)p.ldg * 4;
+                    const int dma_lane = (lane >> 4) * ldr4 + (lane & 15) * 16;            // a 1 KB piece = 4 rows x 256 B
+                    const int st_lane = erow * ldc4 + ecol * 4;
+                    char* const slot0 = smem + NSTAGE * STAGE + wave * 4096;
+                    char* const slot12 = smem + RPF_RING_BASE + wave * 8192;
+                    auto slot = [&](int h) -> char* { return (h % 3) == 0 ? slot0 : slot12 + ((h % 3) - 1) * 4096; };
+                    auto issue_res = [&](int h) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lptr_t)(slot(h) + q * 1024), 16, dma_lane, (h * 16 + q * 4) * ldr4, 0, 0);
+                    };
+                    f32x4_t gq2[2][2][2];
+                    auto fetch_gate = [&](int h) {
+#pragma unroll
+                        for (int ps = 0; ps < 2; ++ps) {
+                            const int m = mw + h * 16 + ps * 8 + erow;
+                            const int goff = fast_div(m, p.gate_magic, p.gate_shift) * ldg4 + ecol * 4;
+                            gq2[h & 1][ps][0] = __builtin_bit_cast(f32x4_t, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(g_rsrc, goff, 0, 0));
+                            gq2[h & 1][ps][1] = __builtin_bit_cast(f32x4_t, (v4i_t)__builtin_amdgcn_raw_buffer_load_b128(g_rsrc, goff + 16, 0, 0));
+                        }
+                    };
+                    // issue order: G0 D0 D1 D2 | per half-pass h: wait D_h, stage + combine, G_{h+1}, S_h, D_{h+3}.  G = 4 loads, S = 4 stores, D = 4 pieces.
+                    fetch_gate(0);
+                    issue_res(0); issue_res(1); issue_res(2);
+                    const float* stg_r = stg + erow * EROW + ecol;
+#pragma clang loop unroll(full)
+                    for (int h = 0; h < 2 * MI; ++h) {
+                        // operations issued after D_h: h == 0: D1 D2 (8); h == 1: D2 G1 S0 D3 (16); h >= 2: [G S D] x 2 (24), less the D that no longer exist near the end
+                        constexpr int NH = 2 * MI;
+                        const int after = h == 0 ? 8 : (h == 1 ? 4 + 4 + 4 + (3 < NH ? 4 : 0)
+                                                              : (4 + 4 + (h + 1 < NH ? 4 : 0)) + (4 + 4 + (h + 2 < NH ? 4 : 0)));
+                        // (G_{h} of the previous iteration exists only if h < NH; S always; see the issue code below - the two must agree)
+                        if (after == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        else if (after == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                        else if (after == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+                        else if (after == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                        else if (after == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        stage_block(h >> 1, h & 1);
+                        float v[2][8];
+                        const char* sl = slot(h) + erow * 256 + ecol * 4;
+#pragma unroll
+                        for (int ps = 0; ps < 2; ++ps) {
+                            const f32x4_t a0 = *(const f32x4_t*)(stg_r + (ps * 8) * EROW), a1 = *(const f32x4_t*)(stg_r + (ps * 8) * EROW + 4);
+                            const f32x4_t r0 = *(const f32x4_t*)(sl + ps * 2048), r1 = *(const f32x4_t*)(sl + ps * 2048 + 16);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                v[ps][e] = a0[e] * p.alpha + bias8[e]; v[ps][4 + e] = a1[e] * p.alpha + bias8[4 + e];
+                                v[ps][e] *= gq2[h & 1][ps][0][e]; v[ps][4 + e] *= gq2[h & 1][ps][1][e];
+                                v[ps][e] += r0[e]; v[ps][4 + e] += r1[e];
+                            }
+                        }
+                        if (h + 1 < NH) fetch_gate(h + 1);
+#pragma unroll
+                        for (int ps = 0; ps < 2; ++ps) {
+                            const f32x4_t o0 = {v[ps][0], v[ps][1], v[ps][2], v[ps][3]}, o1 = {v[ps][4], v[ps][5], v[ps][6], v[ps][7]};
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_t, o0), c_rsrc, st_lane, (h * 16 + ps * 8) * ldc4, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_t, o1), c_rsrc, st_lane + 16, (h * 16 + ps * 8) * ldc4, 0);
+                        }
+                        if (h + 3 < NH) issue_res(h + 3);
+                    }
+                    return;
+                }
+            }
+#endif
             const int mrow = m0 + wm * SUB_M + erow;
             const float* stg_r = stg + erow * EROW + ecol;
             char* c_lane = Cb + (cz + n) * OES;
@@ -978,7 +1069,8 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     // neutral or -1 % for the K = 1536 bf16-output GEMMs; 16 loses everywhere.
     if (p.group_m <= 0) p.group_m = (!p.conv && ((long)p.K * (long)sizeof(T) >= 8192 || p.out_dtype == CVAR_F32)) ? 4 : 8;
     if (p.conv) { const int kt_e = 128 / (int)sizeof(T); p.cv_adv = kt_e / p.Cin; p.cv_rem = kt_e % p.Cin; }
-    const size_t lds = NSTAGE * (BM + BN) * 128;
+    // (+32 KB behind the stages for the eight-wave 256x256 bf16 tile: slot 0 of the RPF epilogue's residual ring; the CU holds one such workgroup either way)
+    const size_t lds = NSTAGE * (BM + BN) * 128 + ((sizeof(T) == 2 && BM == 256 && BN == 256 && WM == 2 && WN == 4 && NSTAGE == 2 && !CONVFAST) ? 32768 : 0);
     const int nk_all = (p.K + (128 / (int)sizeof(T)) - 1) / (128 / (int)sizeof(T));
     const int splits = p.split_tiles > 0 ? (nk_all + p.split_tiles - 1) / p.split_tiles : 1;
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits, (unsigned)batch), block(WM * WN * 64);
@@ -1019,7 +1111,7 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
 // cvar_gemm_desc::tile_cfg -> the A/B selector of launch_typed: -1 automatic, 0 128x128 tiles only, 1 the 8-wave 256x256 tile, 3 the
 // 4-wave 256x256 tile (part of the call, not of the process environment)
 static int gemm_cfg_override(const GemmParams& p) {
-    return p.tile_cfg == 1 ? 0 : (p.tile_cfg == 2 || p.tile_cfg == 7) ? 1 : (p.tile_cfg == 3 || p.tile_cfg == 8) ? 3 : p.tile_cfg == 4 ? 4 : -1;
+    return p.tile_cfg == 1 ? 0 : (p.tile_cfg == 2 || p.tile_cfg == 7 || p.tile_cfg == 28) ? 1 : (p.tile_cfg == 3 || p.tile_cfg == 8) ? 3 : p.tile_cfg == 4 ? 4 : -1;
 }
 
 template <typename T>

@@ -532,6 +532,97 @@ extern "C" int cvar_groupnorm_silu(const void* x, int dtype, const float* weight
     return CVAR_EUNSUPPORTED;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 operands ("bf16x3", ABI 20): the middle precision of the VQVAE encoder.  An fp32 value x is carried as hi = bf16(x) and lo = bf16(x - hi)
+// (x - hi is exact in fp32; |x - hi - lo| <= 2^-17 |x|), and a product a * w is taken as a_hi w_hi + a_lo w_hi + a_hi w_lo on the bf16 matrix pipe with fp32
+// accumulation (the dropped a_lo w_lo term is <= 2^-16 |a w|).  The three products are three K SEGMENTS of one conv / GEMM: an activation row of C channels is
+// stored as [hi(C) | lo(C) | hi(C)] bf16 and the weight row as [w_hi | w_hi | w_lo], so the existing bf16 kernels run the sum with 3 x the K extent - no new
+// contraction kernel.  These two kernels produce the activation side: from an fp32 tensor as it is, or from GroupNorm (+ SiLU) of it (the apply pass of
+// cvar_groupnorm_silu in fp32 arithmetic with the exact quotient, as the fp32 parity mode runs it).  Cpad >= 3 C pads a pixel's row with zeros (the image conv: 3 -> 4
+// channels fp32, 12 split channels padded to 16).
+__device__ __forceinline__ void split3_store(bf16_t* __restrict__ o, const float* y, int C) {
+    float hi[4], lo[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const bf16_t h = f32_to_bf16(y[e]); hi[e] = bf16_to_f32(h); lo[e] = y[e] - hi[e]; }
+    const bf16x4_t H = pack_bf16x4(hi), L = pack_bf16x4(lo);          // hi is a bf16 value already: packing it is exact
+    *(bf16x4_t*)(o) = H;
+    *(bf16x4_t*)(o + C) = L;
+    *(bf16x4_t*)(o + 2 * C) = H;
+}
+
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ out, long M, int C, int Cpad) {
+    const int nq = C / 4, npad = (Cpad - 3 * C) / 4;
+    const long total = M * (nq + npad);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / (nq + npad);
+        const int q = (int)(i % (nq + npad));
+        if (q < nq) {
+            const f32x4_t v = *(const f32x4_t*)(x + m * ldx + q * 4);
+            const float y[4] = {v[0], v[1], v[2], v[3]};
+            split3_store(out + m * Cpad + q * 4, y, C);
+        } else {
+            const bf16x4_t z = {0, 0, 0, 0};
+            *(bf16x4_t*)(out + m * Cpad + 3 * C + (q - nq) * 4) = z;
+        }
+    }
+}
+
+extern "C" int cvar_split3(const float* x, int64_t ldx, void* out, int64_t M, int C, int Cpad, void* stream) {
+    if (!x || !out || M <= 0 || C <= 0) return CVAR_EINVAL;
+    if (C % 4 || ldx % 4 || Cpad < 3 * C || Cpad % 4 || (((uintptr_t)x | (uintptr_t)out) & 15)) return CVAR_EUNSUPPORTED;
+    const long total = M * (long)(Cpad - 2 * C) / 4;
+    const int blocks = (int)std::min<long>(cdiv(total, 256L), 256L * 32);
+    hipLaunchKernelGGL(split3_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, (long)ldx, (bf16_t*)out, (long)M, C, Cpad);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
+// gn_apply_kernel<float> with the split store: y = silu?(x a_c + d_c) -> [hi | lo | hi]
+__global__ __launch_bounds__(256) void gn_apply_split3_kernel(const float* __restrict__ x, const float* __restrict__ coef, bf16_t* __restrict__ out,
+                                                             int HW, int C, int ppb, int silu) {
+    const int ncg = C / 4, PL = 256 / ncg;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int cg = threadIdx.x % ncg, pl = threadIdx.x / ncg;
+    if (pl >= PL) return;
+    float a[4], d[4];
+    {
+        const float* cf = coef + ((long)b * C + cg * 4) * 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = cf[2 * e]; d[e] = cf[2 * e + 1]; }
+    }
+    const int p0 = chunk * ppb, p1 = min(HW, p0 + ppb);
+#pragma unroll 4
+    for (int p = p0 + pl; p < p1; p += PL) {
+        const long row = (long)b * HW + p;
+        const f32x4_t v = *(const f32x4_t*)(x + row * C + cg * 4);
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = v[e] * a[e] + d[e];
+        if (silu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = y[e] / (1.0f + __expf(-y[e]));
+        }
+        split3_store(out + row * 3 * C + cg * 4, y, C);
+    }
+}
+
+extern "C" int cvar_groupnorm_silu_split3(const float* x, const float* weight, const float* bias, void* out, int B, int HW, int C, int groups, float eps, int silu,
+                                          void* ws, void* stream) {
+    if (!x || !weight || !bias || !out || !ws || B <= 0 || HW <= 0 || C <= 0 || groups <= 0) return CVAR_EINVAL;
+    if (C % 4 || C % groups || C / 4 > 256 || (((uintptr_t)x | (uintptr_t)out) & 15)) return CVAR_EUNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const int ppb = gn_pix_per_block(HW);
+    const int nchunk = cdiv(HW, ppb);
+    float* partial = (float*)ws;
+    float* coef = partial + (size_t)B * nchunk * C * 2;
+    const int PL = 256 / (C / 4);
+    hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nchunk, B), dim3(256), (size_t)PL * C * 2 * sizeof(float), st, x, partial, HW, C, ppb);
+    hipLaunchKernelGGL(gn_finalize_kernel<float>, dim3(groups, B), dim3(64), 0, st, partial, nchunk, x, weight, bias, coef, HW, C, groups, eps);
+    hipLaunchKernelGGL(gn_apply_split3_kernel, dim3(nchunk, B), dim3(256), 0, st, x, coef, (bf16_t*)out, HW, C, ppb, silu);
+    CVAR_CHECK_LAUNCH();
+    return CVAR_OK;
+}
+
 // row softmax, one wave per row (cols <= 1024)
 template <typename TO>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, TO* __restrict__ p, int rows, int cols) {
@@ -710,7 +801,7 @@ extern "C" int cvar_nhwc_to_nchw(const void* in, int dtype, int64_t ld_in, float
     return CVAR_OK;
 }
 
-extern "C" int cvar_abi_version(void) { return 19; }
+extern "C" int cvar_abi_version(void) { return 20; }
 extern "C" const char* cvar_status_str(int status) {
     switch (status) {
         case CVAR_OK: return "ok";

@@ -80,7 +80,11 @@ class VQVAE(nn.Module):
 
     def __init__(self, vocab_size=4096, z_channels=32, ch=128, dropout=0.0, beta=0.25, using_znorm=False, quant_conv_ks=3,
                  quant_resi=0.5, share_quant_resi=4, default_qresi_counts=0, v_patch_nums=DEFAULT_PATCH_NUMS, test_mode=True,
-                 compute_dtype=torch.bfloat16, init_seed: int = 0, decode_chunk: int = 128):
+                 compute_dtype=torch.bfloat16, init_seed: int = 0, decode_chunk: int = 128, encoder_precision: Optional[str] = None):
+        """encoder_precision (bf16 compute only; None = 'bf16'): arithmetic of the ENCODER conv stack in front of the exact quantizer -
+        'bf16' (throughput), 'bf16x3' (split-bf16: every operand as hi + lo bf16, three MFMA products per multiply, fp32 accumulate and fp32 activations:
+        ~2^-16 relative error per product, ids agree with the reference's fp32 encoder far beyond plain bf16 at about a third of its encoder rate) or 'fp32'
+        (the parity mode's exact-f32 MFMA for the encoder only).  The decoder keeps compute_dtype either way."""
         super().__init__()
         if using_znorm or quant_conv_ks != 3 or abs(quant_resi - 0.5) > 1e-9 or share_quant_resi != 4 or dropout != 0.0:
             raise NotImplementedError('only the shipped VQVAE configuration (vqvae.py:18-27 defaults, share_quant_resi=4) is built')
@@ -91,6 +95,10 @@ class VQVAE(nn.Module):
         self.Cvae = z_channels
         self.downsample = 2 ** (len(self.cfg.ch_mult) - 1)
         self.compute_dtype = _compute_dtype(compute_dtype)
+        ep = encoder_precision or ('bf16' if self.compute_dtype == torch.bfloat16 else 'fp32')
+        if ep not in ('bf16', 'bf16x3', 'fp32') or (self.compute_dtype == torch.float32 and ep != 'fp32'):
+            raise ValueError(f'encoder_precision={encoder_precision!r}: one of bf16 / bf16x3 / fp32 (an fp32 model encodes in fp32)')
+        self.encoder_precision = ep
         # images per decoder pass (an image's bits do not depend on it).  128 since round 5: VQVAE round trip 1 355 -> 1 373-1 379 images/s, headline +0.4 % at the
         # same 226 GB peak (64 / 128 / 256: 201.5 / 202.3 / 202.0 images/s on one box)
         self.decode_chunk = decode_chunk
@@ -147,6 +155,8 @@ class VQVAE(nn.Module):
                     cin_p = cin
                     w = v.reshape(cout, cin)
                 P['conv'][name] = dict(w=w.to(Tw).contiguous(), b=sd[name + '.bias'].float().contiguous(), cin=cin_p, cout=cout, ks=ks)
+                if name.startswith('encoder.') and T == torch.bfloat16 and self.encoder_precision != 'bf16':
+                    P.setdefault('enc', {})[name] = self._pack_encoder_conv(v, sd[name + '.bias'], dev)
             elif '.norm' in k and k.endswith('.weight'):
                 name = k[:-len('.weight')]
                 P['norm'][name] = (v.float().contiguous(), sd[name + '.bias'].float().contiguous())
@@ -170,6 +180,23 @@ class VQVAE(nn.Module):
         self._packed = P
         self._packed_sig = self._state_sig()
         return P
+
+    def _pack_encoder_conv(self, v, bias, dev):
+        """encoder weights of the non-default encoder precisions: 'fp32' = the parity mode's packing; 'bf16x3' = per tap [w_hi | w_hi | w_lo] over 3 x cin channels
+        (the weight side of the split product, include/cvar.h cvar_split3)"""
+        cout, cin, ks, _ = v.shape
+        cin_p = (cin + 3) // 4 * 4
+        w = torch.zeros(cout, ks, ks, cin_p, device=dev, dtype=torch.float32)
+        w[..., :cin] = v.permute(0, 2, 3, 1).float()
+        b = bias.float().contiguous()
+        if self.encoder_precision == 'fp32':
+            return dict(w=w.reshape(cout, ks * ks * cin_p).contiguous(), b=b, cin=cin_p, cout=cout, ks=ks)
+        hi = w.to(torch.bfloat16)
+        lo = (w - hi.float()).to(torch.bfloat16)
+        cin3 = (3 * cin_p + 7) // 8 * 8                                       # bf16 K moves 16-byte chunks
+        w3 = torch.zeros(cout, ks, ks, cin3, device=dev, dtype=torch.bfloat16)
+        w3[..., :cin_p], w3[..., cin_p:2 * cin_p], w3[..., 2 * cin_p:3 * cin_p] = hi, hi, lo
+        return dict(w=w3.reshape(cout, ks * ks * cin3).contiguous(), b=b, cin=cin_p, cin3=cin3, cout=cout, ks=ks)
 
     # ---- conv-stack building blocks (NHWC activations of compute dtype)
     # GroupNorm statistics from the producing conv's epilogue (round 5): a 3x3 conv that the LDS-halo kernel takes writes per-tile partial sums of its
@@ -242,6 +269,8 @@ class VQVAE(nn.Module):
     def _encode_f(self, img: torch.Tensor) -> torch.Tensor:
         """quant_conv(encoder(img)) -> f (B, Cvae, 16, 16) fp32 (vqvae.py:74; vae_modules.py:144-160)."""
         P = self._pack()
+        if self.encoder_precision != ('bf16' if self.compute_dtype == torch.bfloat16 else 'fp32'):
+            return self._encode_f_hiprec(img)
         B, _, H, W = img.shape
         T = self.compute_dtype
         cfg = self.cfg
@@ -266,6 +295,96 @@ class VQVAE(nn.Module):
         h = self._resblock(h, 'encoder.mid.block_2', B, H, W, cur, cur)
         h = self._gn(h, 'encoder.norm_out', B, H * W, cur)
         z, _, _ = self._conv(h, 'encoder.conv_out', B, H, W, out_dtype=torch.float32)      # (B*HW, Cvae) fp32 NHWC
+        f, _, _ = self._conv(z, 'quant_conv', B, H, W)                                      # fp32 weights
+        out = torch.empty(B, self.Cvae, H, W, device=img.device, dtype=torch.float32)
+        ops.nhwc_to_nchw(f, self.Cvae, out, B, self.Cvae, H * W)
+        return out
+
+    # ---- the encoder in its higher precisions (bf16 model, encoder_precision 'bf16x3' / 'fp32'): fp32 NHWC activations throughout; x3: every conv input is split into
+    # [hi | lo | hi] bf16 rows (by the GroupNorm that feeds it, or by cvar_split3) and contracted with [w_hi | w_hi | w_lo] rows on the bf16 tiles.  The 16 x 16 attention
+    # blocks (0.1 % of the encoder's flops) run q k^T and p v on the exact-f32 MFMA.  Same layer walk as _encode_f (vae_modules.py:144-160).
+    def _hp_conv(self, x, name, B, Hin, Win, *, stride=1, residual=None, pre_split=False):
+        c = self._pack()['enc'][name]
+        x3mode = self.encoder_precision == 'bf16x3'
+        ks = c['ks']
+        Hout, Wout = (Hin // 2, Win // 2) if stride == 2 else (Hin, Win)
+        M = B * Hout * Wout
+        if x3mode and not pre_split:
+            xs = torch.empty(B * Hin * Win, c['cin3'], device=x.device, dtype=torch.bfloat16)
+            ops.split3(x, xs, B * Hin * Win, c['cin'], c['cin3'])
+            x = xs
+        cin = c['cin3'] if x3mode else c['cin']
+        out = torch.empty(M, c['cout'], device=x.device, dtype=torch.float32)
+        if ks == 1:
+            ops.gemm(x, c['w'], out, M=M, N=c['cout'], K=cin, bias=c['b'], residual=residual, split_k=False)
+        else:
+            ops.gemm(x, c['w'], out, M=M, N=c['cout'], K=9 * cin, bias=c['b'], residual=residual,
+                     conv=dict(Hin=Hin, Win=Win, Cin=cin, Hout=Hout, Wout=Wout, stride=stride, up=0))
+        return out, Hout, Wout
+
+    def _hp_gn(self, x, name, B, HW, C, silu=True):
+        """GroupNorm(+SiLU) of the fp32 stream -> the next conv's input: split rows (x3) or fp32"""
+        w, b = self._pack()['norm'][name]
+        ws = torch.empty(ops.groupnorm_ws_bytes(B, HW, C), device=x.device, dtype=torch.uint8)
+        if self.encoder_precision == 'bf16x3':
+            out = torch.empty(B * HW, 3 * C, device=x.device, dtype=torch.bfloat16)
+            return ops.groupnorm_silu_split3(x, w, b, out, B, HW, C, self.cfg.gn_groups, self.cfg.gn_eps, silu, ws)
+        return ops.groupnorm_silu(x, w, b, torch.empty_like(x), B, HW, C, self.cfg.gn_groups, self.cfg.gn_eps, silu, ws)
+
+    def _hp_resblock(self, x, name, B, H, W, cin, cout):
+        h = self._hp_gn(x, name + '.norm1', B, H * W, cin)
+        h, _, _ = self._hp_conv(h, name + '.conv1', B, H, W, pre_split=True)
+        h = self._hp_gn(h, name + '.norm2', B, H * W, cout)
+        if cin != cout:
+            x, _, _ = self._hp_conv(x, name + '.nin_shortcut', B, H, W)
+        h, _, _ = self._hp_conv(h, name + '.conv2', B, H, W, residual=x, pre_split=True)
+        return h
+
+    def _hp_attnblock(self, x, name, B, HW, C):
+        F32 = torch.float32
+        n = self._hp_gn(x, name + '.norm', B, HW, C, silu=False)
+        qkv, _, _ = self._hp_conv(n, name + '.qkv', B, HW, 1, pre_split=True)             # (B*HW, 3C) fp32: q | k | v
+        HWp = -(-HW // 4) * 4
+        vT = torch.empty(B, C, HW, device=x.device, dtype=F32) if HWp == HW else torch.zeros(B, C, HWp, device=x.device, dtype=F32)
+        ops.transpose(qkv, vT, B, HW, C, 3 * C, in_off=2 * C, ld_out=HWp)
+        s = torch.empty(B, HW, HW, device=x.device, dtype=F32)
+        ops.gemm(qkv, qkv, s, M=HW, N=HW, K=C, lda=3 * C, ldw=3 * C, w_off=C, alpha=float(int(C) ** -0.5), batch=B,
+                 strideA=HW * 3 * C, strideW=HW * 3 * C, strideC=HW * HW)
+        p = torch.empty(B, HW, HW, device=x.device, dtype=F32)
+        ops.softmax_rows(s, p, B * HW, HW)
+        if HWp != HW:
+            pp = torch.zeros(B, HW, HWp, device=x.device, dtype=F32)
+            pp[:, :, :HW] = p
+            p = pp
+        o = torch.empty(B * HW, C, device=x.device, dtype=F32)
+        ops.gemm(p, vT, o, M=HW, N=C, K=HWp, batch=B, strideA=HW * HWp, strideW=C * HWp, strideC=HW * C)
+        y, _, _ = self._hp_conv(o, name + '.proj_out', B, HW, 1, residual=x)
+        return y
+
+    def _encode_f_hiprec(self, img: torch.Tensor) -> torch.Tensor:
+        P = self._pack()
+        B, _, H, W = img.shape
+        cfg = self.cfg
+        cin_p = P['enc']['encoder.conv_in']['cin']
+        x = torch.empty(B * H * W, cin_p, device=img.device, dtype=torch.float32)
+        ops.nchw_to_nhwc(img.contiguous().float(), x, B, 3, H * W, cin_p)
+        h, H, W = self._hp_conv(x, 'encoder.conv_in', B, H, W)
+        nlev = len(cfg.ch_mult)
+        cur = cfg.ch
+        for lv in range(nlev):
+            cout = cfg.ch * cfg.ch_mult[lv]
+            for b in range(cfg.num_res_blocks):
+                h = self._hp_resblock(h, f'encoder.down.{lv}.block.{b}', B, H, W, cur, cout)
+                cur = cout
+                if lv == nlev - 1:
+                    h = self._hp_attnblock(h, f'encoder.down.{lv}.attn.{b}', B, H * W, cur)
+            if lv != nlev - 1:
+                h, H, W = self._hp_conv(h, f'encoder.down.{lv}.downsample.conv', B, H, W, stride=2)
+        h = self._hp_resblock(h, 'encoder.mid.block_1', B, H, W, cur, cur)
+        h = self._hp_attnblock(h, 'encoder.mid.attn_1', B, H * W, cur)
+        h = self._hp_resblock(h, 'encoder.mid.block_2', B, H, W, cur, cur)
+        h = self._hp_gn(h, 'encoder.norm_out', B, H * W, cur)
+        z, _, _ = self._hp_conv(h, 'encoder.conv_out', B, H, W, pre_split=True)             # (B*HW, Cvae) fp32 NHWC
         f, _, _ = self._conv(z, 'quant_conv', B, H, W)                                      # fp32 weights
         out = torch.empty(B, self.Cvae, H, W, device=img.device, dtype=torch.float32)
         ops.nhwc_to_nchw(f, self.Cvae, out, B, self.Cvae, H * W)

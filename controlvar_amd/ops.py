@@ -285,6 +285,18 @@ def groupnorm_silu(x, weight, bias, out, B, HW, Cdim, groups, eps, silu, ws):
     return out
 
 
+def split3(x, out, M, Cdim, Cpad=0, ldx=0):
+    """fp32 x[M][ldx] -> bf16 out[M][Cpad or 3 C] = [hi | lo | hi] (+ zero padding): the activation side of a split-bf16 product (cvar_split3, ABI 20)"""
+    check(_lib.load().cvar_split3(_ptr(x), ldx or Cdim, _ptr(out), M, Cdim, Cpad or 3 * Cdim, _stream()), 'cvar_split3')
+    return out
+
+
+def groupnorm_silu_split3(x, weight, bias, out, B, HW, Cdim, groups, eps, silu, ws):
+    check(_lib.load().cvar_groupnorm_silu_split3(_ptr(x), _ptr(weight), _ptr(bias), _ptr(out), B, HW, Cdim, groups, eps, int(silu), _ptr(ws), _stream()),
+          'cvar_groupnorm_silu_split3')
+    return out
+
+
 def conv_gn_partials(dtype: torch.dtype, stride: int, Cin: int, Cout: int, Hin: int, Win: int, Hout: int, Wout: int):
     """(tiles_per_image, pixels_per_tile) when a 3x3 conv of this shape emits GroupNorm partials of its output (gemm(..., gn_part=...)), else None"""
     if GEMM_TILE_CFG not in (0, 6):

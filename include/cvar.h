@@ -87,6 +87,8 @@ typedef struct {
      *                 waves instead of eight (the form before the second half of round 4; A/B measurements, bit-identical);
      *                 27: the 256x192 tile (round 5) on every unsliced plain bf16 call - automatic plans (0 / 12) take it for launches whose 256x256 tiles would
      *                 fill their last round of the chip badly (N % 192 == 0, M >= 2048); bit-identical to the other tiles;
+     *                 28: as 2, with the round-6 LDS-prefetched gate + residual epilogue (RPF) switched off - full 256x256 tiles of an fp32 gate + residual call then run the
+     *                 register-prefetch epilogue that partial tiles always run; bit-identical (A/B measurements, tests);
      *   stagger       > 0: the first workgroup of every CU starts delayed by up to this many shader cycles (by its index), which
      *                 de-phases the output bursts of equally long tiles; 0: off.  Never changes results. */
     void* ws; int64_t ws_bytes;
@@ -251,6 +253,15 @@ int cvar_groupnorm_silu(const void* x, int dtype, const float* weight, const flo
  * double precision in a fixed order, then out = silu?(x * a_c + d_c) as above.  ws: cvar_groupnorm_ws_bytes(B, HW, C) bytes (only the coefficient part is used). */
 int cvar_groupnorm_silu_partials(const void* x, int dtype, const float* weight, const float* bias, void* out, int B, int HW, int C, int groups, float eps,
                                  int silu, const float* gn_part, int tiles_per_image, int pixels_per_tile, void* ws, void* stream);
+/* Split-bf16 operands ("bf16x3", ABI 20) - the middle precision of the VQVAE ENCODER (vae_modules.py:144-160 run in fp32 by the reference; quant.py:196-213 then
+ * takes the nearest code of every feature, so encoder noise moves ids).  An fp32 value x is carried as hi = bf16(x), lo = bf16(x - hi) and a product as
+ * a_hi w_hi + a_lo w_hi + a_hi w_lo on the bf16 matrix pipe with fp32 accumulation (relative error ~2^-16 instead of bf16's 2^-9).  The three products are three
+ * K segments of ONE bf16 conv / GEMM (cvar_gemm, dtype bf16, fp32 output + fp32 residual): activation rows [hi(C) | lo(C) | hi(C)], weight rows [w_hi | w_hi | w_lo]
+ * per tap.  cvar_split3 makes the activation rows from an fp32 tensor x[M][ldx] (Cpad >= 3 C: zero padding behind them, multiples of 4);
+ * cvar_groupnorm_silu_split3 from GroupNorm(+SiLU) of an fp32 NHWC tensor (fp32 arithmetic, exact quotient - the parity mode's GroupNorm; ws as cvar_groupnorm_silu). */
+int cvar_split3(const float* x, int64_t ldx, void* out_bf16, int64_t M, int C, int Cpad, void* stream);
+int cvar_groupnorm_silu_split3(const float* x, const float* weight, const float* bias, void* out_bf16, int B, int HW, int C, int groups, float eps, int silu,
+                               void* ws, void* stream);
 /* row softmax of fp32 scores -> dtype probabilities (AttnBlock, vae_modules.py:84). */
 int cvar_softmax_rows(const float* s, void* p, int out_dtype, int rows, int cols, void* stream);
 /* [B][n][c] -> [B][c][n] transpose of `dtype` (V operand of AttnBlock's second bmm, vae_modules.py:87-89). */

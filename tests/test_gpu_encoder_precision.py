@@ -1,0 +1,121 @@
+"""The tokenizer's middle precision: a bf16 model whose ENCODER runs in split bf16 ("bf16x3": every operand as hi + lo bf16, three MFMA
+products per multiply, fp32 accumulate, fp32 activations) or on the exact-f32 MFMA, in front of the always-exact quantizer (quant.py:196-213).  What is at stake is
+the id agreement with the reference's fp32 encoder (vae_modules.py:144-160; train_control_var_hpu.py:157-176 takes the training labels from it)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import golden, ids_parity, record  # noqa: E402
+from controlvar_amd import models, ops  # noqa: E402
+from controlvar_amd.spec import DEFAULT_PATCH_NUMS as PN  # noqa: E402
+from controlvar_amd.synth import synth_images  # noqa: E402
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _split_ref(y):
+    hi = y.to(BF16)
+    lo = (y - hi.float()).to(BF16)
+    return torch.cat((hi, lo, hi), dim=1)
+
+
+@pytest.mark.parametrize('M,C,Cpad', [(1000, 160, 480), (4097, 4, 16), (333, 640, 1920), (7, 32, 104)])
+def test_split3_is_hi_lo_hi(gpu_device, M, C, Cpad):
+    g = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, C, generator=g) * torch.logspace(-3, 3, M).unsqueeze(1)).to(gpu_device)
+    out = torch.full((M, Cpad), 7.0, device=gpu_device, dtype=BF16)
+    ops.split3(x, out, M, C, Cpad)
+    assert torch.equal(out[:, :3 * C], _split_ref(x))
+    assert not out[:, 3 * C:].any()
+    hi, lo = out[:, :C].double(), out[:, C:2 * C].double()
+    rel = ((hi + lo - x.double()).abs() / x.double().abs().clamp_min(1e-30)).max().item()
+    assert rel <= 2.0 ** -16, rel                           # two bf16 roundings: 2^-9 * 2^-9 (round to nearest: half of that each)
+
+
+@pytest.mark.parametrize('silu', [True, False])
+def test_groupnorm_split3_equals_split_of_the_fp32_groupnorm(gpu_device, silu):
+    B, HW, C = 3, 32 * 32, 320
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(B * HW, C, generator=g) * 2 + 0.7).to(gpu_device)
+    w, b = torch.randn(C, generator=g).to(gpu_device), torch.randn(C, generator=g).to(gpu_device)
+    ws = torch.empty(ops.groupnorm_ws_bytes(B, HW, C), device=gpu_device, dtype=torch.uint8)
+    y = ops.groupnorm_silu(x, w, b, torch.empty_like(x), B, HW, C, 32, 1e-6, silu, ws)
+    out = torch.empty(B * HW, 3 * C, device=gpu_device, dtype=BF16)
+    ops.groupnorm_silu_split3(x, w, b, out, B, HW, C, 32, 1e-6, silu, ws)
+    assert torch.equal(out, _split_ref(y))
+
+
+def test_split_product_is_far_closer_to_fp32_than_bf16(gpu_device):
+    """one 3x3 conv of the encoder's shape three ways: exact-f32 MFMA, plain bf16, split bf16 through the SAME bf16 kernel with K = 3 x 9 Cin"""
+    vae = models.build_vae(ch=32, compute_dtype=BF16, encoder_precision='bf16x3').to(gpu_device)
+    vae32 = models.build_vae(ch=32, compute_dtype=F32).to(gpu_device)
+    vaeb = models.build_vae(ch=32, compute_dtype=BF16).to(gpu_device)
+    B, H, C = 2, 64, 32
+    x = torch.randn(B * H * H, C, generator=torch.Generator().manual_seed(0)).to(gpu_device)
+    name = 'encoder.down.0.block.0.conv1'
+    ref, _, _ = vae32._conv(x, name, B, H, H)
+    x3, _, _ = vae._hp_conv(x, name, B, H, H)
+    pb, _, _ = vaeb._conv(x.to(BF16), name, B, H, H, out_dtype=F32)
+    sc = ref.abs().max().item()
+    e3, eb = (x3 - ref).abs().max().item() / sc, (pb - ref).abs().max().item() / sc
+    print(f'[x3] conv 32->32 at 64x64: split bf16 {e3:.2e}, plain bf16 {eb:.2e} of max|y|')
+    assert e3 < 2e-5 and e3 < eb / 50
+
+
+@pytest.mark.parametrize('prec', ['fp32', 'bf16x3'])
+def test_encoder_precisions_against_the_reference_ids(gpu_device, prec):
+    """ch160 tokenizer of a bf16 model on the reference's fixture images (tokenizer_ch160.npz: ids of the reference's fp32 encoder): 'fp32' must reproduce them
+    strictly; 'bf16x3' is measured and must agree on >= 99 % (plain bf16: 0.647, profiles/r05c_parity_report.json)"""
+    g = golden('tokenizer_ch160')
+    vae = models.build_vae(ch=160, compute_dtype=BF16, encoder_precision=prec).to(gpu_device)
+    img = synth_images(int(g['nimg']), 256, seed=1).to(gpu_device)
+    f = vae._encode_f(img).cpu()
+    err_f = float((f - t(g['f'])).abs().max())
+    ids = torch.cat(vae.img_to_idxBl(img), dim=1).cpu().numpy()
+    ref = g['ids'].astype(np.int64)
+    agree = float((ids == ref).mean())
+    print(f'[parity] encoder_precision={prec}: max|df| {err_f:.3e} (max|f| {float(np.abs(g["f"]).max()):.2f}), id agreement with the reference {agree:.4f} of {ref.size}')
+    record(f'img_to_idxBl ch160 bf16 model, encoder {prec} vs reference fp32 ids', kind='ids', flips=int((ids != ref).sum()), total=int(ref.size), agreement=agree, err_f=err_f,
+           strict=prec == 'fp32', tol=0.0)
+    if prec == 'fp32':
+        ids_parity(ids, ref, np.zeros(ref.shape, np.float32), 0.0, 'bf16 model with the fp32 encoder', strict=True)
+        assert err_f < 2e-4
+    else:
+        assert err_f < 2e-3
+        assert agree >= 0.99, agree
+
+
+def test_encoder_precisions_on_a_larger_sample_and_what_flips_cost_downstream(gpu_device):
+    """64 synthetic images: ids of every encoder precision against the fp32 parity mode (whose ids ARE the reference's: 0 flips over every fixture), and what the
+    flips mean downstream - PSNR of idxBl_to_img(ids) against idxBl_to_img(ids of the fp32 mode), both through the same fp32 decoder."""
+    n = 64
+    img = synth_images(n, 256, seed=11).to(gpu_device)
+    v32 = models.build_vae(ch=160, compute_dtype=F32).to(gpu_device)
+    ids_ref = v32.img_to_idxBl(img)
+    rec_ref = v32.idxBl_to_img(ids_ref, same_shape=True, last_one=True)
+    cat_ref = torch.cat(ids_ref, dim=1)
+    orig_mse = float(((rec_ref - img) ** 2).mean())
+    out = {}
+    for prec in ('bf16', 'bf16x3', 'fp32'):
+        v = models.build_vae(ch=160, compute_dtype=BF16, encoder_precision=prec).to(gpu_device)
+        ids = v.img_to_idxBl(img)
+        cat = torch.cat(ids, dim=1)
+        agree = float((cat == cat_ref).float().mean())
+        per_img = (cat == cat_ref).float().mean(dim=1)
+        rec = v32.idxBl_to_img(ids, same_shape=True, last_one=True)
+        mse = float(((rec - rec_ref) ** 2).mean())
+        psnr = float('inf') if mse == 0 else 10 * np.log10(4.0 / mse)               # pixel range [-1, 1]
+        mse_img = float(((rec - img) ** 2).mean())
+        out[prec] = dict(agreement=agree, images_identical=int((per_img == 1).sum()), psnr_vs_reference_ids_db=psnr, recon_mse=mse_img)
+        print(f'[x3] encoder {prec}: id agreement {agree:.4f} ({out[prec]["images_identical"]} of {n} images identical), reconstruction from these ids vs from the reference ids: '
+              f'PSNR {psnr:.1f} dB; MSE against the input image {mse_img:.5f} (reference ids: {orig_mse:.5f})')
+        del v
+    record('encoder precisions on 64 synthetic images vs the fp32 mode', kind='encoder_precision', **{k: v for k, v in out.items()}, recon_mse_reference_ids=orig_mse)
+    assert out['fp32']['agreement'] == 1.0
+    assert out['bf16x3']['agreement'] >= 0.99 and out['bf16x3']['agreement'] > out['bf16']['agreement']

@@ -1013,3 +1013,36 @@ def test_gemm_256x192_tile_every_hot_epilogue_bit_identical_to_the_256x256_tile(
         elif kind == 'gate':
             want = res0 + gate.cpu().repeat_interleave(256, 0)[:M] * ref
             assert ((a.cpu() - want).abs() <= 1e-2 * (want.abs() + 1)).all()
+
+
+# ------------------------------------------------------------------------------------------------ round 6: RPF epilogue of the 256x256 tile
+@pytest.mark.parametrize('M,N,K,l,inplace', [(2048, 1536, 1536, 512, True), (4096 + 200, 1536, 6144, 2, True), (2304, 512, 128, 90, False), (2560, 1792, 256, 16, True)])
+def test_gemm_gate_residual_lds_prefetch_equals_the_register_form(gpu_device, M, N, K, l, inplace):
+    """x += gate * (A W^T + b) (proj / fc2, basic_var.py:208-209) on the eight-wave 256x256 tile: full tiles take the epilogue whose residual rows are prefetched three
+    half-passes ahead by LDS DMA (round 6), partial tiles and tile_cfg 28 the register form - the SAME arithmetic in the same order, so the results must be bit-identical;
+    rows with ragged M (a partial last row tile), gate rows that change inside a half-pass (l = 2, 90), columns that are not a multiple of 256, out of place and in place."""
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(gpu_device)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(gpu_device)
+    b = torch.randn(N, generator=g).to(gpu_device)
+    nseq = -(-M // l)
+    gate = torch.randn(nseq, 3 * N, generator=g).to(gpu_device)
+    x0 = torch.randn(M, N, generator=g).to(gpu_device)
+    outs = []
+    for cfg in (2, 28):                                        # 2: the eight-wave 256x256 tile wherever it applies (RPF on full tiles); 28: the same without RPF
+        old = ops.GEMM_TILE_CFG
+        try:
+            ops.GEMM_TILE_CFG = cfg
+            res = x0.clone()
+            out = res if inplace else torch.full_like(x0, float('nan'))
+            ops.gemm(A, W, out, M=M, N=N, K=K, bias=b, gate=gate, gate_off=N, ldg=3 * N, gate_rows=l, residual=res, split_k=False)
+            torch.cuda.synchronize()
+            outs.append(out.clone())
+            if not inplace:
+                assert torch.equal(res, x0)                    # the residual operand is only read
+        finally:
+            ops.GEMM_TILE_CFG = old
+    assert torch.equal(outs[0], outs[1])
+    acc = A.float() @ W.float().t() + b
+    ref = x0 + acc * gate[:, N:2 * N].repeat_interleave(l, dim=0)[:M]
+    assert (outs[0] - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
