@@ -51,7 +51,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 
 template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2, bool FAST = false, bool CUP = false>
-__device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
+__device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p, const int vblock) {
     static_assert(!CUP || (CONV && FAST), "CUP (nearest x2 upsample folded into the conv) is a conv FAST variant");
     constexpr int NW = WM * WN;
     constexpr bool FRAG_PIPE = (BM == 256) && (!CONV || FAST);
@@ -92,7 +92,11 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
     unsigned long long dbg_rt_entry = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid = threadIdx.x;
+    // (opaque per call: a workgroup that runs two tiles would otherwise keep every lane constant of a tile - offsets, swizzles, epilogue columns - live across the whole
+    //  loop, hoisted out of it: 256 VGPRs + scratch instead of 240)
+    if constexpr (sizeof(T) == 2 && BM == 256 && BN == 256 && WM == 2 && WN == 4 && !CONV && FAST && NSTAGE == 2) asm volatile("" : "+v"(tid));      // (the one kernel that loops over tiles)
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     auto w_piece = [&](int jj) { const int j = wave + jj * NW; return j < B_INSTR ? j : j - B_DUP; };
@@ -112,7 +116,7 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
 
     // ---- tile coordinates: bijective XCD remap, then grouped-M ordering
     int m0, n0;
-    gemm_tile_origin(p, (int)blockIdx.x, BM, BN, m0, n0);
+    gemm_tile_origin(p, vblock, BM, BN, m0, n0);
     const long zb = blockIdx.z;
 
     const char* const zero = (const char*)cvar_zero_chunk;
@@ -714,26 +718,38 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
                     fetch_gate(0);
                     issue_res(0); issue_res(1); issue_res(2);
                     const float* stg_r = stg + erow * EROW + ecol;
+                    typedef const __attribute__((address_space(3))) char* lcptr_t;
+                    const lcptr_t sl0 = (lcptr_t)(slot0 + erow * 256 + ecol * 4), sl12 = (lcptr_t)(slot12 + erow * 256 + ecol * 4);     // this lane's 32 bytes of a ring row
 #pragma clang loop unroll(full)
                     for (int h = 0; h < 2 * MI; ++h) {
                         // operations issued after D_h: h == 0: D1 D2 (8); h == 1: D2 G1 S0 D3 (16); h >= 2: [G S D] x 2 (24), less the D that no longer exist near the end
                         constexpr int NH = 2 * MI;
-                        const int after = h == 0 ? 8 : (h == 1 ? 4 + 4 + 4 + (3 < NH ? 4 : 0)
-                                                              : (4 + 4 + (h + 1 < NH ? 4 : 0)) + (4 + 4 + (h + 2 < NH ? 4 : 0)));
-                        // (G_{h} of the previous iteration exists only if h < NH; S always; see the issue code below - the two must agree)
-                        if (after == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                        else if (after == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                        else if (after == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-                        else if (after == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-                        else if (after == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef CVAR_RPF_WAIT
+#define CVAR_RPF_WAIT 0
+#endif
+                        // ops issued after D_h, by kind: younger DMA pieces, stores, gate loads (see the issue order above)
+                        const int nd = h == 0 ? 8 : (h == 1 ? 4 + (3 < NH ? 4 : 0) : (h + 1 < NH ? 4 : 0) + (h + 2 < NH ? 4 : 0));
+                        const int ns = h == 0 ? 0 : (h == 1 ? 4 : 8);
+                        const int ng = h == 0 ? 0 : (h == 1 ? 4 : 8);
+                        const int after = CVAR_RPF_WAIT == 1 ? nd + ns : (CVAR_RPF_WAIT == 2 ? nd : nd + ns + ng);
+                        switch (after) {
+                            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+                            case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+                            case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+                            case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+                            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                        }
+                        if (CVAR_RPF_WAIT == 3) __builtin_amdgcn_s_sleep(4);
                         stage_block(h >> 1, h & 1);
                         float v[2][8];
-                        const char* sl = slot(h) + erow * 256 + ecol * 4;
+                        const lcptr_t sl = ((h % 3) == 0 ? sl0 : sl12 + ((h % 3) - 1) * 4096);
 #pragma unroll
                         for (int ps = 0; ps < 2; ++ps) {
                             const f32x4_t a0 = *(const f32x4_t*)(stg_r + (ps * 8) * EROW), a1 = *(const f32x4_t*)(stg_r + (ps * 8) * EROW + 4);
-                            const f32x4_t r0 = *(const f32x4_t*)(sl + ps * 2048), r1 = *(const f32x4_t*)(sl + ps * 2048 + 16);
+                            const f32x4_t r0 = *(const __attribute__((address_space(3))) f32x4_t*)(sl + ps * 2048), r1 = *(const __attribute__((address_space(3))) f32x4_t*)(sl + ps * 2048 + 16);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 v[ps][e] = a0[e] * p.alpha + bias8[e]; v[ps][4 + e] = a1[e] * p.alpha + bias8[4 + e];
@@ -745,8 +761,13 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
 #pragma unroll
                         for (int ps = 0; ps < 2; ++ps) {
                             const f32x4_t o0 = {v[ps][0], v[ps][1], v[ps][2], v[ps][3]}, o1 = {v[ps][4], v[ps][5], v[ps][6], v[ps][7]};
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_t, o0), c_rsrc, st_lane, (h * 16 + ps * 8) * ldc4, 0);
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_t, o1), c_rsrc, st_lane + 16, (h * 16 + ps * 8) * ldc4, 0);
+                            // the row offset rides in the VECTOR offset, soffset stays 0: with an SGPR soffset the compiler assumes a 128-bit buffer store has no
+                            // store-data hazard and lets the next VALU instruction overwrite the data registers (GCNHazardRecognizer: "this hazard only exists if the
+                            // instruction is not using a register in the soffset field") - on gfx950 a quarter of the lanes then stored the NEW register contents
+                            // (last half-pass of every wave tile, nondeterministic; found by the bit-identity test of this path, profiles/r06_rpf_ab.txt)
+                            const int st_off = st_lane + (h * 16 + ps * 8) * ldc4;
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_t, o0), c_rsrc, st_off, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_t, o1), c_rsrc, st_off + 16, 0, 0);
                         }
                         if (h + 3 < NH) issue_res(h + 3);
                     }
@@ -890,6 +911,8 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
                 if (!p.gate && p.residual && p.res_dtype == CVAR_BF16 && p.act == CVAR_ACT_NONE && obf && !rm) {
                     run(Y{}, I0{}, NO{}, I2{}, NO{}); done = true;
                 }
+                // (round 6, measured and not kept: an fp32-output + fp32-residual variant for the split-bf16 encoder's conv2 raises the register allocation of EVERY conv tile
+                //  of this unit - 256x160 four-wave: 94 -> 142 VGPRs beside 160 AGPRs, two workgroups per CU -> one - so those calls stay on the generic epilogue)
             }
         }
     }
@@ -1018,7 +1041,28 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p) {
 
 template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2, bool FAST = false, bool CUP = false>
 __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParams p) {
-    cvar_gemm_tile<T, BM, BN, WM, WN, CONV, NSTAGE, FAST, CUP>(p);
+    // Round 6: a workgroup may own p.tpw CONSECUTIVE tiles of its XCD's range (launch_cfg: 2 for big plain launches of the eight-wave 256x256 tile) and runs them one
+    // after the other - no dispatch gap (1.7 us between workgroups on a CU, profiles/r04_gemm_wg_timeline.txt) and no kernel-argument / descriptor set-up in front of the
+    // second tile.  Nothing is carried from tile to tile (the full persistent form, with its tile counters and DMA stream across tiles, paid for its savings in
+    // registers and a longer epilogue: profiles/r04_gemm_persistent_rejected.txt); one raw barrier separates them because the next prologue's DMA lands in the LDS
+    // that the other waves' epilogues are still staging through.  Virtual block id of tile t of workgroup b: ((b >> 3) * tpw + t) * 8 + (b & 7) - same XCD, neighbours
+    // in the grouped order (they share their A rows or their W columns out of L2).  Same tiles, same arithmetic: results do not depend on tpw.
+    if constexpr (!(sizeof(T) == 2 && BM == 256 && BN == 256 && WM == 2 && WN == 4 && !CONV && FAST && NSTAGE == 2)) {
+        cvar_gemm_tile<T, BM, BN, WM, WN, CONV, NSTAGE, FAST, CUP>(p, (int)blockIdx.x);
+    } else {
+        const int tpw = p.tpw > 1 ? p.tpw : 1;
+        const int nblk = p.tiles_m * p.tiles_n, xcd = (int)blockIdx.x & 7, lim = (nblk >> 3) + (xcd < (nblk & 7) ? 1 : 0);
+#pragma nounroll
+        for (int t = 0; t < tpw; ++t) {
+            const int local = ((int)blockIdx.x >> 3) * tpw + t;
+            if (local >= lim) break;
+            if (t) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            cvar_gemm_tile<T, BM, BN, WM, WN, CONV, NSTAGE, FAST, CUP>(p, local * 8 + xcd);
+        }
+    }
 }
 
 // One output quad of a split-K GEMM: the slices' fp32 partials summed in slice order (bit-reproducible), then the complete epilogue of `p`.
@@ -1073,7 +1117,19 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     const size_t lds = NSTAGE * (BM + BN) * 128 + ((sizeof(T) == 2 && BM == 256 && BN == 256 && WM == 2 && WN == 4 && NSTAGE == 2 && !CONVFAST) ? 32768 : 0);
     const int nk_all = (p.K + (128 / (int)sizeof(T)) - 1) / (128 / (int)sizeof(T));
     const int splits = p.split_tiles > 0 ? (nk_all + p.split_tiles - 1) / p.split_tiles : 1;
-    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits, (unsigned)batch), block(WM * WN * 64);
+    // tiles per workgroup (see cvar_gemm_kernel): two for plain unsliced launches of the eight-wave 256x256 bf16 tile with at least eight rounds of the chip
+    // (tile_cfg 29: one, A/B measurements)
+    p.tpw = 1;
+    const bool plain_fast = !p.conv && p.K % (128 / (int)sizeof(T)) == 0 && (long)(BM - 1) * p.lda * (long)sizeof(T) + (long)p.K * (long)sizeof(T) < (1L << 31) &&
+                            (long)(BN - 1) * p.ldw * (long)sizeof(T) + (long)p.K * (long)sizeof(T) < (1L << 31);
+#ifndef CVAR_GEMM_TPW
+#define CVAR_GEMM_TPW 2
+#endif
+    if (sizeof(T) == 2 && BM == 256 && BN == 256 && WM == 2 && WN == 4 && NSTAGE == 2 && !CONVFAST && !p.conv && splits == 1 && batch == 1 && p.tile_cfg != 29 &&
+        (long)p.tiles_m * p.tiles_n >= 2048 && p.stagger == 0 && plain_fast) p.tpw = CVAR_GEMM_TPW;      // (only the FAST plain kernel loops over tiles)
+    const int nblk_l = p.tiles_m * p.tiles_n;
+    const unsigned gx = p.tpw > 1 ? 8u * (unsigned)((((nblk_l >> 3) + ((nblk_l & 7) ? 1 : 0)) + p.tpw - 1) / p.tpw) : (unsigned)nblk_l;
+    dim3 grid(gx, (unsigned)splits, (unsigned)batch), block(WM * WN * 64);
     // Which kernels a translation unit instantiates: the bf16 conv kernels live in their own unit (gemm_conv.hip), the bf16 GEMM
     // kernels in gemm.hip, everything fp32 in gemm_f32.hip - three compilations that run in parallel.
     constexpr bool WITH_CONV = CVAR_TU_CONV || sizeof(T) == 4, WITH_PLAIN = CVAR_TU_PLAIN || sizeof(T) == 4;
@@ -1094,8 +1150,7 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
         } else return CVAR_EUNSUPPORTED;
     } else if constexpr (!WITH_PLAIN) {
         return CVAR_EUNSUPPORTED;
-    } else if (p.K % (128 / (int)sizeof(T)) == 0 && (long)(BM - 1) * p.lda * (long)sizeof(T) + (long)p.K * (long)sizeof(T) < (1L << 31) &&
-               (long)(BN - 1) * p.ldw * (long)sizeof(T) + (long)p.K * (long)sizeof(T) < (1L << 31)) {
+    } else if (plain_fast) {
         auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, false, NSTAGE, true>;
         set_max_lds_once(kfn, lds);
         hipLaunchKernelGGL(kfn, grid, block, lds, st, p);

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from ._lib import CvarError
 from ._lib import ACT_GELU_TANH
 from .pyramid import packed_tables
 from .spec import DEFAULT_PATCH_NUMS, VaeConfig, VarConfig, attention_levels, vae_state_shapes, var_state_shapes
@@ -219,8 +220,17 @@ class VQVAE(nn.Module):
         out = torch.empty(M, c['cout'], device=x.device, dtype=out_dtype or T)
         geo = ops.conv_gn_partials(T, stride, c['cin'], c['cout'], Hin, Win, Hout, Wout) if (self.GN_FROM_CONV and out.dtype == T) else None
         part = torch.empty(B, geo[0], c['cout'], 3, device=x.device, dtype=torch.float32) if geo else None
-        ops.gemm(x, c['w'], out, M=M, N=c['cout'], K=9 * c['cin'], bias=c['b'], residual=residual,
-                 conv=dict(Hin=Hin, Win=Win, Cin=c['cin'], Hout=Hout, Wout=Wout, stride=stride, up=up), gn_part=part)
+        cv = dict(Hin=Hin, Win=Win, Cin=c['cin'], Hout=Hout, Wout=Wout, stride=stride, up=up)
+        try:
+            ops.gemm(x, c['w'], out, M=M, N=c['cout'], K=9 * c['cin'], bias=c['b'], residual=residual, conv=cv, gn_part=part)
+        except CvarError as e:
+            # conv_gn_partials() decides by shape alone; the kernel that emits the partials also needs 16-byte aligned bias / output / residual and dense
+            # strides (a state dict assigned from a flat buffer can hand over a 4-byte aligned bias).  Such a call is unsupported WITH partials, not
+            # without: run it on the implicit-GEMM tiles and let the GroupNorm that follows make its own statistics pass.
+            if part is None or 'unsupported' not in str(e).lower():
+                raise
+            geo, part = None, None
+            ops.gemm(x, c['w'], out, M=M, N=c['cout'], K=9 * c['cin'], bias=c['b'], residual=residual, conv=cv)
         if geo:
             out._gn_part = (part, geo[0], geo[1])
         return out, Hout, Wout
@@ -668,8 +678,13 @@ class ControlVAR(nn.Module):
                  drop_path_rate=0., layer_scale=-1., tau=4, cos_attn=False, patch_nums=DEFAULT_PATCH_NUMS,
                  flash_if_available=True, fused_if_available=True, mask_factor=2, bidirectional=False, separate_decoding=False,
                  separator=False, type_pos=False, indep=True, multi_cond=False,
-                 compute_dtype=None, init_seed: int = 0):
+                 compute_dtype=None, init_seed: int = 0, deterministic_plan: bool = False):
+        """deterministic_plan (an addition of this library): every transformer GEMM runs on the unsliced tile kernels whatever its row count - no small-M weight-streaming
+        kernel, no K slices - so the fp32 summation order of a row does not depend on how many rows ride beside it, and one (label, condition, g_seed) in batch row 0 gives
+        the same logits and tokens BIT FOR BIT at any batch size (default False: the small-M plans are 1.3-2x faster at B <= 8 and move bf16 logits by ~5e-3 of
+        max|logit| between batch sizes; tests/test_gpu_configs.py).  Can also be flipped on a built model: ``model.deterministic_plan = True``."""
         super().__init__()
+        self.deterministic_plan = bool(deterministic_plan)
         if separator and not (self._control and mask_factor == 2):
             raise NotImplementedError('separator needs the joint (control, image) sequence')
         if separator and len(patch_nums) != 10:
@@ -920,6 +935,7 @@ class ControlVAR(nn.Module):
         # Small passes (early scales, small batches): proj / fc2 also produce the adaLN input of the op that follows (cvar_gemm_desc.ln_out) - their split-K
         # reduction finishes rows, so LayerNorm + modulation ride in that launch instead of a cvar_ln_modulate of their own (same bits).  Large passes keep the
         # separate launch: their GEMMs finish tiles, not rows.
+        sm = not self.deterministic_plan      # small-M plans (weight-streaming kernel, K slices): the summation order then depends on M; off = tile kernels only, unsliced
         fuse_ln = M < FUSE_LN_BELOW   # calls up to here can be sliced along K (small-M split-K, the long-K rule of the 256x256 tiles); an unsliced call launches cvar_ln_modulate itself
         ah = cfg.depth * 6 * C
         ops.ln_modulate(x, ada, 2 * C, 4 * C, n_ada, l, u, M, C, cfg.norm_eps)
@@ -927,25 +943,25 @@ class ControlVAR(nn.Module):
             a0 = i * 6 * C
             # one GEMM for q | k | v: the q columns land in the scratch, k | v rows straight in their KV-arena slots (row remap)
             ops.gemm(u, P['w_qkv'], arena, M=M, N=3 * C, K=C, w_off=i * 3 * C * C, bias=P['b_qkv'][i], c_off=i * arena_stride,
-                     ldc=2 * C, remap=(l, Lmax, q_off), split=(qs, C, C), split_alpha=q_alpha, small_m=True)
+                     ldc=2 * C, remap=(l, Lmax, q_off), split=(qs, C, C), split_alpha=q_alpha, small_m=sm, split_k=sm)
             if cfg.uses_cos_attn:
                 ops.cos_qk_norm(arena, R, H, Lmax, q_off, l, P['scale_mul'], qkv_off=i * arena_stride, sm_off=i * H, q=qs, q_mul=LOG2E if pre else 1.0)
             ops.attention(arena, o, R, H, Lmax, q_off, l, float(cfg.attn_scale), lvl_end, qkv_off=i * arena_stride, holes=holes, q=qs, prescaled=pre)
             ln2 = (u, ada, a0 + 3 * C, a0 + 5 * C, n_ada, l, cfg.norm_eps)
             ops.gemm(o, P['w_proj'], x, M=M, N=C, K=C, w_off=i * C * C, bias=P['b_proj'][i], gate=ada, gate_off=a0, ldg=n_ada, gate_rows=l,
-                     residual=x, ln=ln2 if fuse_ln else None, small_m=True)
+                     residual=x, ln=ln2 if fuse_ln else None, small_m=sm, split_k=sm)
             if not fuse_ln:
                 ops.ln_modulate(x, *ln2[1:6], u, M, C, cfg.norm_eps)
-            ops.gemm(u, P['w_fc1'], hbuf, M=M, N=hid, K=C, w_off=i * hid * C, bias=P['b_fc1'][i], act=ACT_GELU_TANH, small_m=True)
+            ops.gemm(u, P['w_fc1'], hbuf, M=M, N=hid, K=C, w_off=i * hid * C, bias=P['b_fc1'][i], act=ACT_GELU_TANH, small_m=sm, split_k=sm)
             # the row finished by fc2 is the input of the next block's first adaLN (or of the head's)
             a1 = a0 + 6 * C
             ln1 = (u, ada, a1 + 2 * C, a1 + 4 * C, n_ada, l, cfg.norm_eps) if i + 1 < cfg.depth else (u, ada, ah, ah + C, n_ada, l, cfg.norm_eps)
             ops.gemm(hbuf, P['w_fc2'], x, M=M, N=C, K=hid, w_off=i * C * hid, bias=P['b_fc2'][i], gate=ada, gate_off=a0 + C, ldg=n_ada,
-                     gate_rows=l, residual=x, ln=ln1 if fuse_ln else None, small_m=True)
+                     gate_rows=l, residual=x, ln=ln1 if fuse_ln else None, small_m=sm, split_k=sm)
             if not fuse_ln:
                 ops.ln_modulate(x, *ln1[1:6], u, M, C, cfg.norm_eps)
         logits = torch.empty(M, cfg.head_ld, device=dev, dtype=torch.float32)
-        ops.gemm(u, P['w_head'], logits, M=M, N=cfg.head_ld, K=C, bias=P['b_head'], small_m=True)
+        ops.gemm(u, P['w_head'], logits, M=M, N=cfg.head_ld, K=C, bias=P['b_head'], small_m=sm, split_k=sm)
         return logits
 
     def _ada(self, cond: torch.Tensor, R: int):
@@ -953,7 +969,8 @@ class ControlVAR(nn.Module):
         cs = torch.empty(R, self.cfg.C, device=cond.device, dtype=self.compute_dtype)
         ops.silu_cast(cond, cs)
         ada = torch.empty(R, P['n_ada'], device=cond.device, dtype=torch.float32)
-        ops.gemm(cs, P['w_ada'], ada, M=R, N=P['n_ada'], K=self.cfg.C, bias=P['b_ada'], small_m=True)
+        sm = not self.deterministic_plan
+        ops.gemm(cs, P['w_ada'], ada, M=R, N=P['n_ada'], K=self.cfg.C, bias=P['b_ada'], small_m=sm, split_k=sm)
         return ada
 
     def _as_labels(self, B, label_B, seed):
@@ -1294,13 +1311,13 @@ class VAR(ControlVAR):
     def __init__(self, vae_local: VQVAE, num_classes=1000, norm_eps=1e-6, aln=1, aln_gamma_init=1e-3, shared_aln=False,
                  cond_drop_rate=0.1, depth=16, embed_dim=1024, num_heads=16, mlp_ratio=4., drop_rate=0., attn_drop_rate=0.,
                  drop_path_rate=0., layer_scale=-1., tau=4, cos_attn=False, patch_nums=DEFAULT_PATCH_NUMS,
-                 flash_if_available=True, fused_if_available=True, compute_dtype=None, init_seed: int = 0):
+                 flash_if_available=True, fused_if_available=True, compute_dtype=None, init_seed: int = 0, deterministic_plan: bool = False):
         super().__init__(vae_local, num_classes=num_classes, norm_eps=norm_eps, aln=aln, aln_gamma_init=aln_gamma_init,
                          shared_aln=shared_aln, cond_drop_rate=cond_drop_rate, depth=depth, embed_dim=embed_dim, num_heads=num_heads,
                          mlp_ratio=mlp_ratio, drop_rate=drop_rate, attn_drop_rate=attn_drop_rate, drop_path_rate=drop_path_rate,
                          layer_scale=layer_scale, tau=tau, cos_attn=cos_attn, patch_nums=patch_nums,
                          flash_if_available=flash_if_available, fused_if_available=fused_if_available, mask_factor=1,
-                         multi_cond=False, compute_dtype=compute_dtype, init_seed=init_seed)
+                         multi_cond=False, compute_dtype=compute_dtype, init_seed=init_seed, deterministic_plan=deterministic_plan)
 
     @torch.no_grad()
     def autoregressive_infer_cfg(self, B: int, label_B, g_seed: Optional[int] = None, cfg=1.5, top_k=0, top_p=0.0,

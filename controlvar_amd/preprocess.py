@@ -212,7 +212,11 @@ def rle_from_string(s) -> list:
     while p < len(s):
         x, k, more = 0, 0, 1
         while more:
+            if p >= len(s):
+                raise ValueError('malformed COCO RLE string (ends inside a run: the last character has its continuation bit set)')
             c = s[p] - 48
+            if not 0 <= c < 64:                       # the alphabet is the 64 characters '0' (48) .. 'o' (111)
+                raise ValueError(f'malformed COCO RLE string (character {s[p]!r} at position {p} is outside the 6-bit alphabet)')
             x |= (c & 0x1f) << (5 * k)
             more = c & 0x20
             p += 1
@@ -262,6 +266,8 @@ def _runs_of(segmentation) -> Tuple[list, int, int]:
             mask_utils = None
         if mask_utils is not None:
             m = np.asarray(mask_utils.decode(segmentation))
+            if m.ndim != 2 or (int(m.shape[0]), int(m.shape[1])) != (int(h), int(w)):
+                raise ValueError(f'decoded mask is {tuple(m.shape)}, size says {h}x{w}')
             return runs_from_mask(m), int(m.shape[0]), int(m.shape[1])
         if not _WARNED_RLE_STRING:
             import warnings

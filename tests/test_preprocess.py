@@ -251,3 +251,17 @@ def test_device_mask_painting_equals_process_anns(gpu_device, seed):
         np.testing.assert_array_equal(P.paint_annotations(packed, 512, gpu_device).cpu().numpy(), want)
     empty = P.paint_annotations([a for a in anns if a['area'] < 5000], 512, gpu_device)
     assert int(empty.max()) == 0
+
+
+def test_rle_string_decoder_rejects_malformed_input():
+    """the compressed-RLE decoder is on the product path for annotation files - a truncated string (continuation bit set on the last character) and characters
+    outside the 6-bit alphabet ('0' .. 'o') must raise ValueError, not IndexError / silent garbage"""
+    from controlvar_amd.preprocess import rle_from_string, rle_to_string
+    good = rle_to_string([5, 3, 40, 2, 1000, 7])
+    assert rle_from_string(good) == [5, 3, 40, 2, 1000, 7]
+    trunc = rle_to_string([5, 3, 1000])[:-1]                      # 1000 needs two characters: cut inside the run
+    with pytest.raises(ValueError, match='malformed COCO RLE'):
+        rle_from_string(trunc)
+    for bad in ('5#3', 'ab\x7f', '0 1', 'p'):                      # '#', DEL, ' ' below / above the alphabet; 'p' = 112 is one past 'o'
+        with pytest.raises(ValueError, match='malformed COCO RLE'):
+            rle_from_string(bad)
