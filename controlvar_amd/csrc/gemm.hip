@@ -92,10 +92,7 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p, const int vb
     unsigned long long dbg_rt_entry = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    int tid = threadIdx.x;
-    // (opaque per call: a workgroup that runs two tiles would otherwise keep every lane constant of a tile - offsets, swizzles, epilogue columns - live across the whole
-    //  loop, hoisted out of it: 256 VGPRs + scratch instead of 240)
-    if constexpr (sizeof(T) == 2 && BM == 256 && BN == 256 && WM == 2 && WN == 4 && !CONV && FAST && NSTAGE == 2) asm volatile("" : "+v"(tid));      // (the one kernel that loops over tiles)
+    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
@@ -1041,28 +1038,8 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p, const int vb
 
 template <typename T, int BM, int BN, int WM, int WN, bool CONV, int NSTAGE = 2, bool FAST = false, bool CUP = false>
 __global__ __launch_bounds__(WM * WN * 64) void cvar_gemm_kernel(const GemmParams p) {
-    // Round 6: a workgroup may own p.tpw CONSECUTIVE tiles of its XCD's range (launch_cfg: 2 for big plain launches of the eight-wave 256x256 tile) and runs them one
-    // after the other - no dispatch gap (1.7 us between workgroups on a CU, profiles/r04_gemm_wg_timeline.txt) and no kernel-argument / descriptor set-up in front of the
-    // second tile.  Nothing is carried from tile to tile (the full persistent form, with its tile counters and DMA stream across tiles, paid for its savings in
-    // registers and a longer epilogue: profiles/r04_gemm_persistent_rejected.txt); one raw barrier separates them because the next prologue's DMA lands in the LDS
-    // that the other waves' epilogues are still staging through.  Virtual block id of tile t of workgroup b: ((b >> 3) * tpw + t) * 8 + (b & 7) - same XCD, neighbours
-    // in the grouped order (they share their A rows or their W columns out of L2).  Same tiles, same arithmetic: results do not depend on tpw.
-    if constexpr (!(sizeof(T) == 2 && BM == 256 && BN == 256 && WM == 2 && WN == 4 && !CONV && FAST && NSTAGE == 2)) {
-        cvar_gemm_tile<T, BM, BN, WM, WN, CONV, NSTAGE, FAST, CUP>(p, (int)blockIdx.x);
-    } else {
-        const int tpw = p.tpw > 1 ? p.tpw : 1;
-        const int nblk = p.tiles_m * p.tiles_n, xcd = (int)blockIdx.x & 7, lim = (nblk >> 3) + (xcd < (nblk & 7) ? 1 : 0);
-#pragma nounroll
-        for (int t = 0; t < tpw; ++t) {
-            const int local = ((int)blockIdx.x >> 3) * tpw + t;
-            if (local >= lim) break;
-            if (t) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-            cvar_gemm_tile<T, BM, BN, WM, WN, CONV, NSTAGE, FAST, CUP>(p, local * 8 + xcd);
-        }
-    }
+    // (round 6, built and measured a loss, no longer here: a workgroup that runs two neighbouring tiles one after the other - profiles/r06_gemm_two_tiles_rejected.txt)
+    cvar_gemm_tile<T, BM, BN, WM, WN, CONV, NSTAGE, FAST, CUP>(p, (int)blockIdx.x);
 }
 
 // One output quad of a split-K GEMM: the slices' fp32 partials summed in slice order (bit-reproducible), then the complete epilogue of `p`.
@@ -1117,19 +1094,9 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     const size_t lds = NSTAGE * (BM + BN) * 128 + ((sizeof(T) == 2 && BM == 256 && BN == 256 && WM == 2 && WN == 4 && NSTAGE == 2 && !CONVFAST) ? 32768 : 0);
     const int nk_all = (p.K + (128 / (int)sizeof(T)) - 1) / (128 / (int)sizeof(T));
     const int splits = p.split_tiles > 0 ? (nk_all + p.split_tiles - 1) / p.split_tiles : 1;
-    // tiles per workgroup (see cvar_gemm_kernel): two for plain unsliced launches of the eight-wave 256x256 bf16 tile with at least eight rounds of the chip
-    // (tile_cfg 29: one, A/B measurements)
-    p.tpw = 1;
     const bool plain_fast = !p.conv && p.K % (128 / (int)sizeof(T)) == 0 && (long)(BM - 1) * p.lda * (long)sizeof(T) + (long)p.K * (long)sizeof(T) < (1L << 31) &&
                             (long)(BN - 1) * p.ldw * (long)sizeof(T) + (long)p.K * (long)sizeof(T) < (1L << 31);
-#ifndef CVAR_GEMM_TPW
-#define CVAR_GEMM_TPW 2
-#endif
-    if (sizeof(T) == 2 && BM == 256 && BN == 256 && WM == 2 && WN == 4 && NSTAGE == 2 && !CONVFAST && !p.conv && splits == 1 && batch == 1 && p.tile_cfg != 29 &&
-        (long)p.tiles_m * p.tiles_n >= 2048 && p.stagger == 0 && plain_fast) p.tpw = CVAR_GEMM_TPW;      // (only the FAST plain kernel loops over tiles)
-    const int nblk_l = p.tiles_m * p.tiles_n;
-    const unsigned gx = p.tpw > 1 ? 8u * (unsigned)((((nblk_l >> 3) + ((nblk_l & 7) ? 1 : 0)) + p.tpw - 1) / p.tpw) : (unsigned)nblk_l;
-    dim3 grid(gx, (unsigned)splits, (unsigned)batch), block(WM * WN * 64);
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)splits, (unsigned)batch), block(WM * WN * 64);
     // Which kernels a translation unit instantiates: the bf16 conv kernels live in their own unit (gemm_conv.hip), the bf16 GEMM
     // kernels in gemm.hip, everything fp32 in gemm_f32.hip - three compilations that run in parallel.
     constexpr bool WITH_CONV = CVAR_TU_CONV || sizeof(T) == 4, WITH_PLAIN = CVAR_TU_PLAIN || sizeof(T) == 4;

@@ -30,7 +30,6 @@ struct GemmParams {
     int group_m;              // row tiles per scheduling group (see launch_cfg)
     int stagger;              // > 0: the first wave of workgroups (one per CU) starts spread over this many shader cycles (see cvar_gemm_kernel)
     int tile_cfg;             // cvar_gemm_desc::tile_cfg (0 = automatic)
-    int tpw;                  // output tiles per workgroup (cvar_gemm_kernel; set by launch_cfg)
 };
 
 

@@ -89,8 +89,6 @@ typedef struct {
      *                 fill their last round of the chip badly (N % 192 == 0, M >= 2048); bit-identical to the other tiles;
      *                 28: as 2, with the round-6 LDS-prefetched gate + residual epilogue (RPF) switched off - full 256x256 tiles of an fp32 gate + residual call then run the
      *                 register-prefetch epilogue that partial tiles always run; bit-identical (A/B measurements, tests);
-     *                 29: as 0, with one output tile per workgroup everywhere (round 6: big plain launches of the 256x256 tile give a workgroup two consecutive
-     *                 tiles; same results, A/B measurements);
      *   stagger       > 0: the first workgroup of every CU starts delayed by up to this many shader cycles (by its index), which
      *                 de-phases the output bursts of equally long tiles; 0: off.  Never changes results. */
     void* ws; int64_t ws_bytes;
