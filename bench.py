@@ -51,6 +51,7 @@ def parse(argv=None):
     ap.add_argument('--decode-chunk', type=int, default=0, help='images per VQVAE decoder pass (0 = the model default); A/B knob')
     ap.add_argument('--cpu-depth', type=int, default=0, help='depth of the CPU baseline model (0 = same as --depth)')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-probe', action='store_true', help='skip the MFMA probe behind roofline.sustained_peak / telemetry_probe (profiling passes: its launches would sit in the kernel stats)')
     ap.add_argument('--no-telemetry', action='store_true', help='do not sample socket power / gfx clock (AMD SMI) beside the timed region and the MFMA probe')
     ap.add_argument('--mode', default='infer', choices=['infer', 'train'],
                     help="infer (default, the BASELINE headline metric) | train: BASELINE config 3 - the d24 data-parallel training step, gradient "
@@ -317,7 +318,7 @@ def sustained_mfma(dev, launches=8, iters=6000, telemetry_s=1.5):
     res = {}
     for name, ops in (('randn', torch.randn(1 << 17, device=dev).to(torch.bfloat16)), ('zeros', torch.zeros(1 << 17, device=dev, dtype=torch.bfloat16))):
         st = torch.cuda.current_stream().cuda_stream
-        sink = torch.zeros(2, device=dev)
+        sink = torch.zeros(4, device=dev)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(launches + 1)]
         ev[0].record()
         for i in range(launches):
@@ -340,7 +341,21 @@ def sustained_mfma(dev, launches=8, iters=6000, telemetry_s=1.5):
                 torch.cuda.synchronize()
             tel = bs.summary(skip_first_s=0.3)
             tel['tflops'] = round(n * lib.cvar_probe_mfma_flops(iters) / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+            tel['mfma'] = 'v_mfma_f32_16x16x32_bf16'
             res[name + '_telemetry'] = tel
+            # the same stream on v_mfma_f32_32x32x16_bf16 (the guide's 2 495 TFLOP/s microbenchmark shape): issue rate and clock apart
+            with BoardSampler(dev.index or 0) as bs:
+                e0.record()
+                for i in range(n):
+                    _lib.check(lib.cvar_probe_mfma_bf16_32x32(ops.data_ptr(), ops.numel() * 2, iters, sink.data_ptr(), st), 'cvar_probe_mfma_bf16_32x32')
+                e1.record()
+                torch.cuda.synchronize()
+            tel = bs.summary(skip_first_s=0.3)
+            tel['tflops'] = round(n * lib.cvar_probe_mfma_flops(iters) / (e0.elapsed_time(e1) * 1e-3) / 1e12, 1)
+            tel['mfma'] = 'v_mfma_f32_32x32x16_bf16'
+            ticks, real = float(sink[1]), float(sink[2])
+            tel['s_memtime_ticks_per_us'] = round(ticks / (real / 100.0), 1) if real > 0 else None      # s_memrealtime runs at 100 MHz
+            res[name + '_telemetry_32x32'] = tel
     return res
 
 
@@ -597,11 +612,12 @@ def main_infer(a):
             peak = 2500.0 if a.dtype == 'bf16' else 157.3
             sustained = {}
             telemetry_probe = None
-            if a.dtype == 'bf16':
+            if a.dtype == 'bf16' and not a.no_probe:
                 try:
                     sm = sustained_mfma(dev, telemetry_s=0.0 if a.no_telemetry else 1.5)
                     if 'randn_telemetry' in sm:
-                        telemetry_probe = {'randn_operands': sm['randn_telemetry'], 'zero_operands': sm['zeros_telemetry']}
+                        telemetry_probe = {'randn_operands': sm['randn_telemetry'], 'zero_operands': sm['zeros_telemetry'],
+                                           'randn_operands_32x32x16': sm.get('randn_telemetry_32x32'), 'zero_operands_32x32x16': sm.get('zeros_telemetry_32x32')}
                     sustained = {'sustained_peak': round(sm['randn'], 1), 'frac_of_sustained': round(ach / sm['randn'], 4), 'peak_on_zero_operands': round(sm['zeros'], 1),
                                  'clock_ghz_randn_zeros': [round(sm['randn_ghz'], 2), round(sm['zeros_ghz'], 2)],
                                  'sustained_note': 'cvar_probe_mfma_bf16 in this run on this device: a register-fed stream of the GEMM\'s MFMA (v_mfma_f32_16x16x32_bf16, two waves '

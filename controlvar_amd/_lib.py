@@ -101,6 +101,7 @@ SIGNATURES = {
     'cvar_clip_coef': (c_i, [c_p, c_l, c_f, c_f, c_p, c_p]),
     # measurement aid (bench.py roofline.sustained_*)
     'cvar_probe_mfma_bf16': (c_i, [c_p, c_l, c_i, c_p, c_p]),
+    'cvar_probe_mfma_bf16_32x32': (c_i, [c_p, c_l, c_i, c_p, c_p]),
     'cvar_probe_mfma_flops': (C.c_double, [c_i]),
 }
 

@@ -208,6 +208,34 @@ __global__ __launch_bounds__(TW * 16, 2) void conv3x3_halo_bf16_kernel(const Con
                         else op[co] = f32_to_bf16(v);
                     }
                 }
+        } else if constexpr (CH_NB == 5 && sizeof(TO) == 4) {
+            // wide form with an fp32 output and an optional fp32 residual (round 6: the convs of the split-bf16 / fp32-stream encoder, models.VQVAE._hp_conv): straight from the
+            // accumulator layout - a lane's four consecutive couts are one 16-byte store; the residual quads of one 32-cout block are loaded just before it is finished
+            float* op = (float*)p.out + gpix * p.Cout + cout0 + 4 * hi;
+            const float* rp = p.res ? (const float*)p.res + gpix * p.Cout + cout0 + 4 * hi : nullptr;
+            const float* bp = p.bias ? p.bias + cout0 + 4 * hi : nullptr;
+#pragma unroll
+            for (int j = 0; j < CH_NB; ++j) {
+                f32x4_t rq[4];
+                if (rp) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) rq[g] = *(const f32x4_t*)(rp + 32 * j + 8 * g);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = 32 * j + 8 * g;
+                    f32x4_t bq = {0.f, 0.f, 0.f, 0.f};
+                    if (bp) bq = *(const f32x4_t*)(bp + co);
+                    f32x4_t v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] + bq[e];
+                    if (rp) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += rq[g][e];
+                    }
+                    *(f32x4_t*)(op + co) = v;
+                }
+            }
         } else if constexpr (CH_EPI_LDS != 0 && CH_NB == 5) {
             // Row-major epilogue through LDS (round 4).  In the accumulator layout a store instruction writes 16 B to each of 32 pixels (32 cache lines, 2 560
             // partial-line requests per wave and tile) and a residual load reads the same way; that burst also sits in front of the co-resident workgroup's
@@ -318,7 +346,7 @@ __global__ __launch_bounds__(TW * 16, 2) void conv3x3_halo_bf16_kernel(const Con
                 }
         }
     }
-    if constexpr (CH_NB == 5 && CH_EPI_LDS != 0) {
+    if constexpr (CH_NB == 5 && CH_EPI_LDS != 0 && sizeof(TO) == 2) {
         if (p.gn_part) {
             // per-lane partials -> the wave's slack -> 160 threads sum (wave, pixel residue) in a fixed order and write (S, Q, piv) of their channel
             constexpr int PS = 336, SLICE = (2 * CH_HALO_BYTES + 3 * CH_W_BYTES) / NW / 64 * 64, RED = 32 * PS + 512;
@@ -350,7 +378,7 @@ __global__ __launch_bounds__(TW * 16, 2) void conv3x3_halo_bf16_kernel(const Con
 }
 
 // (H, W: the OUTPUT grid) eligibility is checked by the caller (cvar_gemm): bf16 operands, stride 1, Cin % 32 == 0, H % 16 == 0, W % 16 == 0 and
-// either Cout % 160 == 0 with a bf16 output (optional bf16 residual) or Cout <= 32 without residual (bf16 or fp32 output: conv_out)
+// either Cout % 160 == 0 with a bf16 output (optional bf16 residual) or an fp32 output (optional FP32 residual; round 6), or Cout <= 32 without residual (bf16 or fp32 output: conv_out)
 int cvar_conv3x3_halo_bf16(const void* X, const void* Wt, const float* bias, const void* residual, void* out, int out_f32, int B, int H, int W, int Cin,
                            int Cout, int up, float* gn_part, hipStream_t st) {
     ConvHaloParams p;
@@ -361,7 +389,11 @@ int cvar_conv3x3_halo_bf16(const void* X, const void* Wt, const float* bias, con
     if (gn_part && !(Cout % 160 == 0 && !out_f32)) return CVAR_EUNSUPPORTED;      // only the wide form emits GroupNorm partials
     const long tiles = (long)B * p.tiles_x * p.tiles_y;
     if (tiles <= 0 || tiles > 0x7fffffffL) return CVAR_EINVAL;
-    if (Cout % 160 == 0 && !out_f32) {
+    if (Cout % 160 == 0 && out_f32) {
+        // round 6: fp32 output + optional fp32 residual (16-byte aligned, < 2^31 elements per image as below); no GroupNorm partials
+        if ((((uintptr_t)out | (uintptr_t)residual) & 15) != 0 || (long)H * W * Cout >= 0x7fffffffL) return CVAR_EUNSUPPORTED;
+        hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<5, float>), dim3((unsigned)tiles, Cout / 160), dim3(256), 0, st, p);
+    } else if (Cout % 160 == 0 && !out_f32) {
         // the row-major epilogue moves 16-byte vectors at 32-bit element offsets inside an image: callers whose output / residual are only
         // 8-byte aligned or whose images exceed 2^31 elements stay on the implicit-GEMM tiles
         if ((((uintptr_t)out | (uintptr_t)residual) & 15) != 0 || (long)H * W * Cout >= 0x7fffffffL) return CVAR_EUNSUPPORTED;

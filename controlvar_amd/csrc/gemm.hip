@@ -1464,7 +1464,11 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
         // (decided by the IMAGE size, not by the batch: the two kernels sum K in different orders, and an image's pixels must not depend on the batch it rides in)
         const bool narrow = d->N <= 32 && !d->residual && (d->out_dtype == CVAR_BF16 || d->out_dtype == CVAR_F32) && ((long)d->Hout * d->Wout >= 65536 || d->tile_cfg == 6);
         if (d->gn_part && !wide) return CVAR_EUNSUPPORTED;       // GroupNorm partials come out of the wide halo kernel only (cvar_conv3x3_gn_partials says which calls)
-        if (wide || narrow)
+        // round 6: the same kernel with an fp32 output and an fp32 residual - the 3x3 convs of the split-bf16 encoder (fp32 activation stream, 3 x Cin split channels)
+        const bool wide32 = d->N % 160 == 0 && d->out_dtype == CVAR_F32 && (((uintptr_t)d->C & 15) == 0) && !d->up &&
+                            (!d->residual || (d->res_dtype == CVAR_F32 && d->ldr == d->N && (((uintptr_t)d->residual & 15) == 0))) &&
+                            (long)d->Hout * d->Wout * d->N < 0x7fffffffL;
+        if (wide || narrow || wide32)
             return cvar_conv3x3_halo_bf16(d->A, d->W, d->bias, d->residual, d->C, d->out_dtype == CVAR_F32, d->M / (d->Hout * d->Wout), d->Hout, d->Wout, d->Cin,
                                           d->N, d->up, d->gn_part, st);
     }

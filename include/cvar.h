@@ -374,6 +374,9 @@ int cvar_rle_paint(const int* run_ends, const int* ann_offsets, const void* colo
  * kind is the ceiling a GEMM kernel can approach by scheduling alone on that device; on zeros it reaches the 2.4 GHz peak.
  * cvar_probe_mfma_flops(iters) = flop of one launch. */
 int cvar_probe_mfma_bf16(const void* operands, int64_t operand_bytes, int iters, float* sink, void* stream);
+/* ABI 20: the same stream on v_mfma_f32_32x32x16_bf16 (2 x 2 blocks of 32x32, same flop count per round); sink: 3 floats - [1] s_memtime ticks, [2] s_memrealtime
+ * ticks (100 MHz) of one wave's loop.  Tells issue rate from clock beside the 16x16x32 probe (bench.py roofline.telemetry_probe). */
+int cvar_probe_mfma_bf16_32x32(const void* operands, int64_t operand_bytes, int iters, float* sink, void* stream);
 double cvar_probe_mfma_flops(int iters);
 
 #ifdef __cplusplus

@@ -144,3 +144,36 @@ def test_conv_with_a_misaligned_bias_falls_back_to_the_statistics_pass(gpu_devic
     # (the statistics pass sums in another order than the conv's partials: the GroupNorm coefficients move by ~1 ulp and bf16 roundings behind it flip - the features
     #  agree to bf16 noise, which is what the ids of a bf16 encoder are sensitive to anyway: 0.83 id agreement between the two routes on this input)
     assert float((got - want).abs().max()) < 0.05 * float(want.abs().max())
+
+
+@pytest.mark.parametrize('with_res', [False, True])
+def test_halo_conv_fp32_output_form_equals_the_implicit_gemm_tiles(gpu_device, with_res):
+    """round 6: the LDS-halo 3x3 kernel with an fp32 output (+ fp32 residual) - the form the split-bf16 encoder's convs take (480 = 3 x 160 split channels -> 160) -
+    against the implicit-GEMM tiles on the same operands (tile_cfg 5 keeps a conv there; the two sum K in different orders: chunk-major vs tap-major) and against torch."""
+    import torch.nn.functional as F
+    B, H, Cin, Cout = 2, 32, 480, 320
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(B * H * H, Cin, generator=g).to(BF16).to(gpu_device)
+    w = (torch.randn(Cout, 9 * Cin, generator=g) / (9 * Cin) ** 0.5).to(BF16).to(gpu_device)
+    b = torch.randn(Cout, generator=g).to(gpu_device)
+    res = torch.randn(B * H * H, Cout, generator=g).to(gpu_device) if with_res else None
+    outs = []
+    for cfg in (0, 5):
+        old = ops.GEMM_TILE_CFG
+        try:
+            ops.GEMM_TILE_CFG = cfg
+            out = torch.full((B * H * H + 3, Cout), float('nan'), device=gpu_device)
+            ops.gemm(x, w, out, M=B * H * H, N=Cout, K=9 * Cin, bias=b, residual=res, conv=dict(Hin=H, Win=H, Cin=Cin, Hout=H, Wout=H, stride=1, up=0))
+            torch.cuda.synchronize()
+            assert torch.isnan(out[B * H * H:]).all()
+            outs.append(out[:B * H * H].clone())
+        finally:
+            ops.GEMM_TILE_CFG = old
+    xr = x.float().view(B, H, H, Cin).permute(0, 3, 1, 2)
+    wr = w.float().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    ref = F.conv2d(xr, wr, b, padding=1).permute(0, 2, 3, 1).reshape(B * H * H, Cout)
+    if with_res:
+        ref = ref + res
+    sc = float(ref.abs().max())
+    assert float((outs[0] - ref).abs().max()) < 2e-5 * sc + 1e-4
+    assert float((outs[0] - outs[1]).abs().max()) < 2e-5 * sc + 1e-4

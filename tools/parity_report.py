@@ -30,10 +30,11 @@ def main():
         env = dict(os.environ, CVAR_PARITY_REPORT=a.jsonl)
         rc = subprocess.call([sys.executable, '-m', 'pytest', os.path.join(ROOT, 'tests'), '-q', '-m', 'gpu', '-x'], env=env, cwd=ROOT)
     recs = [json.loads(l) for l in open(a.jsonl)] if os.path.exists(a.jsonl) else []
-    ids, bf = {}, {}
+    ids, bf, other = {}, {}, {}
     for r in recs:
-        (ids if r.get('kind') == 'ids' else bf)[r['what']] = {k: v for k, v in r.items() if k not in ('what', 'kind')}     # last run of a name wins
-    strict = {k: v for k, v in ids.items() if v['strict']}
+        kind = r.get('kind')
+        (ids if kind == 'ids' else (bf if kind in ('bf16_logits', 'bf16', None) else other))[r['what']] = {k: v for k, v in r.items() if k != 'what'}     # last run of a name wins
+    strict = {k: v for k, v in ids.items() if v.get('strict')}
     out = {
         'pytest_rc': rc,
         'summary': {'fixtures_strict': len(strict), 'ids_compared_strict': sum(v['total'] for v in strict.values()),
@@ -41,6 +42,7 @@ def main():
                     'fixtures_margin_bounded': len(ids) - len(strict), 'ids_compared_margin_bounded': sum(v['total'] for k, v in ids.items() if k not in strict),
                     'flips_margin_bounded': sum(v['flips'] for k, v in ids.items() if k not in strict)},
         'ids': ids, 'bf16_logits': bf,
+        'other': other,           # round 6: encoder precisions (id agreement, PSNR), the two-rank data-parallel step (gradient / parameter distances, bytes exchanged)
     }
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(out, open(a.out, 'w'), indent=1)
