@@ -201,6 +201,23 @@ def side_configs(a, dev, box):
         out[f'small_batch_b{Bs}'] = {'value': round(Bs / g, 1), 'unit': 'images/s', 'steps': 3, 'ms_per_step': round(g * 1e3, 2),
                                      'config': f'd{a.depth} autoregressive_infer_cfg B={Bs}, one HIP graph per generation, incl. the decode'}
         del run
+    # deterministic_plan (round 6): every transformer GEMM on the unsliced tile kernels, so that one (label, g_seed) is bit-identical at any batch size - what that costs
+    # where the small-M plans matter
+    try:
+        var.deterministic_plan = True
+        det = {}
+        for Bs in (1, 8, 32):
+            ls, ts = torch.arange(Bs, device=dev) % 1000, torch.arange(Bs, device=dev) % 4
+            run = var.graphed_generator(Bs, cfg=a.cfg, top_k=a.top_k, top_p=a.top_p)
+            g = _timeit(lambda i: run(ls, ts, g_seed=i), 3, 1)
+            base = out['latency_b1_ms']['ms_per_step'] if Bs == 1 else out[f'small_batch_b{Bs}']['ms_per_step']
+            det[f'b{Bs}_ms'] = round(g * 1e3, 2)
+            det[f'b{Bs}_cost_vs_default_plan'] = round(g * 1e3 / base, 3)
+            del run
+        out['deterministic_plan'] = {'value': det['b1_ms'], 'unit': 'ms', 'steps': 3, 'ms_per_step': det['b1_ms'], **det,
+                                     'config': f'd{a.depth} autoregressive_infer_cfg as one HIP graph with deterministic_plan=True (tile kernels only, no K slices: same bits at any batch size), B = 1 / 8 / 32'}
+    finally:
+        var.deterministic_plan = False
     var._arena = None
     del var
     torch.cuda.empty_cache()

@@ -824,8 +824,9 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p, const int vb
                 stage_block(i, half);
                 // 16x16-block staging with idle lanes in the row-major phase (LPR does not divide 64, e.g. the 64x96 wave tile): an idle lane never reads the staging
                 // region itself, so from ITS point of view every staging store but the last is dead and the compiler predicates them on lane_on - but the
-                // other lanes of the wave read those bytes.  A compiler-level memory clobber keeps the stores (no instruction; only these instantiations).
-                if constexpr (M16 && (64 % LPR) != 0) asm volatile("" ::: "memory");
+                // other lanes of the wave read those bytes.  A wavefront-scope release fence (the staging stores must be performed before anything behind it) plus a
+                // wave barrier keep them - no instruction either; only these instantiations (the documented primitives instead of an empty asm clobber).
+                if constexpr (M16 && (64 % LPR) != 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) {
                     const int roff = i * 32 + 16 * half + ps * RPP;          // wave-uniform, known at compile time
@@ -923,7 +924,7 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p, const int vb
         const unsigned long long te0 = __builtin_amdgcn_s_memtime();
 #endif
         stage_block(i, half);
-        if constexpr (M16 && (64 % LPR) != 0) asm volatile("" ::: "memory");          // see the specialised loop above
+        if constexpr (M16 && (64 % LPR) != 0) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }          // see the specialised loop above
 #ifdef CVAR_GEMM_TIMING
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned long long te1 = __builtin_amdgcn_s_memtime();

@@ -681,7 +681,7 @@ class ControlVAR(nn.Module):
                  compute_dtype=None, init_seed: int = 0, deterministic_plan: bool = False):
         """deterministic_plan (an addition of this library): every transformer GEMM runs on the unsliced tile kernels whatever its row count - no small-M weight-streaming
         kernel, no K slices - so the fp32 summation order of a row does not depend on how many rows ride beside it, and one (label, condition, g_seed) in batch row 0 gives
-        the same logits and tokens BIT FOR BIT at any batch size (default False: the small-M plans are 1.3-2x faster at B <= 8 and move bf16 logits by ~5e-3 of
+        the same logits and tokens BIT FOR BIT at any batch size (default False: the small-M plans are 2.0x / 1.24x / 1.05x faster at B = 1 / 8 / 32 and move bf16 logits by ~5e-3 of
         max|logit| between batch sizes; tests/test_gpu_configs.py).  Can also be flipped on a built model: ``model.deterministic_plan = True``."""
         super().__init__()
         self.deterministic_plan = bool(deterministic_plan)
