@@ -90,6 +90,11 @@ def one(case):
     use_gate = (not conv) and rng.random() < 0.3
     use_res = rng.random() < 0.4
     out_dtype = rng.choice([dtype, torch.float32])
+    # round 6: a tenth of the big bf16 GEMMs as proj / fc2 issue them (gate + fp32 residual + fp32 output, no activation) on the forced 256x256 tile: full tiles take the
+    # LDS-prefetched read-modify-write epilogue (RPF), ragged last tiles the register form, in one launch
+    rpf = (not conv) and dtype == torch.bfloat16 and M >= 2048 and N >= 256 and rng.random() < 0.35
+    if rpf:
+        act, use_gate, use_res, out_dtype = ACT_NONE, True, True, torch.float32
     y = ref.clone()
     if bias is not None: y = y + bias
     if act == ACT_GELU_TANH: y = F.gelu(y, approximate='tanh')
@@ -97,13 +102,13 @@ def one(case):
     if use_gate:
         gt = torch.randn((M + gate_rows - 1) // gate_rows, N, generator=g)
         y = y * gt.repeat_interleave(gate_rows, 0)[:M]
-    res_dtype = rng.choice([dtype, torch.float32])
+    res_dtype = torch.float32 if rpf else rng.choice([dtype, torch.float32])
     if use_res:
         r = torch.randn(M, N, generator=g)
         y = y + r.to(res_dtype).float()
     # KV-arena style output row remap (qkv GEMM): row m -> (m // l) * L + off + m % l
     remap = None
-    if (not conv) and (not use_res) and rng.random() < 0.3:
+    if (not conv) and (not use_res) and (not rpf) and rng.random() < 0.3:
         l = rng.choice([1, 2, 8, 50, 128, 200])
         L = l + rng.choice([0, 7, 100]); off = rng.randint(0, L - l)
         remap = (l, L, off)
@@ -112,10 +117,11 @@ def one(case):
     # eligible 3x3 convs: force the LDS-halo kernel (tile_cfg 6) on most of them, whatever the grid size; the rest stay on the implicit GEMM
     ops.GEMM_TILE_CFG = 6 if conv and rng.random() < 0.8 else 0
     # plain bf16 GEMMs: a quarter of them forced onto the 256x192 tile (tile_cfg 27; in the automatic plan it only takes launches with badly filled last rounds)
-    t192 = (not conv) and dtype == torch.bfloat16 and rng.random() < 0.25
+    t192 = (not conv) and (not rpf) and dtype == torch.bfloat16 and rng.random() < 0.25
     if t192: ops.GEMM_TILE_CFG = 27; desc += ' [tile_cfg 27]'
+    if rpf: ops.GEMM_TILE_CFG = 2; desc += ' [rpf: tile_cfg 2]'
     # plain GEMMs: half of them as the transformer issues its passes (tile_cfg 12: streaming small-M kernel / three-stage tiles where their plan applies)
-    small = (not conv) and (not t192) and rng.random() < 0.5
+    small = (not conv) and (not t192) and (not rpf) and rng.random() < 0.5
     if small: desc += ' [small_m]'
     ops.gemm(A, Wd, out, M=M, N=N, K=K, bias=arena(bias, torch.float32) if bias is not None else None, act=act,
              gate=arena(gt, torch.float32) if use_gate else None, ldg=N if use_gate else 0, gate_rows=gate_rows,

@@ -10,6 +10,7 @@ M = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 print(f'lib {os.environ.get("CVAR_LIB", "default")}  data {os.environ.get("ISO_DATA", "randn")}  tile_cfg {os.environ.get("ISO_CFG", "0")}')
 ops.GEMM_TILE_CFG = int(os.environ.get('ISO_CFG', '0'))      # 0 automatic, 2 8-wave 256x256, 3 4-wave 256x256 (128x128 per wave)
+ops.GEMM_GROUP_M = int(os.environ.get('ISO_GM', '0'))          # row tiles per scheduling group (0 = automatic)
 EPI = os.environ.get('ISO_EPI') == '1'          # the epilogues the transformer uses: GELU (fc1), bias + gate + fp32 residual in place (fc2 / proj)
 for N, K in ((4608, 1536), (6144, 1536), (1536, 6144), (1536, 1536)):
     A = torch.randn(M, K, device=dev).to(T); W = (torch.randn(N, K, device=dev) / K ** 0.5).to(T)
