@@ -162,3 +162,48 @@ def test_unbuilt_variant_flags_fail_loudly_and_indep_defaults_follow_upstream():
     assert torch.equal(m.state_dict()['attn_bias_for_masking'], f.state_dict()['attn_bias_for_masking'])
     s = models.build_control_var(vae, depth=2, mask_type='interleave_append', multi_cond=True, separate_decoding=True, indep=True)
     assert not torch.equal(s.state_dict()['attn_bias_for_masking'], f.state_dict()['attn_bias_for_masking'])
+
+
+# ------------------------------------------------------------------------------------------------ round 6: host-side additions
+def test_board_sampler_degrades_without_a_device():
+    """controlvar_amd.telemetry is a measurement aid: without an AMD SMI device (this container) it must report 'unavailable' with a reason and never raise"""
+    from controlvar_amd.telemetry import BoardSampler
+    with BoardSampler(0, period_s=0.01) as bs:
+        pass
+    s = bs.summary()
+    assert isinstance(s, dict) and 'available' in s
+    if not s['available']:
+        assert s.get('reason')
+
+
+def test_encoder_precision_and_deterministic_plan_keywords():
+    """the two constructor keywords this library adds: validated at build time, no GPU needed"""
+    import torch
+    from controlvar_amd import models
+    for ep in ('bf16', 'bf16x3', 'fp32'):
+        assert models.build_vae(ch=32, compute_dtype=torch.bfloat16, encoder_precision=ep).encoder_precision == ep
+    assert models.build_vae(ch=32, compute_dtype=torch.bfloat16).encoder_precision == 'bf16'
+    assert models.build_vae(ch=32, compute_dtype=torch.float32).encoder_precision == 'fp32'
+    with pytest.raises(ValueError):
+        models.build_vae(ch=32, compute_dtype=torch.bfloat16, encoder_precision='fp8')
+    with pytest.raises(ValueError):
+        models.build_vae(ch=32, compute_dtype=torch.float32, encoder_precision='bf16x3')      # an fp32 model encodes in fp32
+    vae = models.build_vae(ch=32)
+    m = models.build_control_var(vae, depth=2, mask_type='interleave_append', multi_cond=True, deterministic_plan=True)
+    assert m.deterministic_plan is True
+    assert models.build_control_var(vae, depth=2, mask_type='interleave_append', multi_cond=True).deterministic_plan is False
+    assert models.build_var(vae, depth=2, deterministic_plan=True).deterministic_plan is True
+
+
+def test_current_md_and_readme_table_regenerate_from_the_committed_profiles(tmp_path):
+    """profiles/CURRENT.md and README's numbers table are generated files: the generators must run on the committed evidence (tools/current_md.py, tools/fill_readme.py)"""
+    import subprocess, sys, glob
+    lines = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_default_line.json')))
+    if not lines:
+        pytest.skip('no bench line under profiles/')
+    tag = os.path.basename(lines[-1]).split('_')[0]
+    out = tmp_path / 'CURRENT.md'
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'current_md.py'), tag, str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    txt = out.read_text()
+    assert 'images/s' in txt and 'frac' in txt and len(txt.splitlines()) <= 80
