@@ -609,6 +609,15 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p, const int vb
 #ifndef CVAR_GEMM_RPF
 #define CVAR_GEMM_RPF 1
 #endif
+#ifndef CVAR_RPF_LD_AUX
+#define CVAR_RPF_LD_AUX 2      // cache policy of the residual DMA / of the fp32 stores of the RPF epilogue (gfx940+: 2 = nt): x is read once and written once per call
+#endif
+#ifndef CVAR_GEMM_ST_NT
+#define CVAR_GEMM_ST_NT 1      // the specialised epilogues of the plain GEMM tiles (256-row tiles: M >= 2048) store non-temporally - streaming outputs no longer evict the operand panels from the L2s (profiles/r06_nt_policy_ab.txt)
+#endif
+#ifndef CVAR_RPF_ST_AUX
+#define CVAR_RPF_ST_AUX 2
+#endif
     // RPF tile: the eight-wave 256x256 bf16 GEMM (16-row staging, 64 columns per wave = 8 lanes per row, two 8-row passes per half-pass); its launch allocates 32 KB
     // behind the pipeline stages (launch_cfg) - see the RPF epilogue below
     constexpr bool RPF_TILE = (CVAR_GEMM_RPF != 0) && M16 && !CONV && FAST && ES == 2 && BM == 256 && BN == 256 && NW == 8 && SUB_N == 64 && SUB_M == 128 && NSTAGE == 2;
@@ -699,7 +708,7 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p, const int vb
                     auto issue_res = [&](int h) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lptr_t)(slot(h) + q * 1024), 16, dma_lane, (h * 16 + q * 4) * ldr4, 0, 0);
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_rsrc, (lptr_t)(slot(h) + q * 1024), 16, dma_lane, (h * 16 + q * 4) * ldr4, 0, CVAR_RPF_LD_AUX);
                     };
                     f32x4_t gq2[2][2][2];
                     auto fetch_gate = [&](int h) {
@@ -763,8 +772,8 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p, const int vb
                             // instruction is not using a register in the soffset field") - on gfx950 a quarter of the lanes then stored the NEW register contents
                             // (last half-pass of every wave tile, nondeterministic; found by the bit-identity test of this path, profiles/r06_rpf_ab.txt)
                             const int st_off = st_lane + (h * 16 + ps * 8) * ldc4;
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_t, o0), c_rsrc, st_off, 0, 0);
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_t, o1), c_rsrc, st_off + 16, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_t, o0), c_rsrc, st_off, 0, CVAR_RPF_ST_AUX);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i_t, o1), c_rsrc, st_off + 16, 0, CVAR_RPF_ST_AUX);
                         }
                         if (h + 3 < NH) issue_res(h + 3);
                     }
@@ -878,10 +887,12 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p, const int vb
                             }
                         }
                         if constexpr (out_bf) {
-                            *(bf16x8_t*)cp = pack_bf16x8(v);
+                            if constexpr (CVAR_GEMM_ST_NT != 0 && !CONV) __builtin_nontemporal_store(pack_bf16x8(v), (bf16x8_t*)cp);
+                            else *(bf16x8_t*)cp = pack_bf16x8(v);
                         } else {
                             const f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                            *(f32x4_t*)cp = o0; *(f32x4_t*)(cp + 16) = o1;
+                            if constexpr (CVAR_GEMM_ST_NT != 0 && !CONV) { __builtin_nontemporal_store(o0, (f32x4_t*)cp); __builtin_nontemporal_store(o1, (f32x4_t*)(cp + 16)); }
+                            else { *(f32x4_t*)cp = o0; *(f32x4_t*)(cp + 16) = o1; }
                         }
                     }
                 }
@@ -1068,10 +1079,11 @@ __device__ __forceinline__ void splitk_finish_quad(const GemmParams& p, const fl
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is sticky per (function, device): set it the first time a kernel is launched on a
-// device instead of on every launch (~1200 launches per generation)
+// device instead of on every launch (~1200 launches per generation).  `done` is the caller's table for THIS kernel (launch_cfg holds one per kernel it can launch:
+// every instantiation has the same function-pointer type, so a table keyed by that type - the form before round 6 - was shared by all of them and only the first
+// kernel a process launched ever got the attribute; ROCm does not enforce it, which is why that went unnoticed)
 template <typename K>
-static void set_max_lds_once(K kfn, size_t lds) {
-    static unsigned char done[64] = {0};          // one table per kernel instantiation
+static void set_max_lds_once(K kfn, size_t lds, unsigned char* done) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (dev < 0 || dev >= 64 || !done[dev]) {
@@ -1105,7 +1117,8 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
         if (!p.conv) return CVAR_EINVAL;
         if constexpr (WITH_CONV) {
             auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, true, NSTAGE, true, CUP>;
-            set_max_lds_once(kfn, lds);
+            static unsigned char lds_set[64] = {0};
+            set_max_lds_once(kfn, lds, lds_set);
             hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
             CVAR_CHECK_LAUNCH();
             return CVAR_OK;
@@ -1113,18 +1126,21 @@ static int launch_cfg(const GemmParams& gp, int batch, hipStream_t st) {
     } else if (p.conv) {
         if constexpr (WITH_CONV) {
             auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, true, NSTAGE>;
-            set_max_lds_once(kfn, lds);
+            static unsigned char lds_set[64] = {0};
+            set_max_lds_once(kfn, lds, lds_set);
             hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
         } else return CVAR_EUNSUPPORTED;
     } else if constexpr (!WITH_PLAIN) {
         return CVAR_EUNSUPPORTED;
     } else if (plain_fast) {
         auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, false, NSTAGE, true>;
-        set_max_lds_once(kfn, lds);
+        static unsigned char lds_set[64] = {0};
+        set_max_lds_once(kfn, lds, lds_set);
         hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
     } else {
         auto kfn = cvar_gemm_kernel<T, BM, BN, WM, WN, false, NSTAGE>;
-        set_max_lds_once(kfn, lds);
+        static unsigned char lds_set[64] = {0};
+        set_max_lds_once(kfn, lds, lds_set);
         hipLaunchKernelGGL(kfn, grid, block, lds, st, p);
     }
     CVAR_CHECK_LAUNCH();
