@@ -692,7 +692,7 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p, const int vb
             // every count below is static because nothing in this path is predicated) waits for exactly its own four pieces.  Stores and gate loads go through
             // buffer instructions on scalar bases + 32-bit offsets.  Same arithmetic in the same order as the register form: bit-identical results.
             if constexpr (RPF_TILE && gate && res == 1 && !out_bf && !remap && act == CVAR_ACT_NONE) {
-                const bool rpf_ok = vec_ok && m0 + BM <= p.M && n0 + BN <= p.N && !p.C2 && !p.gate_scale && p.tile_cfg != 28 &&
+                const bool rpf_ok = vec_ok && m0 + BM <= p.M && n0 + BN <= p.N && !p.C2 && !p.gate_scale && p.tile_cfg != 28 && (p.nt || p.tile_cfg == 2) &&
                                     ((long)(p.M / max(p.gate_rows, 1) + 1) * p.ldg * 4 < 0x7fffffffL) && (long)SUB_M * p.ldr * 4 < 0x7fffffffL && (long)SUB_M * p.ldc * 4 < 0x7fffffffL;
                 if (rpf_ok) {
                     const int mw = m0 + wm * SUB_M, nw = n0 + wn * SUB_N;
@@ -887,11 +887,11 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p, const int vb
                             }
                         }
                         if constexpr (out_bf) {
-                            if constexpr (CVAR_GEMM_ST_NT != 0 && !CONV) __builtin_nontemporal_store(pack_bf16x8(v), (bf16x8_t*)cp);
+                            if (CVAR_GEMM_ST_NT != 0 && !CONV && p.nt) __builtin_nontemporal_store(pack_bf16x8(v), (bf16x8_t*)cp);
                             else *(bf16x8_t*)cp = pack_bf16x8(v);
                         } else {
                             const f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                            if constexpr (CVAR_GEMM_ST_NT != 0 && !CONV) { __builtin_nontemporal_store(o0, (f32x4_t*)cp); __builtin_nontemporal_store(o1, (f32x4_t*)(cp + 16)); }
+                            if (CVAR_GEMM_ST_NT != 0 && !CONV && p.nt) { __builtin_nontemporal_store(o0, (f32x4_t*)cp); __builtin_nontemporal_store(o1, (f32x4_t*)(cp + 16)); }
                             else { *(f32x4_t*)cp = o0; *(f32x4_t*)(cp + 16) = o1; }
                         }
                     }
@@ -1362,6 +1362,10 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     make_fast_div(p.gate ? p.gate_rows : 1, &p.gate_magic, &p.gate_shift);
     p.split_tiles = 0; p.split_stride = 0;
     p.tile_cfg = d->tile_cfg; p.stagger = d->stagger > 0 ? d->stagger : 0; p.group_m = d->group_m > 0 ? d->group_m : 0;
+    // round 6: outputs far beyond the L2s (32 MB) and the better part of the Infinity Cache stream - the specialised epilogues of the 256-row tiles store them non-temporally and
+    // the fp32 read-modify-write of proj / fc2 takes its LDS-prefetched form; mid-size passes (B = 8: 25-100 MB per tensor) keep the default policy, which still finds them
+    // in the caches when the next kernel reads them (B = 8: 133 -> 128.6 images/s with the policy on everything, profiles/r06_nt_policy_ab.txt)
+    p.nt = ((long)d->M * d->N * (d->out_dtype == CVAR_F32 ? 4 : 2) >= (128L << 20)) ? 1 : 0;
     // split-K workspace: part of the call (caller-owned, any stream / device), nothing process-wide
     float* const g_splitk_ws = (d->ws && d->ws_bytes > 0 && (((uintptr_t)d->ws & 15) == 0)) ? (float*)d->ws : nullptr;
     const size_t g_splitk_ws_bytes = g_splitk_ws ? (size_t)d->ws_bytes : 0;

@@ -30,6 +30,7 @@ struct GemmParams {
     int group_m;              // row tiles per scheduling group (see launch_cfg)
     int stagger;              // > 0: the first wave of workgroups (one per CU) starts spread over this many shader cycles (see cvar_gemm_kernel)
     int tile_cfg;             // cvar_gemm_desc::tile_cfg (0 = automatic)
+    int nt;                   // 1: the output streams (>= 128 MB): non-temporal stores in the specialised epilogues, RPF for the fp32 read-modify-write (set by cvar_gemm)
 };
 
 
