@@ -1046,3 +1046,43 @@ def test_gemm_gate_residual_lds_prefetch_equals_the_register_form(gpu_device, M,
     acc = A.float() @ W.float().t() + b
     ref = x0 + acc * gate[:, N:2 * N].repeat_interleave(l, dim=0)[:M]
     assert (outs[0] - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize('kind', ['plain', 'gelu', 'gate', 'f32'])
+def test_gemm_streaming_policy_changes_no_bit(gpu_device, kind):
+    """round 6: `cvar_gemm` treats outputs of >= 128 MB as streams - non-temporal stores in the specialised epilogues of the 256-row tiles, the LDS-prefetched
+    read-modify-write (RPF) for proj / fc2 - and smaller ones as before.  The policy must not change a bit: one call over M rows (above the threshold) against the same
+    problem issued as two calls over M / 2 rows each (below it).  The parity fixtures run at small batches and never reach the threshold; this test and the bench do."""
+    K = 256
+    M, N = (40960, 1536) if kind in ('gate', 'f32') else (40960, 2048)           # fp32: 251 MB / 126 MB per half; bf16: 168 MB / 84 MB per half
+    g = torch.Generator().manual_seed(7)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(gpu_device)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(gpu_device)
+    b = torch.randn(N, generator=g).to(gpu_device)
+    l = 512
+    gate = torch.randn(M // l, N, generator=g).to(gpu_device)
+    x0 = torch.randn(M, N, generator=g).to(gpu_device) if kind == 'gate' else None
+    odt = torch.float32 if kind in ('gate', 'f32') else torch.bfloat16
+    assert M * N * (4 if odt == torch.float32 else 2) >= 128 << 20 > (M // 2) * N * (4 if odt == torch.float32 else 2)
+
+    def call(a, out, g_rows):
+        m = a.shape[0]
+        if kind == 'gate':
+            ops.gemm(a, W, out, M=m, N=N, K=K, bias=b, gate=g_rows, ldg=N, gate_rows=l, residual=out)
+        else:
+            ops.gemm(a, W, out, M=m, N=N, K=K, bias=b, act=ACT_GELU_TANH if kind == 'gelu' else 0)
+
+    whole = x0.clone() if kind == 'gate' else torch.empty(M, N, device=gpu_device, dtype=odt)
+    call(A, whole, gate)
+    halves = x0.clone() if kind == 'gate' else torch.empty(M, N, device=gpu_device, dtype=odt)
+    h = M // 2
+    call(A[:h], halves[:h], gate[:h // l])
+    call(A[h:], halves[h:], gate[h // l:])
+    torch.cuda.synchronize()
+    assert torch.equal(whole, halves)
+    ref = A[:512].float() @ W.float().t() + b
+    if kind == 'gelu':
+        ref = F.gelu(ref, approximate='tanh')
+    if kind == 'gate':
+        ref = x0[:512] + ref * gate[:1]
+    assert (whole[:512].float() - ref).abs().max().item() < 3e-2 * max(1.0, ref.abs().max().item())
