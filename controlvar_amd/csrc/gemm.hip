@@ -1365,10 +1365,7 @@ extern "C" int cvar_gemm(const cvar_gemm_desc* d, void* stream) {
     // round 6: outputs far beyond the L2s (32 MB) and the better part of the Infinity Cache stream - the specialised epilogues of the 256-row tiles store them non-temporally and
     // the fp32 read-modify-write of proj / fc2 takes its LDS-prefetched form; mid-size passes (B = 8: 25-100 MB per tensor) keep the default policy, which still finds them
     // in the caches when the next kernel reads them (B = 8: 133 -> 128.6 images/s with the policy on everything, profiles/r06_nt_policy_ab.txt)
-#ifndef CVAR_NT_MIN_MB
-#define CVAR_NT_MIN_MB 128
-#endif
-    p.nt = ((long)d->M * d->N * (d->out_dtype == CVAR_F32 ? 4 : 2) >= ((long)CVAR_NT_MIN_MB << 20)) ? 1 : 0;
+    p.nt = ((long)d->M * d->N * (d->out_dtype == CVAR_F32 ? 4 : 2) >= (128L << 20)) ? 1 : 0;
     // split-K workspace: part of the call (caller-owned, any stream / device), nothing process-wide
     float* const g_splitk_ws = (d->ws && d->ws_bytes > 0 && (((uintptr_t)d->ws & 15) == 0)) ? (float*)d->ws : nullptr;
     const size_t g_splitk_ws_bytes = g_splitk_ws ? (size_t)d->ws_bytes : 0;
