@@ -691,6 +691,8 @@ __device__ __forceinline__ void cvar_gemm_tile(const GemmParams& p, const int vb
             // are issued when half-pass h has consumed its slot, and one counted vmcnt in front of a half-pass (loads, stores and DMA retire in issue order on gfx9;
             // every count below is static because nothing in this path is predicated) waits for exactly its own four pieces.  Stores and gate loads go through
             // buffer instructions on scalar bases + 32-bit offsets.  Same arithmetic in the same order as the register form: bit-identical results.
+            // Taken by calls whose output streams (p.nt, set by cvar_gemm for outputs of >= 128 MB: the ring's DMA and the stores then carry the non-temporal bit - x is
+            // read once and written once per call) and by tile_cfg 2 (tests, A/B runs); smaller calls, partial tiles and tile_cfg 28 run the register form.
             if constexpr (RPF_TILE && gate && res == 1 && !out_bf && !remap && act == CVAR_ACT_NONE) {
                 const bool rpf_ok = vec_ok && m0 + BM <= p.M && n0 + BN <= p.N && !p.C2 && !p.gate_scale && p.tile_cfg != 28 && (p.nt || p.tile_cfg == 2) &&
                                     ((long)(p.M / max(p.gate_rows, 1) + 1) * p.ldg * 4 < 0x7fffffffL) && (long)SUB_M * p.ldr * 4 < 0x7fffffffL && (long)SUB_M * p.ldc * 4 < 0x7fffffffL;

@@ -119,6 +119,9 @@ typedef struct {
      * CVAR_EUNSUPPORTED (never silently skips). */
     float* gn_part;
 } cvar_gemm_desc;
+/* Cache policy (round 6; nothing to set): a call whose output is >= 128 MB is treated as a stream - the specialised epilogues of the 256-row tiles store it non-temporally
+ * and the fp32 gate + residual read-modify-write (proj / fc2) takes its LDS-prefetched form with non-temporal residual reads - so that it does not evict the operand panels
+ * the CUs of an XCD share in their L2; smaller outputs keep the default policy.  Results do not depend on it (tests/test_gpu_kernels.py::test_gemm_streaming_policy_changes_no_bit). */
 int cvar_gemm(const cvar_gemm_desc* d, void* stream);
 /* 1 (and the partial geometry) when a conv of this shape honours cvar_gemm_desc.gn_part, else 0 */
 int cvar_conv3x3_gn_partials(int dtype, int stride, int Cin, int Cout, int Hin, int Win, int Hout, int Wout, int* tiles_per_image, int* pixels_per_tile);
